@@ -1,0 +1,227 @@
+/* minsdtf_hip.h — C ABI of libminsdtf_hip.so: the MI355X (gfx950) kernels behind the
+ * SD1.5 denoise hot path of cpuimage/minSDTF.
+ *
+ * The reference has no native / FFI boundary (it is pure Python over Keras), so
+ * there is no reference header to mirror.  Each entry point below replaces the stock Keras op(s)
+ * the reference's hot path invokes; the reference call site is cited per function
+ * (paths relative to /root/reference/stable_diffusion/).
+ *
+ * Conventions
+ *  - every pointer is a raw DEVICE pointer (hipMalloc / torch tensor.data_ptr()); the caller owns
+ *    all memory, including workspaces; nothing is allocated or freed inside the library;
+ *  - activations are NHWC ("channels_last", like the reference's Keras tensors), bf16 unless noted;
+ *  - `stream` is a hipStream_t; all work is stream-ordered, never synchronises, and is capturable
+ *    into a hipGraph;
+ *  - return value: 0 on success, a negative MSD_E_* code for an argument error (nothing was
+ *    launched), or a positive hipError_t from the launch; msd_last_error() gives the text;
+ *  - `step_ptr` (nullable) points at a device int32 holding the current denoise-step index, so a
+ *    captured step graph can be replayed for every step: per-step tables (time-embedding
+ *    projections, scheduler coefficients) are indexed with it on the device.
+ */
+#ifndef MINSDTF_HIP_H
+#define MINSDTF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSD_ABI_VERSION 1
+
+#define MSD_OK 0
+#define MSD_E_ARG (-1)      /* bad / inconsistent argument */
+#define MSD_E_ALIGN (-2)    /* pointer or leading dimension not aligned as required */
+#define MSD_E_UNSUPPORTED (-3)
+#define MSD_E_WORKSPACE (-4) /* workspace too small */
+
+typedef void* msd_stream_t; /* hipStream_t */
+
+int msd_abi_version(void);
+const char* msd_last_error(void);
+/* One-time per-process set-up (raises the dynamic-LDS limits of the kernels). Idempotent. */
+int msd_init(void);
+
+/* ------------------------------------------------------------------------------------------
+ * msd_conv_gemm — implicit-GEMM convolution / dense layer on MFMA (bf16 in, fp32 accumulate).
+ * Replaces: PaddedConv2D 3x3 s1/s2 and 1x1 (layers.py:17-25; diffusion_model.py:29,34,38,62,67,
+ * 136,200,209,218), keras Dense (diffusion_model.py:60-65,90,102-108,146; layers.py:33-36),
+ * UpSampling2D(2)+conv (diffusion_model.py:132-139; image_decoder.py:36-47), Concatenate feeding
+ * a conv (diffusion_model.py:237-273) and the GEGLU gate (diffusion_model.py:142-153).
+ *
+ *   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )
+ *   m = (b, y, x) output pixel / token,  M = batch*h_out*w_out
+ *   k = (tap, c): tap = ky*ksize+kx, c over the concatenated channels of a0|a1, K = taps*(c0+c1)
+ *   A[m,(tap,c)] = in[b, y*stride+ky-pad, x*stride+kx-pad, c]  (zero outside; with `upsample`
+ *                  the logical input is the stored tensor repeated 2x2, nearest)
+ *   W is pre-packed [N][K] bf16 (k contiguous) — see minsdtf_amd/packing.py.
+ * Requirements: c0 % 64 == 0, c1 % 64 == 0, N % 4 == 0, all pointers 16-byte aligned,
+ *               leading dimensions multiples of 4 elements.
+ * Epilogue order: + bias[n] -> + rowvec[step, b, n] -> act -> + residual[m, n] -> store.
+ */
+#define MSD_ACT_NONE 0
+#define MSD_ACT_SILU 1
+#define MSD_ACT_GEGLU 2 /* W rows interleaved in 16-column x|gate groups; writes N/2 columns */
+
+#define MSD_OUT_BF16 0
+#define MSD_OUT_F32 1
+
+typedef struct MsdConvGemm {
+    const void* a0;      /* bf16 [batch][h_in][w_in][c0] */
+    const void* a1;      /* bf16 [batch][h_in][w_in][c1] or NULL (channel concat a0|a1) */
+    const void* w;       /* bf16 [N][K] */
+    const float* bias;   /* [N] or NULL */
+    const float* rowvec; /* fp32, element (step*rv_step_stride + b*rv_batch_stride + n) or NULL */
+    const int32_t* step_ptr; /* device int32 or NULL (step = 0) */
+    const void* residual;    /* bf16 [M][res_ld] or NULL */
+    void* out;           /* bf16 or fp32 [M][out_ld]  (split mode: part 0) */
+    void* out1;          /* split mode part 1: bf16 [M][out1_ld] */
+    void* out2;          /* split mode part 2: bf16 TRANSPOSED [batch][N-ns0-ns1][out2_ld] (token contiguous) */
+    float* workspace;    /* fp32 split-K partial slabs, >= splitk*M*N floats (or NULL if splitk<=1) */
+    int64_t workspace_floats;
+    int32_t batch, h_in, w_in, c0, c1;
+    int32_t h_out, w_out;
+    int32_t ksize;       /* 1 or 3 */
+    int32_t stride;      /* 1 or 2 */
+    int32_t pad;         /* 0 or 1 */
+    int32_t upsample;    /* 0 or 1: nearest x2 of the stored input before the conv */
+    int32_t N;
+    int32_t act;
+    int32_t out_dtype;
+    int32_t out_ld, res_ld;
+    int32_t rv_step_stride, rv_batch_stride;
+    int32_t split_mode;  /* 0: plain; 1: columns [0,ns0)->out, [ns0,ns0+ns1)->out1, rest->out2 transposed */
+    int32_t ns0, ns1, out1_ld, out2_ld;
+    int32_t splitk;      /* >=1; K-tiles are divided over this many slices */
+    int32_t tile_n;      /* 0 = auto, else 64 or 128 */
+} MsdConvGemm;
+
+int msd_conv_gemm(const MsdConvGemm* p, msd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * msd_conv_direct — small-channel direct convolution / dense on vector FMAs (fp32 weights).
+ * For the layers whose channel counts cannot fill an MFMA tile: UNet conv_in 4->320 and conv_out
+ * 320->4 (diffusion_model.py:191,279), VAE post_quant/conv_in/conv_out (image_decoder.py:28-29,53),
+ * HintNet (control_net.py:14-30), the time-embedding MLP and the per-ResBlock time projections
+ * (diffusion_model.py:30,184-188) evaluated for all steps at once.
+ *   w: fp32 Keras layout [ksize][ksize][c_in][c_out];  in: fp32 or bf16 NHWC;  batch index of the
+ *   input is (b % in_batch_mod) so one latent can feed the cond and uncond halves.
+ * Epilogue: (+bias) -> act(SiLU optional) -> (+residual bf16) -> out as bf16 / fp32 / uint8 where
+ * uint8 = clip(trunc(((v+1)*0.5)*255), 0, 255) (stable_diffusion.py:483-486).
+ */
+#define MSD_OUT_U8 2
+typedef struct MsdConvDirect {
+    const void* in;
+    const float* w;
+    const float* bias;     /* or NULL */
+    const void* residual;  /* bf16 [M][c_out] or NULL */
+    void* out;
+    int32_t batch, in_batch_mod, h_in, w_in, c_in;
+    int32_t h_out, w_out, c_out;
+    int32_t ksize, stride, pad;
+    int32_t in_dtype;      /* MSD_OUT_BF16 or MSD_OUT_F32 */
+    int32_t out_dtype;     /* MSD_OUT_BF16 / MSD_OUT_F32 / MSD_OUT_U8 */
+    int32_t act;           /* MSD_ACT_NONE or MSD_ACT_SILU */
+    int32_t act_in;        /* apply SiLU to the input values as they are read (0/1) */
+    float in_scale;        /* input multiplier (VAE Rescaling 1/0.18215, image_decoder.py:27) */
+} MsdConvDirect;
+
+int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * msd_group_norm — GroupNormalization(groups=32, eps) [+ swish], NHWC, fp32 statistics.
+ * Replaces keras GroupNormalization + Activation("swish") (diffusion_model.py:27-28,32-33,57,
+ * 277-278; layers.py:32,66-68,78-79; image_decoder.py:51-52) and the Concatenate in front of it
+ * (reads x0|x1 through two base pointers, never materialised).
+ *   x0: bf16 [batch][hw][c0], x1: bf16 [batch][hw][c1] or NULL;  out: bf16 [batch][hw][c0+c1]
+ *   stats: fp32 [batch][32][2] scratch, MUST be zero on entry (sum, sum of squares accumulate
+ *          with atomics); one slot per call site, cleared by one memset per forward pass.
+ */
+typedef struct MsdGroupNorm {
+    const void* x0;
+    const void* x1;
+    const float* gamma; /* [c0+c1] */
+    const float* beta;  /* [c0+c1] */
+    float* stats;
+    void* out;
+    int32_t batch, hw, c0, c1;
+    int32_t silu; /* 0/1 */
+    float eps;
+} MsdGroupNorm;
+
+int msd_group_norm(const MsdGroupNorm* p, msd_stream_t stream);
+
+/* msd_layer_norm — LayerNormalization(eps) over the last axis (diffusion_model.py:84-88).
+ * x, out: bf16 [rows][c], c % 8 == 0, c <= 2048. */
+int msd_layer_norm(const void* x, const float* gamma, const float* beta, void* out, int32_t rows, int32_t c,
+                   float eps, msd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * msd_attention — fused scaled-dot-product attention, online softmax, MFMA QK^T and PV.
+ * Replaces einsum/softmax/einsum of CrossAttention.call (diffusion_model.py:110-127); the
+ * (B,heads,S,T) score tensor never exists in HBM.
+ *   q:  bf16 [batch][s][q_ld], head h at columns [h*d, (h+1)*d)
+ *   k:  bf16 [batch][t][k_ld]
+ *   vt: bf16 [batch][heads*d][vt_ld]  (V transposed: key index contiguous; vt_ld % 8 == 0;
+ *       columns >= t must hold finite values, e.g. zeros)
+ *   out: bf16 [batch][s][o_ld]
+ *   softmax(scale * q k^T) v, scale applied to the scores (diffusion_model.py:105,123).
+ * head_dim in {40, 80, 160}.
+ */
+typedef struct MsdAttention {
+    const void* q;
+    const void* k;
+    const void* vt;
+    void* out;
+    int32_t batch, heads, head_dim;
+    int32_t s, t;
+    int32_t q_ld, k_ld, vt_ld, o_ld;
+    float scale;
+} MsdAttention;
+
+int msd_attention(const MsdAttention* p, msd_stream_t stream);
+
+/* msd_softmax_rows — out[r, :cols] = softmax(scale * x[r, :cols]); x fp32 [rows][ld_in], out bf16
+ * [rows][ld_out] (VAE single-head attention, layers.py:48-50). cols % 8 == 0. */
+int msd_softmax_rows(const float* x, void* out, int64_t rows, int32_t cols, int32_t ld_in, int32_t ld_out, float scale,
+                     msd_stream_t stream);
+
+/* msd_memset_zero — stream-ordered hipMemsetAsync(ptr, 0, bytes) (GroupNorm statistic slots). */
+int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * msd_cfg_step — classifier-free guidance + guidance rescale + sampler step, fp32, one launch.
+ * Replaces stable_diffusion.py:458-461 (CFG, rescale_noise_cfg :304-315) and Scheduler.step
+ * non-TCD branch (scheduler.py:272-285,308-312).
+ *   eps:    fp32 [2*batch][n]  rows [0,batch) = unconditional, [batch,2*batch) = text-conditioned
+ *           (guidance <= 0: fp32 [batch][n], used as is — stable_diffusion.py:462-467)
+ *   latent: fp32 [batch][n], updated in place
+ *   coef:   fp32 [steps][4] = {signal_rate[t], noise_rate[t], signal_rate[t_prev],
+ *           noise_rate[t_prev]}; the last step's row holds {sr, nr, 1, 0} and is_last picks x0.
+ *   The row used is coef[*step_ptr]; after the update the kernel increments *step_ptr when
+ *   advance != 0.
+ */
+typedef struct MsdCfgStep {
+    const float* eps;
+    float* latent;
+    const float* coef;
+    int32_t* step_ptr;
+    int32_t batch, n, num_steps;
+    float guidance, guidance_rescale;
+    int32_t advance;
+} MsdCfgStep;
+
+int msd_cfg_step(const MsdCfgStep* p, msd_stream_t stream);
+
+/* msd_add_bf16 — out = a + b elementwise on bf16 (ControlNet residual adds,
+ * diffusion_model.py:230-234). n % 8 == 0. */
+int msd_add_bf16(const void* a, const void* b, void* out, int64_t n, msd_stream_t stream);
+
+/* msd_cast_f32_to_bf16 / msd_cast_bf16_to_f32 — dtype conversion of a contiguous buffer. */
+int msd_cast_f32_to_bf16(const float* in, void* out, int64_t n, msd_stream_t stream);
+int msd_cast_bf16_to_f32(const void* in, float* out, int64_t n, msd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINSDTF_HIP_H */

@@ -1,0 +1,126 @@
+"""ctypes binding of libminsdtf_hip.so (C ABI declared in include/minsdtf_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If the shared object is
+missing or does not export the ABI the header declares, importing any op raises
+:class:`HipExtensionError` (loudly) instead of silently computing on some other path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+LIB_NAME = "libminsdtf_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+ABI_VERSION = 1
+
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+class MsdConvGemm(C.Structure):
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
+        ("step_ptr", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p), ("out1", C.c_void_p),
+        ("out2", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
+        ("batch", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
+        ("h_out", C.c_int32), ("w_out", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("upsample", C.c_int32), ("N", C.c_int32), ("act", C.c_int32), ("out_dtype", C.c_int32),
+        ("out_ld", C.c_int32), ("res_ld", C.c_int32), ("rv_step_stride", C.c_int32), ("rv_batch_stride", C.c_int32),
+        ("split_mode", C.c_int32), ("ns0", C.c_int32), ("ns1", C.c_int32), ("out1_ld", C.c_int32),
+        ("out2_ld", C.c_int32), ("splitk", C.c_int32), ("tile_n", C.c_int32),
+    ]
+
+
+class MsdConvDirect(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
+        ("batch", C.c_int32), ("in_batch_mod", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
+        ("c_in", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32), ("c_out", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("in_dtype", C.c_int32),
+        ("out_dtype", C.c_int32), ("act", C.c_int32), ("act_in", C.c_int32), ("in_scale", C.c_float),
+    ]
+
+
+class MsdGroupNorm(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("stats", C.c_void_p),
+        ("out", C.c_void_p), ("batch", C.c_int32), ("hw", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
+        ("silu", C.c_int32), ("eps", C.c_float),
+    ]
+
+
+class MsdAttention(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
+        ("batch", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("s", C.c_int32), ("t", C.c_int32),
+        ("q_ld", C.c_int32), ("k_ld", C.c_int32), ("vt_ld", C.c_int32), ("o_ld", C.c_int32), ("scale", C.c_float),
+    ]
+
+
+class MsdCfgStep(C.Structure):
+    _fields_ = [
+        ("eps", C.c_void_p), ("latent", C.c_void_p), ("coef", C.c_void_p), ("step_ptr", C.c_void_p),
+        ("batch", C.c_int32), ("n", C.c_int32), ("num_steps", C.c_int32), ("guidance", C.c_float),
+        ("guidance_rescale", C.c_float), ("advance", C.c_int32),
+    ]
+
+
+# every symbol include/minsdtf_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "msd_abi_version": (C.c_int, []),
+    "msd_last_error": (C.c_char_p, []),
+    "msd_init": (C.c_int, []),
+    "msd_conv_gemm": (C.c_int, [C.POINTER(MsdConvGemm), C.c_void_p]),
+    "msd_conv_direct": (C.c_int, [C.POINTER(MsdConvDirect), C.c_void_p]),
+    "msd_group_norm": (C.c_int, [C.POINTER(MsdGroupNorm), C.c_void_p]),
+    "msd_layer_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                 C.c_void_p]),
+    "msd_attention": (C.c_int, [C.POINTER(MsdAttention), C.c_void_p]),
+    "msd_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                   C.c_void_p]),
+    "msd_memset_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "msd_cfg_step": (C.c_int, [C.POINTER(MsdCfgStep), C.c_void_p]),
+    "msd_add_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "msd_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "msd_cast_bf16_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library.  Raises HipExtensionError when it is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    import torch  # noqa: F401  — torch's bundled libamdhip64.so.7 must be the HIP runtime the library binds to
+
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipExtensionError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipExtensionError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.msd_abi_version() != ABI_VERSION:
+        raise HipExtensionError(f"ABI version mismatch: library {lib.msd_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().msd_last_error().decode(errors="replace")
+        raise HipExtensionError(f"{what} failed (rc={rc}): {msg}")

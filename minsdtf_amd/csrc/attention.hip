@@ -1,0 +1,286 @@
+// Fused scaled-dot-product attention for gfx950 (flash-style, online softmax in registers).
+//
+// Replaces CrossAttention.call's einsum / softmax / einsum (diffusion_model.py:110-127): the
+// reference materialises (B, 8, S, T) fp32 scores (2.9 GB per UNet forward at 512x512); here the
+// scores live only in MFMA accumulators.
+//
+// Work split: one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32
+// queries (two 16-query MFMA column blocks).  K/V are walked in 64-key tiles staged in LDS.
+//
+// Both products are issued TRANSPOSED so that the query index sits on the MFMA column (= lane&15):
+//   S^T[key, q] = sum_d K[key, d] * Q[q, d]      A = K rows (LDS, 16-byte reads), B = Q (registers)
+//   O^T[d, q]   = sum_key V^T[d, key] * P^T[key, q]   A = V^T rows (LDS), B = P (from S^T registers)
+// Consequences: (1) every lane works on ONE query per column block, so the running max / sum and
+// the rescale factor are lane-local scalars and the row max needs only two cross-lane steps
+// (lane ^ 16, lane ^ 32); (2) the S^T accumulator registers of two 16-key blocks ARE the B-operand
+// fragment of the PV product after a bf16 pack — no LDS round trip, no transpose: the k-slot
+// order inside an MFMA is free as long as both operands agree, so V^T is read from LDS in the
+// accumulator's key order (keys 4g..4g+3 and 16+4g..16+4g+3 of each 32-key step);
+// (3) V is consumed as V^T[d][key], which the QKV projection epilogue writes directly
+// (msd_conv_gemm split mode), so no transposing loads anywhere.
+// head_dim 40 / 80 are zero-padded to 64 / 96 in the QK^T k-dimension only (LDS pad columns stay 0).
+#include "common.h"
+
+struct AArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* out;
+    int batch, heads, s, t, q_ld, k_ld, vt_ld, o_ld;
+    float sl2;  // scale * log2(e)
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
+    constexpr int DPAD = ((D + 31) / 32) * 32;
+    constexpr int KS = DPAD / 32;        // k-steps of QK^T
+    constexpr int DF = (D + 15) / 16;    // 16-row blocks of O^T
+    constexpr int KROW = DPAD * 2 + 16;  // bytes; odd number of 16-B slots -> conflict-free fragment reads
+    constexpr int VROW = 64 * 2 + 16;
+    constexpr int DCH = D / 8;           // 16-byte chunks per K row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                      // [64][KROW]
+    char* sV = smem + 64 * KROW;          // [DF*16][VROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    // zero the whole LDS image once: pad columns / pad rows are never written afterwards
+    for (int off = tid * 16; off < 64 * KROW + DF * 16 * VROW; off += 256 * 16)
+        *reinterpret_cast<uint4*>(smem + off) = make_uint4(0, 0, 0, 0);
+
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        int qrow = q0 + f * 16 + r;
+        if (qrow > p.s - 1) qrow = p.s - 1;
+        const bf16_t* qp = p.q + ((size_t)b * p.s + qrow) * p.q_ld + h * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 32 + 8 * g;
+            if (d0 < D) qf[f][ks] = *reinterpret_cast<const bf16x8*>(qp + d0);
+            else qf[f][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    f32x4 oacc[DF][2];
+#pragma unroll
+    for (int df = 0; df < DF; ++df) { oacc[df][0] = (f32x4){0, 0, 0, 0}; oacc[df][1] = (f32x4){0, 0, 0, 0}; }
+    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+
+    const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
+    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
+    const int ntiles = (p.t + 63) / 64;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int t0 = tile * 64;
+        __syncthreads();  // previous tile fully consumed (also orders the zero fill on the first pass)
+        for (int idx = tid; idx < 64 * DCH; idx += 256) {
+            const int row = idx / DCH, ch = idx - row * DCH;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (t0 + row < p.t) v = *reinterpret_cast<const uint4*>(kbase + (size_t)(t0 + row) * p.k_ld + ch * 8);
+            *reinterpret_cast<uint4*>(sK + row * KROW + ch * 16) = v;
+        }
+        for (int idx = tid; idx < D * 8; idx += 256) {
+            const int d = idx >> 3, ch = idx & 7;
+            const int key0 = t0 + ch * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (key0 + 8 <= p.vt_ld && key0 < p.t) v = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + key0);
+            *reinterpret_cast<uint4*>(sV + d * VROW + ch * 16) = v;
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T ------------------------------------------------------------------
+        f32x4 sacc[4][2];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) { sacc[kf][0] = (f32x4){0, 0, 0, 0}; sacc[kf][1] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sK + (kf * 16 + r) * KROW + ks * 64 + g * 16);
+                sacc[kf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[0][ks], sacc[kf][0], 0, 0, 0);
+                sacc[kf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[1][ks], sacc[kf][1], 0, 0, 0);
+            }
+        }
+        // ---- online softmax: lane holds keys t0 + kf*16 + 4g + e of query f*16 + r ----------
+        const bool tail = (t0 + 64 > p.t);
+        bf16x8 pb[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = sacc[kf][f][e] * p.sl2;
+                    if (tail && (t0 + kf * 16 + 4 * g + e >= p.t)) sv = -1e30f;
+                    sacc[kf][f][e] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[f], mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew);
+            mrun[f] = mnew;
+            float ls = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(sacc[kf][f][e] - mnew);
+                    sacc[kf][f][e] = pv;
+                    ls += pv;
+                }
+            lrun[f] = lrun[f] * alpha + ls;
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                oacc[df][f][0] *= alpha; oacc[df][f][1] *= alpha; oacc[df][f][2] *= alpha; oacc[df][f][3] *= alpha;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                union { bf16x8 v; uint32_t u[4]; } pk;
+                pk.u[0] = pack_bf2(sacc[2 * kk][f][0], sacc[2 * kk][f][1]);
+                pk.u[1] = pack_bf2(sacc[2 * kk][f][2], sacc[2 * kk][f][3]);
+                pk.u[2] = pack_bf2(sacc[2 * kk + 1][f][0], sacc[2 * kk + 1][f][1]);
+                pk.u[3] = pack_bf2(sacc[2 * kk + 1][f][2], sacc[2 * kk + 1][f][3]);
+                pb[kk][f] = pk.v;
+            }
+        }
+        // ---- O^T += V^T P^T -----------------------------------------------------------------
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                union { bf16x8 v; uint2 h2[2]; } vf;
+                const char* vp = sV + (df * 16 + r) * VROW + kk * 64 + g * 8;
+                vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
+                vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 32);
+                oacc[df][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[kk][0], oacc[df][0], 0, 0, 0);
+                oacc[df][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[kk][1], oacc[df][1], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        float lt = lrun[f];
+        lt += __shfl_xor(lt, 16);
+        lt += __shfl_xor(lt, 32);
+        const float inv = 1.0f / lt;
+        const int qrow = q0 + f * 16 + r;
+        if (qrow < p.s) {
+            bf16_t* op = p.out + ((size_t)b * p.s + qrow) * p.o_ld + h * D;
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                const int d = df * 16 + 4 * g;
+                if (d < D) {
+                    uint2 o;
+                    o.x = pack_bf2(oacc[df][f][0] * inv, oacc[df][f][1] * inv);
+                    o.y = pack_bf2(oacc[df][f][2] * inv, oacc[df][f][3] * inv);
+                    *reinterpret_cast<uint2*>(op + d) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+static constexpr int attn_lds_bytes() {
+    return 64 * (((D + 31) / 32) * 32 * 2 + 16) + ((D + 15) / 16) * 16 * (64 * 2 + 16);
+}
+
+static bool g_attn_attr_done = false;
+int msd_attention_init() {
+    if (g_attn_attr_done) return MSD_OK;
+    hipError_t e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<40>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<40>());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<80>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<80>());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<160>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<160>());
+    if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
+    g_attn_attr_done = true;
+    return MSD_OK;
+}
+
+extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !q->q || !q->k || !q->vt || !q->out) MSD_FAIL(MSD_E_ARG, "attention: null pointer");
+    if (q->batch <= 0 || q->heads <= 0 || q->s <= 0 || q->t <= 0) MSD_FAIL(MSD_E_ARG, "attention: bad dims");
+    if ((q->q_ld % 8) || (q->k_ld % 8) || (q->vt_ld % 8) || (q->o_ld % 4))
+        MSD_FAIL(MSD_E_ALIGN, "attention: leading dimensions must be multiples of 8 (o_ld: 4)");
+    if (q->q_ld < q->heads * q->head_dim || q->k_ld < q->heads * q->head_dim || q->o_ld < q->heads * q->head_dim ||
+        q->vt_ld < q->t)
+        MSD_FAIL(MSD_E_ARG, "attention: leading dimension smaller than the row");
+    if (!msd_aligned16(q->q) || !msd_aligned16(q->k) || !msd_aligned16(q->vt) || !msd_aligned16(q->out))
+        MSD_FAIL(MSD_E_ALIGN, "attention: pointers must be 16-byte aligned");
+    int rc = msd_attention_init();
+    if (rc) return rc;
+    AArgs a;
+    a.q = (const bf16_t*)q->q; a.k = (const bf16_t*)q->k; a.vt = (const bf16_t*)q->vt; a.out = (bf16_t*)q->out;
+    a.batch = q->batch; a.heads = q->heads; a.s = q->s; a.t = q->t;
+    a.q_ld = q->q_ld; a.k_ld = q->k_ld; a.vt_ld = q->vt_ld; a.o_ld = q->o_ld;
+    a.sl2 = q->scale * 1.4426950408889634f;
+    dim3 grid((q->s + 127) / 128, q->heads, q->batch);
+    switch (q->head_dim) {
+        case 40: hipLaunchKernelGGL(attention_kernel<40>, grid, dim3(256), attn_lds_bytes<40>(), stream, a); break;
+        case 80: hipLaunchKernelGGL(attention_kernel<80>, grid, dim3(256), attn_lds_bytes<80>(), stream, a); break;
+        case 160: hipLaunchKernelGGL(attention_kernel<160>, grid, dim3(256), attn_lds_bytes<160>(), stream, a); break;
+        default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 80, 160)", q->head_dim);
+    }
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}
+
+// ---- row softmax (VAE single-head attention scores, layers.py:48-50) ----------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, bf16_t* out, int cols, int ld_in, int ld_out,
+                                                           float sl2) {
+    __shared__ float red[4];
+    const float* row = x + (size_t)blockIdx.x * ld_in;
+    bf16_t* orow = out + (size_t)blockIdx.x * ld_out;
+    const int t = threadIdx.x;
+    const int ncv = cols >> 2;
+    float mx = -1e30f;
+    for (int cv = t; cv < ncv; cv += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + cv * 4);
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y) * 1.0f), fmaxf(v.z, v.w));
+    }
+    mx = wave_max(mx);
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * sl2;  // scale > 0: max commutes with it
+    __syncthreads();
+    float sum = 0.f;
+    for (int cv = t; cv < ncv; cv += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + cv * 4);
+        sum += __builtin_amdgcn_exp2f(v.x * sl2 - mx) + __builtin_amdgcn_exp2f(v.y * sl2 - mx) +
+               __builtin_amdgcn_exp2f(v.z * sl2 - mx) + __builtin_amdgcn_exp2f(v.w * sl2 - mx);
+    }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) red[t >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int cv = t; cv < ncv; cv += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + cv * 4);
+        uint2 o;
+        o.x = pack_bf2(__builtin_amdgcn_exp2f(v.x * sl2 - mx) * inv, __builtin_amdgcn_exp2f(v.y * sl2 - mx) * inv);
+        o.y = pack_bf2(__builtin_amdgcn_exp2f(v.z * sl2 - mx) * inv, __builtin_amdgcn_exp2f(v.w * sl2 - mx) * inv);
+        *reinterpret_cast<uint2*>(orow + cv * 4) = o;
+    }
+}
+
+extern "C" int msd_softmax_rows(const float* x, void* out, int64_t rows, int32_t cols, int32_t ld_in, int32_t ld_out,
+                                float scale, msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !out || rows <= 0 || cols <= 0 || (cols % 8) || (ld_in % 4) || (ld_out % 4) || ld_in < cols || ld_out < cols ||
+        !(scale > 0.f))
+        MSD_FAIL(MSD_E_ARG, "softmax_rows: bad arguments");
+    if (!msd_aligned16(x) || !msd_aligned16(out)) MSD_FAIL(MSD_E_ALIGN, "softmax_rows: pointers must be 16-byte aligned");
+    if (rows > 0x7fffffffLL) MSD_FAIL(MSD_E_ARG, "softmax_rows: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, (bf16_t*)out, cols, ld_in, ld_out,
+                       scale * 1.4426950408889634f);
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}

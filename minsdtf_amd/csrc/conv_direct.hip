@@ -1,0 +1,117 @@
+// Small-channel direct convolution / dense layer on vector FMAs (fp32 weights, fp32 accumulate).
+//
+// For the handful of layers whose channel counts cannot fill an MFMA tile (see
+// include/minsdtf_hip.h): UNet conv_in / conv_out (diffusion_model.py:191,279), VAE post_quant /
+// conv_in / conv_out (image_decoder.py:28-29,53), HintNet (control_net.py:14-30) and the
+// time-embedding MLP + per-ResBlock projections (diffusion_model.py:30,184-188).
+// Work item = (output pixel, group of CG output channels).  Consecutive work items walk the
+// channel groups of one pixel first, so a wave reads ONE input pixel (broadcast) and a contiguous
+// run of the Keras-layout weights [tap][c_in][c_out] (coalesced); with a single channel group
+// (c_out <= 4) consecutive lanes are consecutive pixels and the weights broadcast instead.
+#include "common.h"
+
+struct CDArgs {
+    const void* in; const float* w; const float* bias; const bf16_t* residual; void* out;
+    int batch, in_batch_mod, h_in, w_in, c_in, h_out, w_out, c_out, ksize, stride, pad;
+    int in_f32, out_dtype, act, act_in, ncg;
+    long long total;
+    float in_scale;
+};
+
+template <int CG, bool IN_F32>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const CDArgs p) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= p.total) return;
+    const int cg = (int)(gid % p.ncg);
+    const long long pix = gid / p.ncg;
+    const int hw = p.h_out * p.w_out;
+    const int b = (int)(pix / hw);
+    const int rem = (int)(pix - (long long)b * hw);
+    const int y = rem / p.w_out, x = rem - y * p.w_out;
+    const int co = cg * CG;
+    const bool full = (co + CG <= p.c_out);
+
+    float acc[CG];
+#pragma unroll
+    for (int k = 0; k < CG; ++k) acc[k] = (p.bias && co + k < p.c_out) ? p.bias[co + k] : 0.f;
+
+    const int bi = b % p.in_batch_mod;
+    for (int ky = 0; ky < p.ksize; ++ky) {
+        const int iy = y * p.stride + ky - p.pad;
+        if ((unsigned)iy >= (unsigned)p.h_in) continue;
+        for (int kx = 0; kx < p.ksize; ++kx) {
+            const int ix = x * p.stride + kx - p.pad;
+            if ((unsigned)ix >= (unsigned)p.w_in) continue;
+            const size_t ioff = ((size_t)(bi * p.h_in + iy) * p.w_in + ix) * p.c_in;
+            const float* wp = p.w + (size_t)((ky * p.ksize + kx) * p.c_in) * p.c_out + co;
+            for (int ci = 0; ci < p.c_in; ++ci) {
+                float xv;
+                if (IN_F32) xv = reinterpret_cast<const float*>(p.in)[ioff + ci];
+                else xv = bf2f(reinterpret_cast<const bf16_t*>(p.in)[ioff + ci]);
+                xv *= p.in_scale;
+                if (p.act_in) xv = silu_f(xv);
+                const float* wr = wp + (size_t)ci * p.c_out;
+                if (full) {
+#pragma unroll
+                    for (int k = 0; k < CG; ++k) acc[k] += xv * wr[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CG; ++k)
+                        if (co + k < p.c_out) acc[k] += xv * wr[k];
+                }
+            }
+        }
+    }
+    const size_t ooff = (size_t)pix * p.c_out + co;
+#pragma unroll
+    for (int k = 0; k < CG; ++k) {
+        if (co + k >= p.c_out) break;
+        float v = acc[k];
+        if (p.act == MSD_ACT_SILU) v = silu_f(v);
+        if (p.residual) v += bf2f(p.residual[ooff + k]);
+        if (p.out_dtype == MSD_OUT_F32) reinterpret_cast<float*>(p.out)[ooff + k] = v;
+        else if (p.out_dtype == MSD_OUT_BF16) reinterpret_cast<bf16_t*>(p.out)[ooff + k] = f2bf(v);
+        else {
+            // stable_diffusion.py:483-486: clip(((v + 1) * 0.5) * 255, 0, 255).astype(uint8) — truncation
+            float u = ((v + 1.0f) * 0.5f) * 255.0f;
+            u = fminf(fmaxf(u, 0.0f), 255.0f);
+            reinterpret_cast<uint8_t*>(p.out)[ooff + k] = (uint8_t)u;
+        }
+    }
+}
+
+extern "C" int msd_conv_direct(const MsdConvDirect* q, msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !q->in || !q->w || !q->out) MSD_FAIL(MSD_E_ARG, "conv_direct: null pointer");
+    if (q->batch <= 0 || q->in_batch_mod <= 0 || q->h_in <= 0 || q->w_in <= 0 || q->c_in <= 0 || q->c_out <= 0 ||
+        q->h_out <= 0 || q->w_out <= 0)
+        MSD_FAIL(MSD_E_ARG, "conv_direct: bad dims");
+    if (q->ksize < 1 || q->ksize > 3 || q->stride < 1 || q->stride > 2 || q->pad < 0 || q->pad > 1)
+        MSD_FAIL(MSD_E_UNSUPPORTED, "conv_direct: ksize/stride/pad");
+    {
+        const int ho = (q->h_in + 2 * q->pad - q->ksize) / q->stride + 1, wo = (q->w_in + 2 * q->pad - q->ksize) / q->stride + 1;
+        if (ho != q->h_out || wo != q->w_out) MSD_FAIL(MSD_E_ARG, "conv_direct: output dims do not match the geometry");
+    }
+    if (q->in_dtype != MSD_OUT_BF16 && q->in_dtype != MSD_OUT_F32) MSD_FAIL(MSD_E_ARG, "conv_direct: in_dtype");
+    if (q->out_dtype < 0 || q->out_dtype > 2) MSD_FAIL(MSD_E_ARG, "conv_direct: out_dtype");
+    if (q->act != MSD_ACT_NONE && q->act != MSD_ACT_SILU) MSD_FAIL(MSD_E_ARG, "conv_direct: act");
+    CDArgs a;
+    a.in = q->in; a.w = q->w; a.bias = q->bias; a.residual = (const bf16_t*)q->residual; a.out = q->out;
+    a.batch = q->batch; a.in_batch_mod = q->in_batch_mod; a.h_in = q->h_in; a.w_in = q->w_in; a.c_in = q->c_in;
+    a.h_out = q->h_out; a.w_out = q->w_out; a.c_out = q->c_out; a.ksize = q->ksize; a.stride = q->stride; a.pad = q->pad;
+    a.in_f32 = q->in_dtype == MSD_OUT_F32; a.out_dtype = q->out_dtype; a.act = q->act; a.act_in = q->act_in ? 1 : 0;
+    a.in_scale = q->in_scale;
+    const int cg = q->c_out <= 4 ? 4 : 8;
+    a.ncg = (q->c_out + cg - 1) / cg;
+    a.total = (long long)q->batch * q->h_out * q->w_out * a.ncg;
+    const unsigned blocks = (unsigned)((a.total + 255) / 256);
+    if (cg == 4) {
+        if (a.in_f32) hipLaunchKernelGGL((conv_direct_kernel<4, true>), dim3(blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_direct_kernel<4, false>), dim3(blocks), dim3(256), 0, stream, a);
+    } else {
+        if (a.in_f32) hipLaunchKernelGGL((conv_direct_kernel<8, true>), dim3(blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((conv_direct_kernel<8, false>), dim3(blocks), dim3(256), 0, stream, a);
+    }
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}

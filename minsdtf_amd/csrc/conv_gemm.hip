@@ -1,0 +1,374 @@
+// Implicit-GEMM convolution / dense layer for gfx950: bf16 MFMA 16x16x32, fp32 accumulate.
+//
+// Replaces PaddedConv2D / Dense / UpSampling2D+conv / Concatenate+conv / GEGLU of the reference
+// (layers.py:17-25, diffusion_model.py:22-153) — see include/minsdtf_hip.h for the contract.
+//
+// Structure (one 256-thread workgroup = 4 waves, one BM x BN output tile):
+//   * K is walked in 64-channel tiles of one filter tap at a time, so the A tile is a gather of BM
+//     pixel rows x 128 contiguous bytes (NHWC): 8 lanes fetch one pixel's 128 B -> coalesced;
+//     zero padding, stride 2, nearest x2 upsampling and the channel concat of two tensors are all
+//     address generation in the loader, nothing is materialised in HBM;
+//   * A and W tiles are staged registers -> LDS (double buffered, one barrier per K tile); the LDS
+//     image is [row][8 x 16 B] with the 16-byte chunk index XOR-swizzled by (row>>1)&7, which makes
+//     both the ds_write_b128 (8 lanes = one row) and the MFMA fragment ds_read_b128 (16 rows x one
+//     chunk per 16-lane group) bank-conflict free;
+//   * the MFMA is issued "swapped" (A operand = weights, B operand = activations) so each lane's
+//     accumulator holds 4 CONSECUTIVE output channels of one pixel: the epilogue reads bias /
+//     time-embedding / residual and writes the result with 8- or 16-byte vectors;
+//   * small-M layers (8x8 and 16x16 levels at batch 1) are split over K into fp32 partial slabs
+//     reduced by a second tiny kernel, deterministically (no atomics).
+#include "common.h"
+
+struct CGArgs {
+    const bf16_t* a0; const bf16_t* a1; const bf16_t* w;
+    const float* bias; const float* rowvec; const int32_t* step_ptr;
+    const bf16_t* residual; void* out; bf16_t* out1; bf16_t* out2; float* ws;
+    int batch, h_in, w_in, c0, c1, h_out, w_out, ksize, stride, pad, upsample;
+    int M, N, K, hw_out, nkc, nk, nk_per, tiles_n;
+    int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
+    int split_mode, ns0, ns1, out1_ld, out2_ld;
+};
+
+// ---- epilogue for one group of 4 consecutive output columns of one row -----------------------
+__device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, int step, float v[4]) {
+    if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (p.rowvec) {
+        const float4 rv = *reinterpret_cast<const float4*>(
+            p.rowvec + (size_t)step * p.rv_step_stride + (size_t)b * p.rv_batch_stride + n);
+        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+    }
+    if (p.act == MSD_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    }
+    if (p.split_mode == 0) {
+        if (p.residual) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.res_ld + n);
+            v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+        }
+        if (p.out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n) =
+                make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+        }
+    } else {
+        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+        if (n < p.ns0) {
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+        } else if (n < p.ns0 + p.ns1) {
+            *reinterpret_cast<uint2*>(p.out1 + (size_t)m * p.out1_ld + (n - p.ns0)) = o;
+        } else {
+            const int nv = p.N - p.ns0 - p.ns1;
+            const int nn = n - p.ns0 - p.ns1;
+            const int s = m - b * p.hw_out;
+            bf16_t* dst = p.out2 + ((size_t)b * nv + nn) * p.out2_ld + s;
+            dst[0] = (bf16_t)(o.x & 0xFFFF);
+            dst[(size_t)p.out2_ld] = (bf16_t)(o.x >> 16);
+            dst[(size_t)2 * p.out2_ld] = (bf16_t)(o.y & 0xFFFF);
+            dst[(size_t)3 * p.out2_ld] = (bf16_t)(o.y >> 16);
+        }
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const CGArgs p) {
+    constexpr int WM = BM / 2, WN = BN / 2;      // 2 x 2 waves
+    constexpr int MI = WM / 16, NJ = WN / 16;    // 16x16 fragments per wave tile
+    constexpr int AR = BM / 32, BR = BN / 32;    // rows staged per thread (256 threads = 32 rows x 8 chunks)
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sB = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 15, g = lane >> 4;
+    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kt_begin = blockIdx.y * p.nk_per;
+    const int kt_end = min(p.nk, kt_begin + p.nk_per);
+
+    const int chunk = tid & 7, lrow = tid >> 3;
+    const int Hl = p.upsample ? 2 * p.h_in : p.h_in;
+    const int Wl = p.upsample ? 2 * p.w_in : p.w_in;
+    int ab[AR], ay[AR], ax[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int b = m / p.hw_out;
+            const int rem = m - b * p.hw_out;
+            const int y = rem / p.w_out;
+            const int x = rem - y * p.w_out;
+            ab[i] = b * p.h_in * p.w_in;
+            ay[i] = y * p.stride - p.pad;
+            ax[i] = x * p.stride - p.pad;
+        } else {
+            ab[i] = 0; ay[i] = -(1 << 20); ax[i] = -(1 << 20);
+        }
+    }
+    const bf16_t* wrow[BR];
+    bool wok[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        wok[i] = n < p.N;
+        wrow[i] = p.w + (size_t)(wok[i] ? n : 0) * p.K + chunk * 8;
+    }
+
+    uint4 ra[AR], rb[BR];
+    auto load_tile = [&](int kt) {
+        const int tap = kt / p.nkc;
+        const int c = (kt - tap * p.nkc) * 64;
+        const int ky = tap / p.ksize;
+        const int kx = tap - ky * p.ksize;
+        const bf16_t* src; int csrc, coff;
+        if (c < p.c0) { src = p.a0; csrc = p.c0; coff = c; } else { src = p.a1; csrc = p.c1; coff = c - p.c0; }
+        coff += chunk * 8;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int iy = ay[i] + ky, ix = ax[i] + kx;
+            const bool ok = ((unsigned)iy < (unsigned)Hl) && ((unsigned)ix < (unsigned)Wl);
+            if (p.upsample) { iy >>= 1; ix >>= 1; }
+            if (ok) {
+                ra[i] = *reinterpret_cast<const uint4*>(src + (size_t)(ab[i] + iy * p.w_in + ix) * csrc + coff);
+            } else {
+                ra[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            if (wok[i]) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (size_t)kt * 64);
+            else rb[i] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int row = lrow + 32 * i;
+            *reinterpret_cast<uint4*>(sA + buf * A_BYTES + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const int row = lrow + 32 * i;
+            *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = rb[i];
+        }
+    };
+
+    f32x4 acc[NJ][MI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    const int swz = r >> 1;  // (row>>1)&7 for row = 16*q + r
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = (kt + 1) < kt_end;
+        if (more) load_tile(kt + 1);
+        const char* bA = sA + buf * A_BYTES + (wm * WM + r) * 128;
+        const char* bB = sB + buf * B_BYTES + (wn * WN + r) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + g) ^ swz) << 4;
+            bf16x8 af[MI], wf[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, per (j, i), channels n..n+3 (n = ..+4g) of pixel m (= ..+r) ----
+    if (gridDim.y > 1) {
+        float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * WM + i * 16 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                if (n >= p.N) continue;
+                *reinterpret_cast<float4*>(ws + (size_t)m * p.N + n) =
+                    make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+            }
+        }
+        return;
+    }
+    const int step = p.step_ptr ? *p.step_ptr : 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WM + i * 16 + r;
+        if (m >= p.M) continue;
+        const int b = m / p.hw_out;
+        if (p.act == MSD_ACT_GEGLU) {
+#pragma unroll
+            for (int j = 0; j < NJ; j += 2) {
+                const int nb = n0 + wn * WN + j * 16;  // multiple of 32: x columns nb+[0,16), gate nb+16+[0,16)
+                const int n = nb + 4 * g;
+                if (n >= p.N) continue;
+                float v[4];
+                float4 bx = make_float4(0, 0, 0, 0), bg = bx;
+                if (p.bias) {
+                    bx = *reinterpret_cast<const float4*>(p.bias + n);
+                    bg = *reinterpret_cast<const float4*>(p.bias + n + 16);
+                }
+                v[0] = geglu_f(acc[j][i][0] + bx.x, acc[j + 1][i][0] + bg.x);
+                v[1] = geglu_f(acc[j][i][1] + bx.y, acc[j + 1][i][1] + bg.y);
+                v[2] = geglu_f(acc[j][i][2] + bx.z, acc[j + 1][i][2] + bg.z);
+                v[3] = geglu_f(acc[j][i][3] + bx.w, acc[j + 1][i][3] + bg.w);
+                const int no = (nb >> 1) + 4 * g;
+                if (p.residual) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.res_ld + no);
+                    v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+                }
+                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * WN + j * 16 + 4 * g;
+                if (n >= p.N) continue;
+                float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+                cg_store4(p, m, b, n, step, v);
+            }
+        }
+    }
+}
+
+// split-K: sum the fp32 slabs in slice order, then the same epilogue (plain mode only)
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, int slices) {
+    const int nq = p.N >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.M * nq) return;
+    const int m = (int)(idx / nq);
+    const int n = (int)(idx - (long long)m * nq) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < slices; ++z) {
+        const float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    const int step = p.step_ptr ? *p.step_ptr : 0;
+    cg_store4(p, m, m / p.hw_out, n, step, v);
+}
+
+static bool g_cg_attr_done = false;
+int msd_conv_gemm_init() {
+    if (g_cg_attr_done) return MSD_OK;
+    hipError_t e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 128>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128);
+    if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_gemm<128,128>): %s", hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128);
+    if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_gemm<128,64>): %s", hipGetErrorString(e));
+    g_cg_attr_done = true;
+    return MSD_OK;
+}
+
+extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q) MSD_FAIL(MSD_E_ARG, "conv_gemm: null params");
+    if (!q->a0 || !q->w || !q->out) MSD_FAIL(MSD_E_ARG, "conv_gemm: null a0/w/out");
+    if (q->batch <= 0 || q->h_in <= 0 || q->w_in <= 0 || q->h_out <= 0 || q->w_out <= 0)
+        MSD_FAIL(MSD_E_ARG, "conv_gemm: non-positive dims");
+    if (q->c0 <= 0 || (q->c0 % 64) || q->c1 < 0 || (q->c1 % 64) || (q->c1 > 0 && !q->a1))
+        MSD_FAIL(MSD_E_ARG, "conv_gemm: channel counts must be positive multiples of 64 (c0=%d c1=%d)", q->c0, q->c1);
+    if (!((q->ksize == 1 && q->pad == 0) || (q->ksize == 3 && q->pad == 1)))
+        MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: ksize/pad %d/%d", q->ksize, q->pad);
+    if (q->stride != 1 && q->stride != 2) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: stride %d", q->stride);
+    {
+        const int hl = q->upsample ? 2 * q->h_in : q->h_in, wl = q->upsample ? 2 * q->w_in : q->w_in;
+        const int ho = (hl + 2 * q->pad - q->ksize) / q->stride + 1, wo = (wl + 2 * q->pad - q->ksize) / q->stride + 1;
+        if (ho != q->h_out || wo != q->w_out)
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: output dims %dx%d do not match the geometry (%dx%d)", q->h_out, q->w_out, ho, wo);
+    }
+    if (q->N <= 0 || (q->N % 4)) MSD_FAIL(MSD_E_ARG, "conv_gemm: N=%d must be a positive multiple of 4", q->N);
+    if (!msd_aligned16(q->a0) || !msd_aligned16(q->a1) || !msd_aligned16(q->w) || !msd_aligned16(q->out) ||
+        !msd_aligned16(q->bias) || !msd_aligned16(q->rowvec) || !msd_aligned16(q->residual) ||
+        !msd_aligned16(q->workspace) || !msd_aligned16(q->out1) || !msd_aligned16(q->out2))
+        MSD_FAIL(MSD_E_ALIGN, "conv_gemm: pointers must be 16-byte aligned");
+    if ((q->out_ld % 4) || (q->residual && (q->res_ld % 4)) || (q->rv_step_stride % 4) || (q->rv_batch_stride % 4))
+        MSD_FAIL(MSD_E_ALIGN, "conv_gemm: leading dimensions must be multiples of 4");
+    if (q->act < 0 || q->act > 2) MSD_FAIL(MSD_E_ARG, "conv_gemm: act");
+    if (q->act == MSD_ACT_GEGLU && ((q->N % 32) || q->out_dtype != MSD_OUT_BF16 || q->split_mode || q->rowvec))
+        MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: GEGLU needs N%%32==0, bf16 out, plain mode");
+    if (q->split_mode) {
+        if (q->split_mode != 1 || (q->ns0 % 4) || (q->ns1 % 4) || q->ns0 < 0 || q->ns1 < 0 || q->ns0 + q->ns1 > q->N ||
+            q->out_dtype != MSD_OUT_BF16 || q->residual || q->act == MSD_ACT_GEGLU)
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: bad split mode arguments");
+        if ((q->ns0 > 0 && (q->out_ld % 4)) || (q->ns1 > 0 && (!q->out1 || (q->out1_ld % 4))) ||
+            (q->ns0 + q->ns1 < q->N && (!q->out2 || q->out2_ld < q->h_out * q->w_out)))
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: split outputs");
+    }
+    int rc = msd_conv_gemm_init();
+    if (rc) return rc;
+
+    CGArgs a;
+    a.a0 = (const bf16_t*)q->a0; a.a1 = (const bf16_t*)q->a1; a.w = (const bf16_t*)q->w;
+    a.bias = q->bias; a.rowvec = q->rowvec; a.step_ptr = q->step_ptr;
+    a.residual = (const bf16_t*)q->residual; a.out = q->out; a.out1 = (bf16_t*)q->out1; a.out2 = (bf16_t*)q->out2;
+    a.ws = q->workspace;
+    a.batch = q->batch; a.h_in = q->h_in; a.w_in = q->w_in; a.c0 = q->c0; a.c1 = q->c1;
+    a.h_out = q->h_out; a.w_out = q->w_out; a.ksize = q->ksize; a.stride = q->stride; a.pad = q->pad;
+    a.upsample = q->upsample ? 1 : 0;
+    a.hw_out = q->h_out * q->w_out;
+    const long long M = (long long)q->batch * a.hw_out;
+    if (M > (1ll << 30)) MSD_FAIL(MSD_E_ARG, "conv_gemm: M too large");
+    a.M = (int)M; a.N = q->N;
+    const int cin = q->c0 + q->c1;
+    a.K = q->ksize * q->ksize * cin;
+    a.nkc = cin / 64;
+    a.nk = q->ksize * q->ksize * a.nkc;
+    a.act = q->act; a.out_f32 = (q->out_dtype == MSD_OUT_F32);
+    a.out_ld = q->out_ld; a.res_ld = q->res_ld;
+    a.rv_step_stride = q->rv_step_stride; a.rv_batch_stride = q->rv_batch_stride;
+    a.split_mode = q->split_mode; a.ns0 = q->ns0; a.ns1 = q->ns1; a.out1_ld = q->out1_ld; a.out2_ld = q->out2_ld;
+
+    int splitk = q->splitk < 1 ? 1 : q->splitk;
+    if (splitk > a.nk) splitk = a.nk;
+    a.nk_per = (a.nk + splitk - 1) / splitk;
+    const int slices = (a.nk + a.nk_per - 1) / a.nk_per;
+    if (slices > 1) {
+        if (q->split_mode || q->act == MSD_ACT_GEGLU) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: split-K needs plain mode");
+        if (!q->workspace || q->workspace_floats < (long long)slices * a.M * a.N)
+            MSD_FAIL(MSD_E_WORKSPACE, "conv_gemm: split-K workspace too small (%lld < %lld floats)",
+                     (long long)q->workspace_floats, (long long)slices * a.M * a.N);
+    }
+    int bn = q->tile_n;
+    if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
+    if (bn != 64 && bn != 128) MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_n must be 0, 64 or 128");
+    const int tiles_m = (a.M + 127) / 128;
+    a.tiles_n = (a.N + bn - 1) / bn;
+    dim3 grid(tiles_m * a.tiles_n, slices);
+    if (bn == 128)
+        hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 2 * (128 + 128) * 128, stream, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<128, 64>), grid, dim3(256), 2 * (128 + 64) * 128, stream, a);
+    MSD_CHECK_LAUNCH();
+    if (slices > 1) {
+        const long long quads = (long long)a.M * (a.N / 4);
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices);
+        MSD_CHECK_LAUNCH();
+    }
+    return MSD_OK;
+}

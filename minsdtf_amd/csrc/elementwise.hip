@@ -1,0 +1,131 @@
+// Host-loop arithmetic of the reference moved onto the device, plus small elementwise helpers.
+//
+// msd_cfg_step fuses stable_diffusion.py:458-461 (classifier-free guidance and
+// rescale_noise_cfg, :304-315) with Scheduler.step's deterministic branch
+// (scheduler.py:272-285,308-312) so the latent never leaves HBM between UNet calls.  The
+// reference does this in numpy: float32 for CFG / std, float64 for the sampler coefficients;
+// here everything is fp32 except the four per-sample moments, which accumulate in fp64.
+#include "common.h"
+
+struct CfgArgs {
+    const float* eps; float* latent; const float* coef; const int32_t* step_ptr;
+    int batch, n, num_steps;
+    float guidance, rescale;
+};
+
+__device__ __forceinline__ double block_sum_1024(double v, double* red) {
+    // wave reduce then 16 waves through LDS
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
+    __shared__ double red[16];
+    const int b = blockIdx.x, t = threadIdx.x;
+    int step = p.step_ptr ? *p.step_ptr : 0;
+    if (step > p.num_steps - 1) step = p.num_steps - 1;
+    if (step < 0) step = 0;
+    const float sr = p.coef[step * 4 + 0], nr = p.coef[step * 4 + 1];
+    const float sr_prev = p.coef[step * 4 + 2], nr_prev = p.coef[step * 4 + 3];
+    const bool last = (step == p.num_steps - 1);
+    float* lat = p.latent + (size_t)b * p.n;
+    const bool cfg = p.guidance > 0.0f;
+    const float* u = p.eps + (size_t)b * p.n;
+    const float* c = cfg ? p.eps + (size_t)(p.batch + b) * p.n : u;
+    float factor = 1.0f;
+    if (cfg && p.rescale > 0.0f) {
+        double s_c = 0, q_c = 0, s_g = 0, q_g = 0;
+        for (int i = t; i < p.n; i += 1024) {
+            const float cu = u[i], cc = c[i];
+            const float gq = cu + p.guidance * (cc - cu);
+            s_c += cc; q_c += (double)cc * cc; s_g += gq; q_g += (double)gq * gq;
+        }
+        s_c = block_sum_1024(s_c, red); q_c = block_sum_1024(q_c, red);
+        s_g = block_sum_1024(s_g, red); q_g = block_sum_1024(q_g, red);
+        const double n = (double)p.n;
+        const double mc = s_c / n, mg = s_g / n;
+        const double vc = fmax(q_c / n - mc * mc, 0.0), vg = fmax(q_g / n - mg * mg, 0.0);
+        const float std_text = (float)sqrt(vc);
+        const float std_cfg = (float)sqrt(vg) + 1e-5f;
+        factor = p.rescale * (std_text / std_cfg) + (1.0f - p.rescale);
+    }
+    for (int i = t; i < p.n; i += 1024) {
+        float e;
+        if (cfg) { const float cu = u[i], cc = c[i]; e = (cu + p.guidance * (cc - cu)) * factor; }
+        else e = u[i];
+        const float x0 = (lat[i] - nr * e) / sr;
+        lat[i] = last ? x0 : (sr_prev * x0 + nr_prev * e);
+    }
+}
+
+__global__ void step_advance_kernel(int32_t* step_ptr) { *step_ptr = *step_ptr + 1; }
+
+extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !q->eps || !q->latent || !q->coef) MSD_FAIL(MSD_E_ARG, "cfg_step: null pointer");
+    if (q->batch <= 0 || q->n <= 0 || q->num_steps <= 0) MSD_FAIL(MSD_E_ARG, "cfg_step: bad dims");
+    if (q->advance && !q->step_ptr) MSD_FAIL(MSD_E_ARG, "cfg_step: advance needs step_ptr");
+    CfgArgs a;
+    a.eps = q->eps; a.latent = q->latent; a.coef = q->coef; a.step_ptr = q->step_ptr;
+    a.batch = q->batch; a.n = q->n; a.num_steps = q->num_steps; a.guidance = q->guidance; a.rescale = q->guidance_rescale;
+    hipLaunchKernelGGL(cfg_step_kernel, dim3(q->batch), dim3(1024), 0, stream, a);
+    MSD_CHECK_LAUNCH();
+    if (q->advance) {
+        hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, stream, q->step_ptr);
+        MSD_CHECK_LAUNCH();
+    }
+    return MSD_OK;
+}
+
+__global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* a, const uint4* b, uint4* o, long long nvec) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float fa[8], fb[8];
+        unpack8(a[i], fa); unpack8(b[i], fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+        o[i] = pack8(fa);
+    }
+}
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* in, bf16_t* out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = f2bf(in[i]);
+}
+__global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* in, float* out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = bf2f(in[i]);
+}
+static unsigned grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+extern "C" int msd_add_bf16(const void* a, const void* b, void* out, int64_t n, msd_stream_t stream_) {
+    if (!a || !b || !out || n <= 0 || (n % 8)) MSD_FAIL(MSD_E_ARG, "add_bf16: bad arguments");
+    if (!msd_aligned16(a) || !msd_aligned16(b) || !msd_aligned16(out)) MSD_FAIL(MSD_E_ALIGN, "add_bf16: alignment");
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream_, (const uint4*)a,
+                       (const uint4*)b, (uint4*)out, (long long)(n / 8));
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}
+extern "C" int msd_cast_f32_to_bf16(const float* in, void* out, int64_t n, msd_stream_t stream_) {
+    if (!in || !out || n <= 0) MSD_FAIL(MSD_E_ARG, "cast: bad arguments");
+    hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream_, in, (bf16_t*)out, (long long)n);
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}
+extern "C" int msd_cast_bf16_to_f32(const void* in, float* out, int64_t n, msd_stream_t stream_) {
+    if (!in || !out || n <= 0) MSD_FAIL(MSD_E_ARG, "cast: bad arguments");
+    hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)in, out, (long long)n);
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}
+extern "C" int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream_) {
+    if (!ptr || bytes <= 0) MSD_FAIL(MSD_E_ARG, "memset_zero: bad arguments");
+    hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream_);
+    if (e != hipSuccess) MSD_FAIL((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    return MSD_OK;
+}

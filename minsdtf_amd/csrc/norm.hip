@@ -1,0 +1,255 @@
+// GroupNormalization(32)(+swish) and LayerNormalization for NHWC bf16 tensors, fp32 statistics.
+//
+// Replaces keras GroupNormalization / Activation("swish") / LayerNormalization on the hot path
+// (diffusion_model.py:27-28,32-33,57,84-88,277-278; layers.py:32,66-68,78-79;
+// image_decoder.py:51-52).  These kernels are HBM-bound: every access is a 16-byte vector
+// (8 bf16 channels) and consecutive lanes cover consecutive channels of one pixel, so a wave
+// instruction touches whole 128-byte lines.  The channel concat of the UNet up path is read
+// through two base pointers (x0|x1) and never materialised.
+#include "common.h"
+
+struct GNArgs {
+    const bf16_t* x0; const bf16_t* x1;
+    const float* gamma; const float* beta;
+    float* stats; bf16_t* out;
+    int batch, hw, c0, c1, C, cv, tpp, pl, ppb, silu;
+    float eps;
+};
+
+template <int VPT>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* part = reinterpret_cast<float*>(smem_raw);  // [pl][C][2]
+    float* chan = part + (size_t)p.pl * p.C * 2;        // [C][2]
+    const int t = threadIdx.x, b = blockIdx.y;
+    const int cvi = t % p.tpp, pli = t / p.tpp;
+    const bool active = pli < p.pl;
+    const int p_begin = blockIdx.x * p.ppb;
+    const int p_end = min(p.hw, p_begin + p.ppb);
+
+    float s[VPT][8], ss[VPT][8];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[v][e] = 0.f; ss[v][e] = 0.f; }
+
+    if (active) {
+        for (int px = p_begin + pli; px < p_end; px += p.pl) {
+            const size_t pix = (size_t)b * p.hw + px;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int cv = cvi + v * p.tpp;
+                if (cv < p.cv) {
+                    const int c = cv * 8;
+                    const bf16_t* src = (c < p.c0) ? (p.x0 + pix * p.c0 + c) : (p.x1 + pix * p.c1 + (c - p.c0));
+                    const uint4 raw = *reinterpret_cast<const uint4*>(src);
+                    float f[8];
+                    unpack8(raw, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[v][e] += f[e]; ss[v][e] += f[e] * f[e]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int cv = cvi + v * p.tpp;
+            if (cv < p.cv) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    part[((size_t)pli * p.C + cv * 8 + e) * 2 + 0] = s[v][e];
+                    part[((size_t)pli * p.C + cv * 8 + e) * 2 + 1] = ss[v][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < p.C; c += 256) {
+        float a = 0.f, q = 0.f;
+        for (int l = 0; l < p.pl; ++l) {
+            a += part[((size_t)l * p.C + c) * 2 + 0];
+            q += part[((size_t)l * p.C + c) * 2 + 1];
+        }
+        chan[c * 2 + 0] = a;
+        chan[c * 2 + 1] = q;
+    }
+    __syncthreads();
+    if (t < 32) {
+        const int cpg = p.C / 32;
+        float a = 0.f, q = 0.f;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) { a += chan[c * 2]; q += chan[c * 2 + 1]; }
+        atomicAdd(p.stats + ((size_t)b * 32 + t) * 2 + 0, a);
+        atomicAdd(p.stats + ((size_t)b * 32 + t) * 2 + 1, q);
+    }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p) {
+    __shared__ float s_mean[32], s_rstd[32];
+    const int t = threadIdx.x, b = blockIdx.y;
+    if (t < 32) {
+        const float cnt = (float)p.hw * (float)(p.C / 32);
+        const float sum = p.stats[((size_t)b * 32 + t) * 2 + 0];
+        const float sq = p.stats[((size_t)b * 32 + t) * 2 + 1];
+        const float mean = sum / cnt;
+        const float var = fmaxf(sq / cnt - mean * mean, 0.f);
+        s_mean[t] = mean;
+        s_rstd[t] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    const int cvi = t % p.tpp, pli = t / p.tpp;
+    if (pli >= p.pl) return;
+    const int cpg = p.C / 32;
+    float ca[VPT][8], cb[VPT][8];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int cv = cvi + v * p.tpp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ca[v][e] = 0.f; cb[v][e] = 0.f;
+            if (cv < p.cv) {
+                const int c = cv * 8 + e;
+                const int g = c / cpg;
+                const float a = s_rstd[g] * p.gamma[c];
+                ca[v][e] = a;
+                cb[v][e] = p.beta[c] - s_mean[g] * a;
+            }
+        }
+    }
+    const int p_begin = blockIdx.x * p.ppb;
+    const int p_end = min(p.hw, p_begin + p.ppb);
+    for (int px = p_begin + pli; px < p_end; px += p.pl) {
+        const size_t pix = (size_t)b * p.hw + px;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int cv = cvi + v * p.tpp;
+            if (cv < p.cv) {
+                const int c = cv * 8;
+                const bf16_t* src = (c < p.c0) ? (p.x0 + pix * p.c0 + c) : (p.x1 + pix * p.c1 + (c - p.c0));
+                const uint4 raw = *reinterpret_cast<const uint4*>(src);
+                float f[8];
+                unpack8(raw, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = f[e] * ca[v][e] + cb[v][e];
+                    f[e] = p.silu ? silu_f(y) : y;
+                }
+                *reinterpret_cast<uint4*>(p.out + pix * p.C + c) = pack8(f);
+            }
+        }
+    }
+}
+
+extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !q->x0 || !q->gamma || !q->beta || !q->stats || !q->out) MSD_FAIL(MSD_E_ARG, "group_norm: null pointer");
+    if (q->batch <= 0 || q->hw <= 0 || q->c0 <= 0 || q->c1 < 0 || (q->c1 > 0 && !q->x1))
+        MSD_FAIL(MSD_E_ARG, "group_norm: bad dims");
+    const int C = q->c0 + q->c1;
+    if ((q->c0 % 8) || (q->c1 % 8) || (C % 32) || C > 4096)
+        MSD_FAIL(MSD_E_UNSUPPORTED, "group_norm: c0,c1 must be multiples of 8, C of 32, C<=4096 (c0=%d c1=%d)", q->c0, q->c1);
+    if (!msd_aligned16(q->x0) || !msd_aligned16(q->x1) || !msd_aligned16(q->out))
+        MSD_FAIL(MSD_E_ALIGN, "group_norm: pointers must be 16-byte aligned");
+    GNArgs a;
+    a.x0 = (const bf16_t*)q->x0; a.x1 = (const bf16_t*)q->x1; a.gamma = q->gamma; a.beta = q->beta;
+    a.stats = q->stats; a.out = (bf16_t*)q->out;
+    a.batch = q->batch; a.hw = q->hw; a.c0 = q->c0; a.c1 = q->c1; a.C = C; a.cv = C / 8;
+    a.tpp = a.cv < 256 ? a.cv : 256;
+    a.pl = 256 / a.tpp;
+    a.silu = q->silu ? 1 : 0; a.eps = q->eps;
+    const int vpt = (a.cv + 255) / 256;  // 1 or 2
+    // pixels per block: aim at >= ~1024 workgroups chip-wide but at least 4 passes of pl pixels each
+    long long target_blocks = 1024 / q->batch;
+    if (target_blocks < 1) target_blocks = 1;
+    int ppb = (int)((q->hw + target_blocks - 1) / target_blocks);
+    const int min_ppb = a.pl * 4;
+    if (ppb < min_ppb) ppb = min_ppb;
+    if (ppb > q->hw) ppb = q->hw;
+    a.ppb = ppb;
+    const int nchunks = (q->hw + ppb - 1) / ppb;
+    dim3 grid(nchunks, q->batch);
+    const size_t lds = ((size_t)a.pl * C * 2 + (size_t)C * 2) * sizeof(float);
+    if (vpt == 1) {
+        hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), lds, stream, a);
+        MSD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), lds, stream, a);
+        MSD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_apply_kernel<2>, grid, dim3(256), 0, stream, a);
+    }
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}
+
+// ---- LayerNorm: one wave per row, the row lives in registers between the two reductions ------
+template <int NV>
+__global__ __launch_bounds__(256) void layer_norm_kernel(const bf16_t* x, const float* gamma, const float* beta,
+                                                         bf16_t* out, int rows, int c, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int ncv = c >> 3;
+    float f[NV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int cv = lane + 64 * v;
+        if (cv < ncv) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(x + (size_t)row * c + cv * 8);
+            unpack8(raw, f[v]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += f[v][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[v][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)c;
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int cv = lane + 64 * v;
+        if (cv < ncv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[v][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)c + eps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int cv = lane + 64 * v;
+        if (cv < ncv) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + cv * 8);
+            const float4 g1 = *reinterpret_cast<const float4*>(gamma + cv * 8 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + cv * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(beta + cv * 8 + 4);
+            float o[8];
+            o[0] = (f[v][0] - mean) * rstd * g0.x + b0.x; o[1] = (f[v][1] - mean) * rstd * g0.y + b0.y;
+            o[2] = (f[v][2] - mean) * rstd * g0.z + b0.z; o[3] = (f[v][3] - mean) * rstd * g0.w + b0.w;
+            o[4] = (f[v][4] - mean) * rstd * g1.x + b1.x; o[5] = (f[v][5] - mean) * rstd * g1.y + b1.y;
+            o[6] = (f[v][6] - mean) * rstd * g1.z + b1.z; o[7] = (f[v][7] - mean) * rstd * g1.w + b1.w;
+            *reinterpret_cast<uint4*>(out + (size_t)row * c + cv * 8) = pack8(o);
+        }
+    }
+}
+
+extern "C" int msd_layer_norm(const void* x, const float* gamma, const float* beta, void* out, int32_t rows, int32_t c,
+                              float eps, msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !gamma || !beta || !out) MSD_FAIL(MSD_E_ARG, "layer_norm: null pointer");
+    if (rows <= 0 || c <= 0 || (c % 8) || c > 2048) MSD_FAIL(MSD_E_UNSUPPORTED, "layer_norm: c=%d must be a multiple of 8, <=2048", c);
+    if (!msd_aligned16(x) || !msd_aligned16(out) || !msd_aligned16(gamma) || !msd_aligned16(beta))
+        MSD_FAIL(MSD_E_ALIGN, "layer_norm: pointers must be 16-byte aligned");
+    const int nv = (c / 8 + 63) / 64;
+    dim3 grid((rows + 3) / 4);
+    const bf16_t* xi = (const bf16_t*)x;
+    bf16_t* o = (bf16_t*)out;
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(layer_norm_kernel<1>, grid, dim3(256), 0, stream, xi, gamma, beta, o, rows, c, eps); break;
+        case 2: hipLaunchKernelGGL(layer_norm_kernel<2>, grid, dim3(256), 0, stream, xi, gamma, beta, o, rows, c, eps); break;
+        case 3: hipLaunchKernelGGL(layer_norm_kernel<3>, grid, dim3(256), 0, stream, xi, gamma, beta, o, rows, c, eps); break;
+        default: hipLaunchKernelGGL(layer_norm_kernel<4>, grid, dim3(256), 0, stream, xi, gamma, beta, o, rows, c, eps); break;
+    }
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}

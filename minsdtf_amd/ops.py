@@ -1,0 +1,146 @@
+"""Typed launch records for the C ABI (include/minsdtf_hip.h).
+
+Every function here only *describes* one library call: it fills the ctypes argument block from
+raw device addresses + shapes and returns a :class:`Call`.  Running a Call on a stream is one
+foreign call, so a whole UNet forward is a flat Python list of Calls that is recorded once and
+then replayed from a hipGraph.  No arithmetic happens in this module and nothing falls back to
+PyTorch: if the library is missing, :func:`_lib.load` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+from . import _lib
+from ._lib import ACT_GEGLU, ACT_NONE, ACT_SILU, OUT_BF16, OUT_F32, OUT_U8  # noqa: F401
+
+
+class Call:
+    """One stream-ordered library call: ``fn(*args, stream)``."""
+
+    __slots__ = ("fn", "args", "name", "keep")
+
+    def __init__(self, fn, args, name, keep=None):
+        self.fn, self.args, self.name, self.keep = fn, args, name, keep
+
+    def __call__(self, stream: int) -> None:
+        rc = self.fn(*self.args, stream)
+        if rc != 0:
+            _lib.check(rc, self.name)
+
+
+def _p(x) -> Optional[int]:
+    """Device address of a torch tensor / Buf / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "ptr"):
+        return x.ptr
+    return x.data_ptr()
+
+
+def conv_gemm(*, a0, w, out, batch, h_in, w_in, c0, N, a1=None, c1=0, ksize=1, stride=1, upsample=False, bias=None,
+              rowvec=None, rv_step_stride=0, rv_batch_stride=0, step_ptr=None, residual=None, res_ld=None, act=ACT_NONE,
+              out_dtype=OUT_BF16, out_ld=None, split=None, workspace=None, workspace_floats=0, splitk=1, tile_n=0,
+              name="conv_gemm") -> Call:
+    """split = (ns0, ns1, out1, out1_ld, out2, out2_ld) selects the q|k|v^T epilogue."""
+    lib = _lib.load()
+    pad = 1 if ksize == 3 else 0
+    hl, wl = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
+    h_out = (hl + 2 * pad - ksize) // stride + 1
+    w_out = (wl + 2 * pad - ksize) // stride + 1
+    n_out = N // 2 if act == ACT_GEGLU else N
+    s = _lib.MsdConvGemm()
+    s.a0, s.a1, s.w = _p(a0), _p(a1), _p(w)
+    s.bias, s.rowvec, s.step_ptr, s.residual = _p(bias), _p(rowvec), _p(step_ptr), _p(residual)
+    s.out = _p(out)
+    s.workspace, s.workspace_floats = _p(workspace), int(workspace_floats)
+    s.batch, s.h_in, s.w_in, s.c0, s.c1 = batch, h_in, w_in, c0, c1
+    s.h_out, s.w_out, s.ksize, s.stride, s.pad, s.upsample = h_out, w_out, ksize, stride, pad, int(bool(upsample))
+    s.N, s.act, s.out_dtype = N, act, out_dtype
+    s.out_ld = n_out if out_ld is None else out_ld
+    s.res_ld = (n_out if res_ld is None else res_ld) if residual is not None else 0
+    s.rv_step_stride, s.rv_batch_stride = rv_step_stride, rv_batch_stride
+    if split is not None:
+        ns0, ns1, out1, out1_ld, out2, out2_ld = split
+        s.split_mode, s.ns0, s.ns1 = 1, ns0, ns1
+        s.out1, s.out1_ld, s.out2, s.out2_ld = _p(out1), out1_ld, _p(out2), out2_ld
+        if out_ld is None:
+            s.out_ld = max(ns0, 4)
+    s.splitk, s.tile_n = splitk, tile_n
+    return Call(lib.msd_conv_gemm, (C.byref(s),), name, keep=s)
+
+
+def conv_direct(*, x, w, out, batch, h_in, w_in, c_in, c_out, ksize=3, stride=1, bias=None, residual=None,
+                in_batch_mod=None, in_dtype=OUT_BF16, out_dtype=OUT_BF16, act=ACT_NONE, act_in=False, in_scale=1.0,
+                name="conv_direct") -> Call:
+    lib = _lib.load()
+    pad = 1 if ksize == 3 else 0
+    s = _lib.MsdConvDirect()
+    s.in_, s.w, s.bias, s.residual, s.out = _p(x), _p(w), _p(bias), _p(residual), _p(out)
+    s.batch, s.in_batch_mod = batch, (batch if in_batch_mod is None else in_batch_mod)
+    s.h_in, s.w_in, s.c_in = h_in, w_in, c_in
+    s.h_out = (h_in + 2 * pad - ksize) // stride + 1
+    s.w_out = (w_in + 2 * pad - ksize) // stride + 1
+    s.c_out, s.ksize, s.stride, s.pad = c_out, ksize, stride, pad
+    s.in_dtype, s.out_dtype, s.act, s.act_in, s.in_scale = in_dtype, out_dtype, act, int(bool(act_in)), float(in_scale)
+    return Call(lib.msd_conv_direct, (C.byref(s),), name, keep=s)
+
+
+def group_norm(*, x0, gamma, beta, stats, out, batch, hw, c0, x1=None, c1=0, silu=False, eps=1e-5,
+               name="group_norm") -> Call:
+    lib = _lib.load()
+    s = _lib.MsdGroupNorm()
+    s.x0, s.x1, s.gamma, s.beta, s.stats, s.out = _p(x0), _p(x1), _p(gamma), _p(beta), _p(stats), _p(out)
+    s.batch, s.hw, s.c0, s.c1, s.silu, s.eps = batch, hw, c0, c1, int(bool(silu)), float(eps)
+    return Call(lib.msd_group_norm, (C.byref(s),), name, keep=s)
+
+
+def layer_norm(*, x, gamma, beta, out, rows, c, eps=1e-5, name="layer_norm") -> Call:
+    lib = _lib.load()
+    return Call(lib.msd_layer_norm, (_p(x), _p(gamma), _p(beta), _p(out), rows, c, C.c_float(eps)), name)
+
+
+def attention(*, q, k, vt, out, batch, heads, head_dim, s, t, q_ld, k_ld, vt_ld, o_ld, scale, name="attention") -> Call:
+    lib = _lib.load()
+    a = _lib.MsdAttention()
+    a.q, a.k, a.vt, a.out = _p(q), _p(k), _p(vt), _p(out)
+    a.batch, a.heads, a.head_dim, a.s, a.t = batch, heads, head_dim, s, t
+    a.q_ld, a.k_ld, a.vt_ld, a.o_ld, a.scale = q_ld, k_ld, vt_ld, o_ld, float(scale)
+    return Call(lib.msd_attention, (C.byref(a),), name, keep=a)
+
+
+def softmax_rows(*, x, out, rows, cols, ld_in, ld_out, scale, name="softmax_rows") -> Call:
+    lib = _lib.load()
+    return Call(lib.msd_softmax_rows, (_p(x), _p(out), rows, cols, ld_in, ld_out, C.c_float(scale)), name)
+
+
+def cfg_step(*, eps, latent, coef, step_ptr, batch, n, num_steps, guidance, guidance_rescale, advance=True,
+             name="cfg_step") -> Call:
+    lib = _lib.load()
+    s = _lib.MsdCfgStep()
+    s.eps, s.latent, s.coef, s.step_ptr = _p(eps), _p(latent), _p(coef), _p(step_ptr)
+    s.batch, s.n, s.num_steps = batch, n, num_steps
+    s.guidance, s.guidance_rescale, s.advance = float(guidance), float(guidance_rescale), int(bool(advance))
+    return Call(lib.msd_cfg_step, (C.byref(s),), name, keep=s)
+
+
+def add_bf16(*, a, b, out, n, name="add_bf16") -> Call:
+    lib = _lib.load()
+    return Call(lib.msd_add_bf16, (_p(a), _p(b), _p(out), n), name)
+
+
+def cast_f32_to_bf16(*, x, out, n, name="cast_f2b") -> Call:
+    lib = _lib.load()
+    return Call(lib.msd_cast_f32_to_bf16, (_p(x), _p(out), n), name)
+
+
+def cast_bf16_to_f32(*, x, out, n, name="cast_b2f") -> Call:
+    lib = _lib.load()
+    return Call(lib.msd_cast_bf16_to_f32, (_p(x), _p(out), n), name)
+
+
+def memset_zero(*, ptr, nbytes, name="memset") -> Call:
+    lib = _lib.load()
+    return Call(lib.msd_memset_zero, (_p(ptr), nbytes), name)

@@ -1,0 +1,59 @@
+"""Weight pre-packing: Keras-layout fp32 weights -> the layouts the gfx950 kernels consume.
+
+Done once at ``set_weights`` time on the host (layout only, no arithmetic beyond the bf16 round):
+
+* MFMA path (``msd_conv_gemm``): ``W[N][K]`` bf16, K contiguous, ``k = (ky*ks + kx)*C_in + c`` —
+  i.e. HWIO ``(kh,kw,cin,cout)`` -> ``(cout,kh,kw,cin)``; Dense ``(in,out)`` -> ``(out,in)``.
+* GEGLU (diffusion_model.py:142-153): the ``8C`` projection rows are interleaved in 16-wide
+  ``x | gate`` groups so both halves of an output element land in one lane's accumulators.
+* q|k|v (diffusion_model.py:102-104): the three bias-free projections are stacked into one
+  ``[3C][C]`` matrix so one GEMM feeds the attention kernel (q, k row-major, v transposed).
+* direct path (``msd_conv_direct``): fp32 Keras layout unchanged.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def _dev_bf16(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(torch.bfloat16).contiguous().to(device)
+
+
+def pack_conv(w_hwio: np.ndarray, device) -> torch.Tensor:
+    """(kh,kw,cin,cout) fp32 -> [cout][kh*kw*cin] bf16 on device."""
+    t = torch.from_numpy(np.ascontiguousarray(w_hwio))
+    kh, kw, cin, cout = t.shape
+    return _dev_bf16(t.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin), device)
+
+
+def pack_dense(w_io: np.ndarray, device) -> torch.Tensor:
+    """(in,out) fp32 -> [out][in] bf16 on device."""
+    return _dev_bf16(torch.from_numpy(np.ascontiguousarray(w_io)).t(), device)
+
+
+def pack_dense_stack(ws, device) -> torch.Tensor:
+    """Stack several (in,out_i) matrices along the output axis -> [sum out_i][in] bf16."""
+    return _dev_bf16(torch.cat([torch.from_numpy(np.ascontiguousarray(w)).t() for w in ws], dim=0), device)
+
+
+def geglu_row_order(n_half: int) -> np.ndarray:
+    """Packed row p -> original column of the (in, 2*n_half) GEGLU projection.
+
+    Packed rows [32i, 32i+16) are value columns [16i, 16i+16); rows [32i+16, 32i+32) are the gate
+    columns n_half + [16i, 16i+16)."""
+    assert n_half % 16 == 0
+    p = np.arange(2 * n_half)
+    grp, within = p // 32, p % 32
+    return np.where(within < 16, grp * 16 + within, n_half + grp * 16 + (within - 16))
+
+
+def pack_geglu(w_io: np.ndarray, b: np.ndarray, device):
+    n_half = w_io.shape[1] // 2
+    order = geglu_row_order(n_half)
+    wt = torch.from_numpy(np.ascontiguousarray(w_io)).t()[torch.from_numpy(order)]
+    return _dev_bf16(wt, device), dev_f32(np.asarray(b)[order], device)
+
+
+def dev_f32(a: np.ndarray, device) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)

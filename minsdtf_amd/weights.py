@@ -1,0 +1,368 @@
+"""Checkpoint layout contract, synthetic checkpoints and checkpoint loading.
+
+The reference loads weights *positionally*: ``load_weights_from_file`` walks an ordered table
+of ``(checkpoint_key, perm)`` pairs, transposes each tensor with ``perm`` and hands the list to
+``model.set_weights`` (reference ``stable_diffusion/ckpt_loader.py:2136-2193``; tables
+``ckpt_loader.py:708-2133``).  This module *generates* the same ordered tables from the network
+topology (reference ``diffusion_model.py:184-279``, ``image_decoder.py:26-53``,
+``control_net.py:14-106``) instead of carrying 2k lines of literals; ``tests/test_weights.py``
+checks the generated tables against the reference's (when ``/root/reference`` is present) and
+against a committed digest (always).
+
+Each table row is a :class:`WeightSpec`:
+
+* ``key``      checkpoint key as the reference's table spells it (LDM naming for the UNet /
+               ControlNet, diffusers naming for the VAE),
+* ``alt_key``  the diffusers spelling the reference falls back to (``UNET_KEY_MAPPING``) or None,
+* ``name``     logical module path used by this package (diffusers-style, no ``.weight``),
+* ``kind``     one of ``conv_w dense_w bias gamma beta``,
+* ``perm``     transpose taking the checkpoint (PyTorch) layout to the Keras layout the reference
+               model holds: ``(2,3,1,0)`` OIHW->HWIO, ``(1,0)`` (out,in)->(in,out), ``None``,
+* ``shape``    the Keras-layout shape (what ``model.weights[i].shape`` is in the reference).
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+CONV_PERM = (2, 3, 1, 0)
+DENSE_PERM = (1, 0)
+
+
+@dataclass(frozen=True)
+class WeightSpec:
+    key: str
+    alt_key: Optional[str]
+    name: str
+    kind: str
+    perm: Optional[Tuple[int, ...]]
+    shape: Tuple[int, ...]
+
+    @property
+    def torch_shape(self) -> Tuple[int, ...]:
+        """Shape of the tensor as stored in the checkpoint (PyTorch layout)."""
+        if self.perm is None:
+            return self.shape
+        inv = np.argsort(self.perm)
+        return tuple(self.shape[i] for i in inv)
+
+
+class _Table:
+    def __init__(self, prefix: str, use_alt: bool):
+        self.rows: List[WeightSpec] = []
+        self.prefix = prefix
+        self.use_alt = use_alt
+
+    def _add(self, key, name, suffix, kind, perm, shape):
+        alt = (name + "." + suffix) if self.use_alt else None
+        self.rows.append(WeightSpec(self.prefix + key + "." + suffix, alt, name, kind, perm, tuple(shape)))
+
+    def conv(self, key, name, cin, cout, k):
+        self._add(key, name, "weight", "conv_w", CONV_PERM, (k, k, cin, cout))
+        self._add(key, name, "bias", "bias", None, (cout,))
+
+    def dense(self, key, name, cin, cout, bias=True):
+        self._add(key, name, "weight", "dense_w", DENSE_PERM, (cin, cout))
+        if bias:
+            self._add(key, name, "bias", "bias", None, (cout,))
+
+    def norm(self, key, name, c):
+        self._add(key, name, "weight", "gamma", None, (c,))
+        self._add(key, name, "bias", "beta", None, (c,))
+
+
+# --------------------------------------------------------------------------------------
+# UNet (reference diffusion_model.py:184-279; table order ckpt_loader.py:709-1394)
+# --------------------------------------------------------------------------------------
+UNET_CH = (320, 640, 1280, 1280)
+UNET_HEADS = 8
+CTX_DIM = 768
+TEMB_DIM = 1280
+
+
+def _ldm_resblock(t: _Table, key, name, cin, cout):
+    t.norm(key + ".in_layers.0", name + ".norm1", cin)
+    t.conv(key + ".in_layers.2", name + ".conv1", cin, cout, 3)
+    t.dense(key + ".emb_layers.1", name + ".time_emb_proj", TEMB_DIM, cout)
+    t.norm(key + ".out_layers.0", name + ".norm2", cout)
+    t.conv(key + ".out_layers.3", name + ".conv2", cout, cout, 3)
+    if cin != cout:
+        t.conv(key + ".skip_connection", name + ".conv_shortcut", cin, cout, 1)
+
+
+def _ldm_attention(t: _Table, key, name, c):
+    t.norm(key + ".norm", name + ".norm", c)
+    t.conv(key + ".proj_in", name + ".proj_in", c, c, 1)
+    tb_k, tb_n = key + ".transformer_blocks.0", name + ".transformer_blocks.0"
+    t.norm(tb_k + ".norm1", tb_n + ".norm1", c)
+    for p in ("to_q", "to_k", "to_v"):
+        t.dense(tb_k + ".attn1." + p, tb_n + ".attn1." + p, c, c, bias=False)
+    t.dense(tb_k + ".attn1.to_out.0", tb_n + ".attn1.to_out.0", c, c)
+    t.norm(tb_k + ".norm2", tb_n + ".norm2", c)
+    t.dense(tb_k + ".attn2.to_q", tb_n + ".attn2.to_q", c, c, bias=False)
+    t.dense(tb_k + ".attn2.to_k", tb_n + ".attn2.to_k", CTX_DIM, c, bias=False)
+    t.dense(tb_k + ".attn2.to_v", tb_n + ".attn2.to_v", CTX_DIM, c, bias=False)
+    t.dense(tb_k + ".attn2.to_out.0", tb_n + ".attn2.to_out.0", c, c)
+    t.norm(tb_k + ".norm3", tb_n + ".norm3", c)
+    t.dense(tb_k + ".ff.net.0.proj", tb_n + ".ff.net.0.proj", c, 8 * c)
+    t.dense(tb_k + ".ff.net.2", tb_n + ".ff.net.2", 4 * c, c)
+    t.conv(key + ".proj_out", name + ".proj_out", c, c, 1)
+
+
+def _unet_encoder(t: _Table, control: bool):
+    """Shared down + mid path of the UNet and the ControlNet (control_net.py:47-90)."""
+    t.dense("time_embed.0", "time_embedding.linear_1", 320, TEMB_DIM)
+    t.conv("input_blocks.0.0", "conv_in", 4, 320, 3)
+    t.dense("time_embed.2", "time_embedding.linear_2", TEMB_DIM, TEMB_DIM)
+    ib = 1
+    cin = 320
+    for lvl, ch in enumerate(UNET_CH):
+        for r in range(2):
+            _ldm_resblock(t, f"input_blocks.{ib}.0", f"down_blocks.{lvl}.resnets.{r}", cin, ch)
+            cin = ch
+            if lvl < 3:
+                _ldm_attention(t, f"input_blocks.{ib}.1", f"down_blocks.{lvl}.attentions.{r}", ch)
+            ib += 1
+        if lvl < 3:
+            t.conv(f"input_blocks.{ib}.0.op", f"down_blocks.{lvl}.downsamplers.0.conv", ch, ch, 3)
+            ib += 1
+    _ldm_resblock(t, "middle_block.0", "mid_block.resnets.0", 1280, 1280)
+    _ldm_attention(t, "middle_block.1", "mid_block.attentions.0", 1280)
+    _ldm_resblock(t, "middle_block.2", "mid_block.resnets.1", 1280, 1280)
+
+
+# skip-stack channel counts popped by the up path
+UNET_SKIP_CH = (320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 1280)
+
+
+def unet_table() -> List[WeightSpec]:
+    t = _Table("model.diffusion_model.", use_alt=True)
+    _unet_encoder(t, control=False)
+    skips = list(UNET_SKIP_CH)
+    cin = 1280
+    ob = 0
+    for ui, lvl in enumerate((3, 2, 1, 0)):
+        ch = UNET_CH[lvl]
+        for r in range(3):
+            sk = skips.pop()
+            _ldm_resblock(t, f"output_blocks.{ob}.0", f"up_blocks.{ui}.resnets.{r}", cin + sk, ch)
+            cin = ch
+            sub = 1
+            if lvl < 3:
+                _ldm_attention(t, f"output_blocks.{ob}.1", f"up_blocks.{ui}.attentions.{r}", ch)
+                sub = 2
+            if r == 2 and lvl > 0:
+                t.conv(f"output_blocks.{ob}.{sub}.conv", f"up_blocks.{ui}.upsamplers.0.conv", ch, ch, 3)
+            ob += 1
+    t.norm("out.0", "conv_norm_out", 320)
+    t.conv("out.2", "conv_out", 320, 4, 3)
+    return t.rows
+
+
+def controlnet_table() -> List[WeightSpec]:
+    t = _Table("control_model.", use_alt=False)
+    _unet_encoder(t, control=True)
+    for i, ch in enumerate(UNET_SKIP_CH):
+        t.conv(f"zero_convs.{i}.0", f"zero_convs.{i}", ch, ch, 1)
+    t.conv("middle_block_out.0", "zero_convs.12", 1280, 1280, 1)
+    return t.rows
+
+
+HINT_CH = ((3, 16, 1), (16, 16, 1), (16, 32, 2), (32, 32, 1), (32, 96, 2), (96, 96, 1), (96, 256, 2), (256, 320, 1))
+
+
+def hintnet_table() -> List[WeightSpec]:
+    t = _Table("control_model.", use_alt=False)
+    for i, (cin, cout, _s) in enumerate(HINT_CH):
+        t.conv(f"input_hint_block.{2 * i}", f"input_hint_block.{i}", cin, cout, 3)
+    return t.rows
+
+
+# --------------------------------------------------------------------------------------
+# VAE decoder (reference image_decoder.py:26-53, layers.py:28-80; table ckpt_loader.py:1505-1646)
+# --------------------------------------------------------------------------------------
+def _vae_resnet(t: _Table, key, cin, cout):
+    t.norm(key + ".norm1", key + ".norm1", cin)
+    t.conv(key + ".conv1", key + ".conv1", cin, cout, 3)
+    t.norm(key + ".norm2", key + ".norm2", cout)
+    t.conv(key + ".conv2", key + ".conv2", cout, cout, 3)
+    if cin != cout:
+        t.conv(key + ".conv_shortcut", key + ".conv_shortcut", cin, cout, 1)
+
+
+def _vae_attention(t: _Table, key, c):
+    t.norm(key + ".group_norm", key + ".group_norm", c)
+    for p in ("query", "key", "value", "proj_attn"):
+        t.dense(key + "." + p, key + "." + p, c, c)
+
+
+VAE_DEC_BLOCKS = ((512, 512, True), (512, 512, True), (512, 256, True), (256, 128, False))
+
+
+def decoder_table() -> List[WeightSpec]:
+    t = _Table("", use_alt=False)
+    t.conv("post_quant_conv", "post_quant_conv", 4, 4, 1)
+    t.conv("decoder.conv_in", "decoder.conv_in", 4, 512, 3)
+    _vae_resnet(t, "decoder.mid_block.resnets.0", 512, 512)
+    _vae_attention(t, "decoder.mid_block.attentions.0", 512)
+    _vae_resnet(t, "decoder.mid_block.resnets.1", 512, 512)
+    for bi, (cin, cout, up) in enumerate(VAE_DEC_BLOCKS):
+        for r in range(3):
+            _vae_resnet(t, f"decoder.up_blocks.{bi}.resnets.{r}", cin if r == 0 else cout, cout)
+        if up:
+            t.conv(f"decoder.up_blocks.{bi}.upsamplers.0.conv", f"decoder.up_blocks.{bi}.upsamplers.0.conv",
+                   cout, cout, 3)
+    t.norm("decoder.conv_norm_out", "decoder.conv_norm_out", 128)
+    t.conv("decoder.conv_out", "decoder.conv_out", 128, 3, 3)
+    return t.rows
+
+
+TABLES = {
+    "civitai_model": unet_table,
+    "decoder": decoder_table,
+    "controlnet": controlnet_table,
+    "hintnet": hintnet_table,
+}
+
+
+def table(kind: str) -> List[WeightSpec]:
+    return TABLES[kind]()
+
+
+def table_digest(kind: str) -> str:
+    """SHA-256 over the ordered (key, perm) list — the positional contract (golden G6)."""
+    h = hashlib.sha256()
+    for s in table(kind):
+        h.update(repr((s.key, s.perm)).encode())
+    return h.hexdigest()
+
+
+def param_count(kind: str) -> int:
+    return int(sum(int(np.prod(s.shape)) for s in table(kind)))
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic checkpoints: seeded Glorot-uniform, zeros bias, ones/zeros norm,
+# emitted in *checkpoint* (PyTorch) layout under the reference's key names so the same file can
+# be given to real minSDTF through unet_ckpt= / vae_ckpt= / controlnet_path=.
+# --------------------------------------------------------------------------------------
+def _glorot_limit(spec: WeightSpec) -> float:
+    if spec.kind == "conv_w":
+        kh, kw, cin, cout = spec.shape
+        fan_in, fan_out = kh * kw * cin, kh * kw * cout
+    else:
+        fan_in, fan_out = spec.shape
+    return float(np.sqrt(6.0 / (fan_in + fan_out)))
+
+
+def synth_tensors(kind: str, seed: int = 0, bias_scale: float = 0.0) -> Iterator[Tuple[WeightSpec, np.ndarray]]:
+    """Yield (spec, tensor in checkpoint/PyTorch layout) in table order.
+
+    One PCG64 stream per table, consumed in table order, so the values do not depend on how the
+    caller batches the work.  ``bias_scale`` > 0 draws biases / norm offsets from U(-s, s) (used by
+    parity tests so that bias / beta paths are not vacuous); 0 gives the Keras default init.
+    """
+    salt = {"civitai_model": 0, "decoder": 1, "controlnet": 2, "hintnet": 3}[kind]
+    rng = np.random.Generator(np.random.PCG64([seed, salt]))
+    for spec in table(kind):
+        if spec.kind in ("conv_w", "dense_w"):
+            lim = np.float32(_glorot_limit(spec))
+            w = rng.random(size=spec.torch_shape, dtype=np.float32)
+            w *= np.float32(2.0) * lim
+            w -= lim
+        elif spec.kind == "gamma":
+            w = np.ones(spec.shape, np.float32)
+            if bias_scale > 0:
+                w += rng.uniform(-bias_scale, bias_scale, size=spec.shape).astype(np.float32)
+        else:
+            w = np.zeros(spec.shape, np.float32)
+            if bias_scale > 0:
+                w = rng.uniform(-bias_scale, bias_scale, size=spec.shape).astype(np.float32)
+        yield spec, w
+
+
+def to_keras_layout(spec: WeightSpec, w: np.ndarray) -> np.ndarray:
+    """Apply the table's perm (ckpt_loader.py:2181-2182); returns a contiguous array."""
+    if spec.perm is None:
+        return w
+    import torch  # torch's permute+contiguous is multi-threaded; numpy's is not
+
+    return torch.from_numpy(np.ascontiguousarray(w)).permute(*spec.perm).contiguous().numpy()
+
+
+def synth_keras_weights(kind: str, seed: int = 0, bias_scale: float = 0.0) -> List[np.ndarray]:
+    """Ordered list in Keras layout — what ``set_weights`` receives in the reference."""
+    return [to_keras_layout(s, w) for s, w in synth_tensors(kind, seed, bias_scale)]
+
+
+def write_synthetic_checkpoint(path: str, kinds=("civitai_model",), seed: int = 0, bias_scale: float = 0.0) -> None:
+    """Write a .safetensors file under the reference's checkpoint keys (PyTorch layout)."""
+    import torch
+    from safetensors.torch import save_file
+
+    sd = {}
+    for kind in kinds:
+        for spec, w in synth_tensors(kind, seed, bias_scale):
+            sd[spec.key] = torch.from_numpy(np.ascontiguousarray(w))
+    save_file(sd, path)
+
+
+# --------------------------------------------------------------------------------------
+# Loading real / synthetic checkpoint files (mirrors ckpt_loader.load_weights_from_file)
+# --------------------------------------------------------------------------------------
+def read_state_dict(ckpt_path: str) -> Dict[str, np.ndarray]:
+    if ckpt_path.endswith(".safetensors"):
+        from safetensors import safe_open
+
+        out = {}
+        with safe_open(ckpt_path, framework="pt", device="cpu") as f:
+            for k in f.keys():
+                out[k] = f.get_tensor(k)
+        return out
+    import torch
+
+    sd = torch.load(ckpt_path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    return sd
+
+
+def load_weights_from_file(model, ckpt_path: str, kind: str, lora_dict: Optional[dict] = None) -> None:
+    """Positional load with the reference's semantics (ckpt_loader.py:2136-2193).
+
+    ``model`` exposes ``name``, ``weights`` (ordered objects with ``.shape``/``.name`` in Keras
+    layout) and ``set_weights(list)`` — the same surface the reference loader uses.
+    """
+    import os
+
+    print("{} loading:[{}]".format(model.name, os.path.basename(ckpt_path)))
+    sd = read_state_dict(ckpt_path)
+    specs = table(kind)
+    out = []
+    lora_keys = list(lora_dict.keys()) if lora_dict is not None else []
+    lora_count, lora_idx = len(lora_keys), 0
+    for i, spec in enumerate(specs):
+        if spec.key in sd:
+            w = sd[spec.key]
+        elif spec.alt_key is not None and spec.alt_key in sd:
+            w = sd[spec.alt_key]
+        else:
+            raise KeyError(spec.key)
+        if hasattr(w, "detach"):
+            w = w.detach().float().numpy()
+        if lora_dict is not None:
+            lw = lora_dict.get(spec.alt_key if spec.alt_key is not None else spec.key, None)
+            if lw is not None:
+                w = w + lw
+                lora_idx += 1
+        w = to_keras_layout(spec, np.asarray(w, dtype=np.float32))
+        if tuple(model.weights[i].shape) != tuple(w.shape):
+            print("Wrong :[{},{}]".format(model.weights[i].name, spec.key))
+        out.append(w)
+    if lora_count > 0:
+        print("Apply {}/{} lora weights".format(lora_idx, lora_count))
+    model.set_weights(out)
+    print("Loaded %d weights for %s" % (len(out), model.name))

@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """Device + stream for GPU tests; the HIP library must load (no fallback)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from minsdtf_amd import _lib
+
+    lib = _lib.load()
+    rc = lib.msd_init()
+    assert rc == 0, lib.msd_last_error()
+    return torch.device("cuda:0")
+
+
+def run_calls(calls):
+    """Run Call objects on torch's current stream and wait."""
+    import torch
+
+    st = torch.cuda.current_stream().cuda_stream
+    for c in calls if isinstance(calls, (list, tuple)) else [calls]:
+        c(st)
+    torch.cuda.synchronize()

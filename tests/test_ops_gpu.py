@@ -1,0 +1,354 @@
+"""Per-kernel parity: each C-ABI entry point against the oracle's fp32 primitive on the same
+(bf16-rounded) inputs.  Tolerances are written next to each check; with identical rounded inputs
+the only differences are fp32 accumulation order and the final bf16 round of the output
+(relative 2^-8), so bf16 outputs are compared with rtol 1e-2 and a small absolute floor."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import run_calls
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(x):
+    """Round an fp32 CPU tensor to bf16 and back (what the device will see)."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def close(got, ref, rtol=1e-2, atol=None, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    if atol is None:
+        atol = 1e-2 * float(ref.abs().max()) + 1e-6
+    err = (got - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {float(err.max()):.4g}, ref max {float(ref.abs().max()):.4g}"
+
+
+def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    if upsample:
+        x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    y = F.conv2d(x, w_hwio.permute(3, 2, 0, 1), bias, stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=16, W=16, c0=64, N=128, ks=3),                       # basic 3x3
+    dict(B=1, H=8, W=8, c0=128, N=320, ks=3),                        # M=64 < tile, N=320 (64-wide tiles)
+    dict(B=2, H=12, W=20, c0=64, N=192, ks=3, tile_n=128),           # ragged M and N edges
+    dict(B=2, H=16, W=16, c0=64, N=64, ks=3, stride=2),              # stride-2 downsampler
+    dict(B=1, H=8, W=8, c0=128, N=128, ks=3, upsample=True),         # nearest x2 fused into the gather
+    dict(B=2, H=8, W=8, c0=128, c1=64, N=128, ks=3),                 # channel concat of two tensors
+    dict(B=2, H=8, W=8, c0=64, c1=128, N=64, ks=1),                  # 1x1 shortcut over a concat
+    dict(B=1, H=16, W=16, c0=320, N=320, ks=1),                      # dense / proj
+    dict(B=2, H=8, W=8, c0=256, N=128, ks=3, splitk=4),              # split-K slabs + finalize
+    dict(B=1, H=8, W=8, c0=1280, N=1280, ks=3, splitk=9),            # 8x8-level shape
+    dict(B=2, H=16, W=16, c0=64, N=128, ks=3, f32out=True, act="silu"),
+])
+def test_conv_gemm(gpu, case):
+    from minsdtf_amd import ops, packing
+
+    torch.manual_seed(1)
+    B, H, W, c0, N, ks = case["B"], case["H"], case["W"], case["c0"], case["N"], case["ks"]
+    c1 = case.get("c1", 0)
+    stride, ups = case.get("stride", 1), case.get("upsample", False)
+    splitk = case.get("splitk", 1)
+    cin = c0 + c1
+    x0 = bf(torch.randn(B, H, W, c0))
+    x1 = bf(torch.randn(B, H, W, c1)) if c1 else None
+    w = bf(torch.randn(ks, ks, cin, N) / math.sqrt(ks * ks * cin))
+    bias = torch.randn(N)
+    pad = 1 if ks == 3 else 0
+    xin = torch.cat([x0, x1], dim=-1) if c1 else x0
+    ref = conv_ref(xin, w, bias, stride=stride, pad=pad, upsample=ups)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    M = B * Ho * Wo
+    steps = 3
+    temb = torch.randn(steps, B, N)
+    resid = bf(torch.randn(B, Ho, Wo, N))
+    ref = ref + temb[2][:, None, None, :]
+    if case.get("act") == "silu":
+        ref = ref * torch.sigmoid(ref)
+    ref = ref + resid
+
+    d = gpu
+    wp = packing.pack_conv(w.numpy(), d)
+    x0d, x1d = x0.to(torch.bfloat16).to(d), (x1.to(torch.bfloat16).to(d) if c1 else None)
+    f32out = case.get("f32out", False)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32 if f32out else torch.bfloat16, device=d)
+    ws = torch.empty(max(1, splitk * M * N), dtype=torch.float32, device=d)
+    step = torch.tensor([2], dtype=torch.int32, device=d)
+    call = ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=wp, out=out, batch=B, h_in=H, w_in=W, c0=c0, N=N, ksize=ks, stride=stride,
+                         upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N, rv_batch_stride=N,
+                         step_ptr=step, residual=resid.to(torch.bfloat16).to(d), act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
+                         out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, workspace=ws, workspace_floats=ws.numel(),
+                         splitk=splitk, tile_n=case.get("tile_n", 0))
+    run_calls(call)
+    close(out.reshape(B, Ho, Wo, N), ref, what=str(case))
+
+
+def test_conv_gemm_geglu(gpu):
+    from minsdtf_amd import ops, packing
+
+    torch.manual_seed(2)
+    M, C = 192, 64
+    x = bf(torch.randn(M, C))
+    w = bf(torch.randn(C, 8 * C) / math.sqrt(C))
+    b = torch.randn(8 * C) * 0.1
+    h = x @ w + b
+    a, gate = h[:, :4 * C], h[:, 4 * C:]
+    ref = a * 0.5 * gate * (1 + torch.tanh(gate * 0.7978845608 * (1 + 0.044715 * gate ** 2)))
+    wp, bp = packing.pack_geglu(w.numpy(), b.numpy(), gpu)
+    out = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device=gpu)
+    call = ops.conv_gemm(a0=x.to(torch.bfloat16).to(gpu), w=wp, out=out, batch=1, h_in=M, w_in=1, c0=C, N=8 * C, bias=bp,
+                         act=ops.ACT_GEGLU)
+    run_calls(call)
+    close(out, ref, what="geglu")
+
+
+@pytest.mark.parametrize("nq", [1, 0])
+def test_conv_gemm_qkv_split(gpu, nq):
+    """q|k|v^T epilogue (nq=1) and the k|v^T form used for the text context (nq=0)."""
+    from minsdtf_amd import ops, packing
+
+    torch.manual_seed(3)
+    B, S, Cin, C = 2, 77 if nq == 0 else 64, 128, 64
+    Sp = (S + 7) // 8 * 8
+    x = bf(torch.randn(B, S, Cin))
+    ws = [bf(torch.randn(Cin, C) / math.sqrt(Cin)) for _ in range(2 + nq)]
+    wp = packing.pack_dense_stack([w.numpy() for w in ws], gpu)
+    refs = [x @ w for w in ws]
+    N = C * (2 + nq)
+    q = torch.full((B * S, C), float("nan"), dtype=torch.bfloat16, device=gpu)
+    k = torch.full((B * S, C), float("nan"), dtype=torch.bfloat16, device=gpu)
+    vt = torch.zeros((B, C, Sp), dtype=torch.bfloat16, device=gpu)
+    call = ops.conv_gemm(a0=x.to(torch.bfloat16).to(gpu), w=wp, out=q, batch=B, h_in=S, w_in=1, c0=Cin, N=N,
+                         split=(C * nq, C, k, C, vt, Sp), out_ld=C)
+    run_calls(call)
+    if nq:
+        close(q.reshape(B, S, C), refs[0], what="q")
+    close(k.reshape(B, S, C), refs[nq], what="k")
+    close(vt[:, :, :S].permute(0, 2, 1), refs[nq + 1], what="v^T")
+    assert float(vt[:, :, S:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, mod=1, H=8, W=8, cin=4, cout=320, in_f32=True),                    # UNet conv_in, latent shared by both halves
+    dict(B=2, mod=2, H=8, W=8, cin=320, cout=4, in_f32=False, out="f32"),        # UNet conv_out
+    dict(B=1, mod=1, H=16, W=16, cin=128, cout=3, in_f32=False, out="u8"),       # VAE conv_out -> uint8
+    dict(B=1, mod=1, H=16, W=16, cin=3, cout=16, in_f32=True, act=True),         # HintNet first conv
+    dict(B=1, mod=1, H=16, W=16, cin=32, cout=96, in_f32=False, stride=2, act=True),
+    dict(B=1, mod=1, H=8, W=8, cin=4, cout=4, in_f32=True, ks=1, scale=1 / 0.18215, out="f32"),  # post_quant
+    dict(B=5, mod=5, H=1, W=1, cin=320, cout=1280, in_f32=True, ks=1, act=True, out="f32"),      # time-embedding dense
+    dict(B=1, mod=1, H=8, W=8, cin=4, cout=320, in_f32=True, resid=True),        # ControlNet conv_in + hint
+])
+def test_conv_direct(gpu, case):
+    from minsdtf_amd import ops
+
+    torch.manual_seed(4)
+    B, mod, H, W, cin, cout = case["B"], case["mod"], case["H"], case["W"], case["cin"], case["cout"]
+    ks, stride = case.get("ks", 3), case.get("stride", 1)
+    scale = case.get("scale", 1.0)
+    x = torch.randn(mod, H, W, cin)
+    if not case["in_f32"]:
+        x = bf(x)
+    w = torch.randn(ks, ks, cin, cout) / math.sqrt(ks * ks * cin)
+    b = torch.randn(cout) * 0.1
+    xb = x[torch.arange(B) % mod]
+    ref = conv_ref(xb * scale, w, b, stride=stride, pad=1 if ks == 3 else 0)
+    if case.get("act"):
+        ref = ref * torch.sigmoid(ref)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    resid = None
+    if case.get("resid"):
+        resid = bf(torch.randn(B, Ho, Wo, cout))
+        ref = ref + resid
+    outk = case.get("out", "bf16")
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "u8": torch.uint8}[outk]
+    out = torch.zeros((B, Ho, Wo, cout), dtype=dt, device=gpu)
+    xd = x.to(gpu) if case["in_f32"] else x.to(torch.bfloat16).to(gpu)
+    call = ops.conv_direct(x=xd, w=w.to(gpu), bias=b.to(gpu), out=out, batch=B, in_batch_mod=mod, h_in=H, w_in=W, c_in=cin,
+                           c_out=cout, ksize=ks, stride=stride, in_dtype=ops.OUT_F32 if case["in_f32"] else ops.OUT_BF16,
+                           out_dtype={"bf16": ops.OUT_BF16, "f32": ops.OUT_F32, "u8": ops.OUT_U8}[outk],
+                           act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE, in_scale=scale,
+                           residual=None if resid is None else resid.to(torch.bfloat16).to(gpu))
+    run_calls(call)
+    if outk == "u8":
+        refu = np.clip(((ref.numpy() + 1.0) * 0.5) * 255.0, 0, 255)
+        got = out.cpu().numpy().astype(np.int32)
+        # truncation: allow off-by-one where the fp32 value sits on an integer boundary
+        assert np.all(np.abs(got - np.floor(refu)) <= 1), "uint8 conversion"
+        assert np.mean(got == np.floor(refu).astype(np.int32)) > 0.995
+    elif outk == "f32":
+        close(out, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()), what=str(case))
+    else:
+        close(out, ref, what=str(case))
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, hw=64, c0=320, silu=True),
+    dict(B=2, hw=256, c0=1280, c1=640, silu=True),     # concat, groups straddle the two tensors
+    dict(B=1, hw=64, c0=1280, c1=1280, silu=True),     # C=2560: two channel vectors per thread
+    dict(B=1, hw=4096, c0=128, silu=False),            # VAE-like: few channels, many pixels
+    dict(B=3, hw=100, c0=512, silu=True),
+])
+def test_group_norm(gpu, case):
+    from minsdtf_amd import ops
+
+    torch.manual_seed(5)
+    B, hw, c0, c1 = case["B"], case["hw"], case["c0"], case.get("c1", 0)
+    C = c0 + c1
+    x0 = bf(torch.randn(B, hw, c0) * 2 + 0.7)
+    x1 = bf(torch.randn(B, hw, c1) - 0.3) if c1 else None
+    x = torch.cat([x0, x1], -1) if c1 else x0
+    gamma, beta = torch.randn(C) * 0.2 + 1, torch.randn(C) * 0.2
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-5).permute(0, 2, 1)
+    if case["silu"]:
+        ref = ref * torch.sigmoid(ref)
+    out = torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=gpu)
+    stats = torch.zeros(B * 64, dtype=torch.float32, device=gpu)
+    call = ops.group_norm(x0=x0.to(torch.bfloat16).to(gpu), x1=None if x1 is None else x1.to(torch.bfloat16).to(gpu),
+                          gamma=gamma.to(gpu), beta=beta.to(gpu), stats=stats, out=out, batch=B, hw=hw, c0=c0, c1=c1,
+                          silu=case["silu"])
+    run_calls(call)
+    close(out, ref, atol=2e-2, what=str(case))
+
+
+@pytest.mark.parametrize("rows,c", [(256, 320), (100, 640), (64, 1280), (7, 2048)])
+def test_layer_norm(gpu, rows, c):
+    from minsdtf_amd import ops
+
+    torch.manual_seed(6)
+    x = bf(torch.randn(rows, c) * 3 + 1)
+    gamma, beta = torch.randn(c) * 0.2 + 1, torch.randn(c) * 0.2
+    ref = F.layer_norm(x, (c,), gamma, beta, eps=1e-5)
+    out = torch.full((rows, c), float("nan"), dtype=torch.bfloat16, device=gpu)
+    run_calls(ops.layer_norm(x=x.to(torch.bfloat16).to(gpu), gamma=gamma.to(gpu), beta=beta.to(gpu), out=out, rows=rows, c=c))
+    close(out, ref, atol=2e-2, what=f"ln {rows}x{c}")
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=8, d=40, S=256, T=256),
+    dict(B=1, H=8, d=40, S=1024, T=1024),
+    dict(B=2, H=8, d=80, S=128, T=77),       # text cross-attention: ragged key tail
+    dict(B=1, H=8, d=160, S=64, T=64),       # 8x8 level: half-empty query tile
+    dict(B=2, H=8, d=160, S=256, T=154),     # long prompt (2 x 77)
+    dict(B=1, H=2, d=40, S=72, T=72),        # ragged queries
+    dict(B=1, H=8, d=80, S=256, T=256, spike=True),  # forces online-softmax rescales
+])
+def test_attention(gpu, case):
+    from minsdtf_amd import ops
+
+    torch.manual_seed(7)
+    B, H, d, S, T = case["B"], case["H"], case["d"], case["S"], case["T"]
+    C = H * d
+    Tp = (T + 7) // 8 * 8
+    q, k, v = bf(torch.randn(B, S, C)), bf(torch.randn(B, T, C)), bf(torch.randn(B, T, C))
+    if case.get("spike"):
+        # later keys score far higher than earlier ones for some queries -> the running max jumps
+        k[:, T // 2 + 3] *= 6.0
+        k[:, T - 5] *= 12.0
+    scale = d ** -0.5
+    qh = q.view(B, S, H, d).permute(0, 2, 1, 3)
+    kh = k.view(B, T, H, d).permute(0, 2, 1, 3)
+    vh = v.view(B, T, H, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax((qh @ kh.transpose(-1, -2)) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, S, C)
+    # q lives inside a wider fused buffer (leading dimension 3C) like the QKV GEMM output would
+    qbuf = torch.zeros(B, S, 3 * C, dtype=torch.bfloat16, device=gpu)
+    qbuf[:, :, C:2 * C] = q.to(torch.bfloat16).to(gpu)
+    vt = torch.zeros(B, C, Tp, dtype=torch.bfloat16, device=gpu)
+    vt[:, :, :T] = v.permute(0, 2, 1).to(torch.bfloat16).to(gpu)
+    out = torch.full((B, S, C), float("nan"), dtype=torch.bfloat16, device=gpu)
+    call = ops.attention(q=qbuf.data_ptr() + 2 * C, k=k.to(torch.bfloat16).to(gpu), vt=vt, out=out, batch=B, heads=H,
+                         head_dim=d, s=S, t=T, q_ld=3 * C, k_ld=C, vt_ld=Tp, o_ld=C, scale=scale)
+    run_calls(call)
+    # P is rounded to bf16 before the PV product (relative 2^-9 per term): the error scales with the
+    # magnitude of the summed terms, so the absolute floor is 1.5e-2 of max(1, max|O|)
+    close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=str(case))
+
+
+def test_softmax_rows(gpu):
+    from minsdtf_amd import ops
+
+    torch.manual_seed(8)
+    rows, cols = 50, 4096
+    x = torch.randn(rows, cols) * 20
+    scale = 1 / math.sqrt(512)
+    ref = torch.softmax(x * scale, -1)
+    out = torch.zeros(rows, cols, dtype=torch.bfloat16, device=gpu)
+    run_calls(ops.softmax_rows(x=x.to(gpu), out=out, rows=rows, cols=cols, ld_in=cols, ld_out=cols, scale=scale))
+    close(out, ref, rtol=1e-2, atol=1e-6, what="softmax")
+
+
+@pytest.mark.parametrize("guidance,rescale", [(7.5, 0.7), (7.5, 0.0), (0.0, 0.0)])
+def test_cfg_step(gpu, guidance, rescale):
+    """CFG + rescale + sampler step against the oracle restatement, for every step of a 5-step run."""
+    from minsdtf_amd import ops
+    from minsdtf_amd.scheduler import Scheduler
+    from oracle import sd_oracle as O
+
+    rng = np.random.default_rng(9)
+    B, n, steps = 3, 8 * 8 * 4, 5
+    sch = Scheduler()
+    sch.set_timesteps(steps)
+    coef = torch.from_numpy(sch.coefficient_table()).to(gpu)
+    osch = O.OracleScheduler()
+    osch.set_timesteps(steps)
+    lat = rng.standard_normal((B, 8, 8, 4)).astype(np.float32)
+    lat_d = torch.from_numpy(lat.reshape(B, n).copy()).to(gpu)
+    step = torch.zeros(1, dtype=torch.int32, device=gpu)
+    ref = lat.astype(np.float64)
+    for i, t in enumerate(osch.timesteps):
+        u = rng.standard_normal((B, 8, 8, 4)).astype(np.float32)
+        c = (u + 0.3 * rng.standard_normal((B, 8, 8, 4))).astype(np.float32)
+        if guidance > 0:
+            e = u + guidance * (c - u)
+            if rescale > 0:
+                e = O.rescale_noise_cfg(e, c, rescale)
+            eps_d = torch.from_numpy(np.concatenate([u, c]).reshape(2 * B, n)).to(gpu)
+        else:
+            e = c
+            eps_d = torch.from_numpy(c.reshape(B, n)).to(gpu)
+        ref = osch.step(e, int(t), ref)
+        run_calls(ops.cfg_step(eps=eps_d, latent=lat_d, coef=coef, step_ptr=step, batch=B, n=n, num_steps=steps,
+                               guidance=guidance, guidance_rescale=rescale, advance=True))
+        got = lat_d.cpu().numpy().reshape(B, 8, 8, 4)
+        # fp32 device math vs the reference's float64 numpy path
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max(), err_msg=f"step {i}")
+        assert int(step.item()) == i + 1
+
+
+def test_elementwise(gpu):
+    from minsdtf_amd import ops
+
+    torch.manual_seed(10)
+    a, b = bf(torch.randn(4096)), bf(torch.randn(4096))
+    out = torch.zeros(4096, dtype=torch.bfloat16, device=gpu)
+    run_calls(ops.add_bf16(a=a.to(torch.bfloat16).to(gpu), b=b.to(torch.bfloat16).to(gpu), out=out, n=4096))
+    assert torch.equal(out.cpu(), (a + b).to(torch.bfloat16))
+    x = torch.randn(1000)
+    o = torch.zeros(1000, dtype=torch.bfloat16, device=gpu)
+    run_calls(ops.cast_f32_to_bf16(x=x.to(gpu), out=o, n=1000))
+    assert torch.equal(o.cpu(), x.to(torch.bfloat16))
+    o2 = torch.zeros(1000, dtype=torch.float32, device=gpu)
+    run_calls(ops.cast_bf16_to_f32(x=o, out=o2, n=1000))
+    assert torch.equal(o2.cpu(), x.to(torch.bfloat16).float())
+    z = torch.ones(1024, dtype=torch.float32, device=gpu)
+    run_calls(ops.memset_zero(ptr=z, nbytes=4096))
+    assert float(z.abs().sum()) == 0
+
+
+def test_argument_errors(gpu):
+    """The ABI rejects bad shapes with an error instead of launching."""
+    from minsdtf_amd import _lib, ops
+
+    x = torch.zeros(1, 8, 8, 48, dtype=torch.bfloat16, device=gpu)
+    w = torch.zeros(64, 48, dtype=torch.bfloat16, device=gpu)
+    o = torch.zeros(64, 64, dtype=torch.bfloat16, device=gpu)
+    with pytest.raises(_lib.HipExtensionError):
+        run_calls(ops.conv_gemm(a0=x, w=w, out=o, batch=1, h_in=8, w_in=8, c0=48, N=64))
