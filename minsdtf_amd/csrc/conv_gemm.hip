@@ -288,7 +288,8 @@ int msd_conv_gemm_init() {
 extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!q) MSD_FAIL(MSD_E_ARG, "conv_gemm: null params");
-    if (!q->a0 || !q->w || !q->out) MSD_FAIL(MSD_E_ARG, "conv_gemm: null a0/w/out");
+    if (!q->a0 || !q->w) MSD_FAIL(MSD_E_ARG, "conv_gemm: null a0/w");
+    if (!q->out && !(q->split_mode == 1 && q->ns0 == 0)) MSD_FAIL(MSD_E_ARG, "conv_gemm: null out");
     if (q->batch <= 0 || q->h_in <= 0 || q->w_in <= 0 || q->h_out <= 0 || q->w_out <= 0)
         MSD_FAIL(MSD_E_ARG, "conv_gemm: non-positive dims");
     if (q->c0 <= 0 || (q->c0 % 64) || q->c1 < 0 || (q->c1 % 64) || (q->c1 > 0 && !q->a1))

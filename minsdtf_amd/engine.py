@@ -1,0 +1,574 @@
+"""Launch plans: the reference's Keras graphs re-expressed as flat lists of C-ABI calls.
+
+A :class:`Plan` is built once per (network, batch, resolution, context length): it walks the
+network topology, assigns every activation a byte range in one HBM arena (ranges are recycled as
+soon as the last consumer has been recorded, which keeps the working set of a UNet forward inside
+the 256 MiB Infinity Cache), and records one :class:`~minsdtf_amd.ops.Call` per kernel.  Running
+a plan is a Python loop of foreign calls on one HIP stream; captured once into a hipGraph it is
+replayed with no host work at all.  Nothing here computes: all arithmetic is in the HIP library.
+
+Topology sources (reference, paths relative to stable_diffusion/):
+  UNet            diffusion_model.py:166-283      ResBlock :22-51   Attentions :54-78
+  TransformerBlock :81-96   CrossAttention :99-129   GEGLU :142-153   Upsamplers :132-139
+  VAE decoder     image_decoder.py:22-55, layers.py:28-80
+  ControlNet / HintNet   control_net.py:10-107
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops, packing
+from . import weights as wtab
+
+EPS = 1e-5  # every normalisation layer of the reference uses epsilon=1e-5
+
+
+# ----------------------------------------------------------------------------- memory
+class Arena:
+    """Plan-time bump/free-list allocator over one device buffer (materialised after planning)."""
+
+    ALIGN = 256
+
+    def __init__(self):
+        self.free_list: List[Tuple[int, int]] = []  # (offset, size), sorted by offset
+        self.top = 0
+        self.base: Optional[int] = None
+        self.storage: Optional[torch.Tensor] = None
+
+    def alloc(self, nbytes: int) -> "Buf":
+        n = (int(nbytes) + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        best = None
+        for i, (off, sz) in enumerate(self.free_list):
+            if sz >= n and (best is None or sz < self.free_list[best][1]):
+                best = i
+        if best is not None:
+            off, sz = self.free_list.pop(best)
+            if sz > n:
+                self.free_list.insert(best, (off + n, sz - n))
+            return Buf(self, off, n)
+        off = self.top
+        self.top += n
+        return Buf(self, off, n)
+
+    def free(self, buf: "Buf") -> None:
+        if buf is None or buf.arena is not self or buf.freed:
+            return
+        buf.freed = True
+        self.free_list.append((buf.offset, buf.nbytes))
+        self.free_list.sort()
+        merged: List[Tuple[int, int]] = []
+        for off, sz in self.free_list:
+            if merged and merged[-1][0] + merged[-1][1] == off:
+                merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+            else:
+                merged.append((off, sz))
+        if merged and merged[-1][0] + merged[-1][1] == self.top:  # give the tail back
+            self.top = merged[-1][0]
+            merged.pop()
+        self.free_list = merged
+
+    def materialize(self, device, high_water: int) -> None:
+        self.storage = torch.zeros(max(high_water, self.ALIGN), dtype=torch.uint8, device=device)
+        self.base = self.storage.data_ptr()
+
+
+class Buf:
+    __slots__ = ("arena", "offset", "nbytes", "freed")
+
+    def __init__(self, arena, offset, nbytes):
+        self.arena, self.offset, self.nbytes, self.freed = arena, offset, nbytes, False
+
+    @property
+    def ptr(self) -> int:
+        assert self.arena.base is not None, "arena not materialised"
+        return self.arena.base + self.offset
+
+    def at(self, byte_offset: int) -> "BufView":
+        return BufView(self, byte_offset)
+
+    def tensor(self, dtype, shape) -> torch.Tensor:
+        """A torch view of this range (host <-> device copies at the model boundary only)."""
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        assert n <= self.nbytes
+        return self.arena.storage[self.offset:self.offset + n].view(dtype).view(*shape)
+
+
+class BufView:
+    __slots__ = ("buf", "off")
+
+    def __init__(self, buf, off):
+        self.buf, self.off = buf, off
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.ptr + self.off
+
+
+@dataclass
+class Act:
+    """bf16 NHWC activation (tokens are the same memory: [B][H*W][C])."""
+    buf: Buf
+    B: int
+    H: int
+    W: int
+    C: int
+
+    @property
+    def M(self) -> int:
+        return self.B * self.H * self.W
+
+
+class Plan:
+    def __init__(self, device):
+        self.device = device
+        self.arena = Arena()
+        self.high_water = 0
+        self.recs: List[Callable[[], ops.Call]] = []
+        self.calls: List[ops.Call] = []
+        self.gn_slots = 0
+        self.gn_batch = 0
+        self.ws_floats = 0
+        self._ws_buf: Optional[Buf] = None
+        self._stats_buf: Optional[Buf] = None
+        self.keep: list = []  # device tensors that must outlive the plan
+
+    # -- memory
+    def alloc(self, nbytes: int) -> Buf:
+        b = self.arena.alloc(nbytes)
+        self.high_water = max(self.high_water, self.arena.top)
+        return b
+
+    def _alloc_tail(self, nbytes: int) -> Buf:
+        n = (int(nbytes) + Arena.ALIGN - 1) // Arena.ALIGN * Arena.ALIGN
+        b = Buf(self.arena, self.high_water, n)
+        self.high_water += n
+        return b
+
+    def free(self, *bufs) -> None:
+        for b in bufs:
+            if isinstance(b, Act):
+                b = b.buf
+            if b is not None:
+                self.arena.free(b)
+
+    def act(self, B, H, W, C) -> Act:
+        return Act(self.alloc(B * H * W * C * 2), B, H, W, C)
+
+    # -- recording
+    def rec(self, fn, **kw) -> None:
+        self.recs.append(lambda: fn(**kw))
+
+    @property
+    def ws(self):
+        return _Lazy(lambda: self._ws_buf.ptr if self._ws_buf is not None else None)
+
+    def gn_stats_slot(self, batch: int):
+        slot = self.gn_slots
+        self.gn_slots += 1
+        self.gn_batch = max(self.gn_batch, batch)
+        return _Lazy(lambda: self._stats_buf.ptr + slot * self.gn_batch * 64 * 4)
+
+    def finalize(self) -> None:
+        """Fix the arena, then turn the recorded closures into typed calls."""
+        # scratch that is live across the whole plan goes ABOVE every recycled range
+        if self.ws_floats:
+            self._ws_buf = self._alloc_tail(self.ws_floats * 4)
+        head: List[ops.Call] = []
+        if self.gn_slots:
+            self._stats_buf = self._alloc_tail(self.gn_slots * self.gn_batch * 64 * 4)
+        self.arena.materialize(self.device, self.high_water)
+        if self.gn_slots:
+            head.append(ops.memset_zero(ptr=self._stats_buf, nbytes=self.gn_slots * self.gn_batch * 64 * 4))
+        self.calls = head + [r() for r in self.recs]
+        self.recs = []
+
+    def run(self, stream: int) -> None:
+        for c in self.calls:
+            c(stream)
+
+
+class _Lazy:
+    """Pointer known only after the arena is materialised."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    @property
+    def ptr(self):
+        return self.fn()
+
+
+def _tile_n(N: int) -> int:
+    return 128 if (N % 128 == 0 or N > 1024) else 64
+
+
+def pick_splitk(M: int, N: int, nk: int) -> int:
+    """Spread small-M layers over the chip: aim at >= ~256 workgroups, >= 4 K-tiles per slice."""
+    tiles = ((M + 127) // 128) * ((N + _tile_n(N) - 1) // _tile_n(N))
+    if tiles >= 160 or nk < 8:
+        return 1
+    s = min((256 + tiles - 1) // tiles, nk // 4, 16)
+    return max(1, s)
+
+
+# ----------------------------------------------------------------------------- layer emitters
+class Emitter:
+    """Emits the calls of the reference's layer types into a Plan. `W` maps logical weight names to
+    device tensors prepared by the model classes (minsdtf_amd/models.py)."""
+
+    def __init__(self, plan: Plan, W: Dict[str, torch.Tensor], step_ptr=None):
+        self.p, self.W, self.step_ptr = plan, W, step_ptr
+
+    # conv / dense on the MFMA path; x may be a single Act or a (Act, Act) channel concat
+    def conv(self, x, name, N, ksize=1, stride=1, upsample=False, act=ops.ACT_NONE, residual: Optional[Act] = None,
+             rowvec=None, out_dtype=ops.OUT_BF16, bias=True, wkey=None, split=None, out: Optional[Act] = None) -> Act:
+        p = self.p
+        x0, x1 = (x if isinstance(x, tuple) else (x, None))
+        cin = x0.C + (x1.C if x1 is not None else 0)
+        hl, wl = (2 * x0.H, 2 * x0.W) if upsample else (x0.H, x0.W)
+        pad = 1 if ksize == 3 else 0
+        ho, wo = (hl + 2 * pad - ksize) // stride + 1, (wl + 2 * pad - ksize) // stride + 1
+        n_out = N // 2 if act == ops.ACT_GEGLU else N
+        M = x0.B * ho * wo
+        nk = ksize * ksize * (cin // 64)
+        sk = 1 if (split is not None or act == ops.ACT_GEGLU) else pick_splitk(M, N, nk)
+        if sk > 1:
+            p.ws_floats = max(p.ws_floats, sk * M * N)
+        if out is None and split is None:
+            esz = 4 if out_dtype == ops.OUT_F32 else 2
+            out = Act(p.alloc(M * n_out * esz), x0.B, ho, wo, n_out)
+        kw = dict(a0=x0.buf, a1=None if x1 is None else x1.buf, c1=0 if x1 is None else x1.C,
+                  w=self.W[(wkey or name) + ".w"], out=out.buf if out is not None else None, batch=x0.B, h_in=x0.H,
+                  w_in=x0.W, c0=x0.C, N=N, ksize=ksize, stride=stride, upsample=upsample,
+                  bias=self.W[(wkey or name) + ".b"] if bias else None, act=act, out_dtype=out_dtype,
+                  residual=None if residual is None else residual.buf, res_ld=None if residual is None else residual.C,
+                  workspace=p.ws if sk > 1 else None, workspace_floats=sk * M * N if sk > 1 else 0, splitk=sk,
+                  step_ptr=self.step_ptr if rowvec is not None else None, name=name)
+        if rowvec is not None:
+            kw.update(rowvec=rowvec[0], rv_step_stride=rowvec[1], rv_batch_stride=rowvec[2])
+        if split is not None:
+            ns0, ns1, out0, out1, out2, out2_ld = split
+            kw.update(out=out0, out_ld=max(ns0, 4), split=(ns0, ns1, out1, ns1, out2, out2_ld))
+        p.rec(ops.conv_gemm, **kw)
+        return out
+
+    def group_norm(self, x, name, silu: bool) -> Act:
+        p = self.p
+        x0, x1 = (x if isinstance(x, tuple) else (x, None))
+        C = x0.C + (x1.C if x1 is not None else 0)
+        out = p.act(x0.B, x0.H, x0.W, C)
+        p.rec(ops.group_norm, x0=x0.buf, x1=None if x1 is None else x1.buf, c1=0 if x1 is None else x1.C,
+              gamma=self.W[name + ".g"], beta=self.W[name + ".b"], stats=p.gn_stats_slot(x0.B), out=out.buf, batch=x0.B,
+              hw=x0.H * x0.W, c0=x0.C, silu=silu, eps=EPS, name=name)
+        return out
+
+    def layer_norm(self, x: Act, name) -> Act:
+        out = self.p.act(x.B, x.H, x.W, x.C)
+        self.p.rec(ops.layer_norm, x=x.buf, gamma=self.W[name + ".g"], beta=self.W[name + ".b"], out=out.buf, rows=x.M,
+                   c=x.C, eps=EPS, name=name)
+        return out
+
+    # ---- reference layer types
+    def res_block(self, x, name, cout, temb=None, free_input=False) -> Act:
+        """ResBlock (diffusion_model.py:22-51) / VAE ResnetBlock (layers.py:62-80, temb=None)."""
+        p = self.p
+        x0 = x[0] if isinstance(x, tuple) else x
+        cin = sum(a.C for a in x) if isinstance(x, tuple) else x.C
+        g1 = self.group_norm(x, name + ".norm1", silu=True)
+        h = self.conv(g1, name + ".conv1", cout, ksize=3, rowvec=temb)
+        p.free(g1)
+        g2 = self.group_norm(h, name + ".norm2", silu=True)
+        p.free(h)
+        if cin != cout:
+            res = self.conv(x, name + ".conv_shortcut", cout, ksize=1)
+        else:
+            assert not isinstance(x, tuple)
+            res = x0
+        out = self.conv(g2, name + ".conv2", cout, ksize=3, residual=res)
+        p.free(g2)
+        if res is not x0:
+            p.free(res)
+        if free_input:
+            for a in (x if isinstance(x, tuple) else (x,)):
+                p.free(a)
+        return out
+
+    def attentions(self, x: Act, name, ctx_kv, ctx_len, heads=8, free_input=False) -> Act:
+        """Attentions / TransformerBlock / CrossAttention / GEGLU (diffusion_model.py:54-153)."""
+        p = self.p
+        B, H, Wd, C = x.B, x.H, x.W, x.C
+        S = H * Wd
+        d = C // heads
+        tb = name + ".transformer_blocks.0"
+        g = self.group_norm(x, name + ".norm", silu=False)
+        t0 = self.conv(g, name + ".proj_in", C)
+        p.free(g)
+        # self-attention: fused q|k|v projection, v written transposed for the PV product
+        n1 = self.layer_norm(t0, tb + ".norm1")
+        q, k = p.act(B, H, Wd, C), p.act(B, H, Wd, C)
+        vt = p.alloc(B * C * S * 2)
+        self.conv(n1, tb + ".attn1.qkv", 3 * C, bias=False, split=(C, C, q.buf, k.buf, vt, S))
+        p.free(n1)
+        a1 = p.act(B, H, Wd, C)
+        p.rec(ops.attention, q=q.buf, k=k.buf, vt=vt, out=a1.buf, batch=B, heads=heads, head_dim=d, s=S, t=S, q_ld=C,
+              k_ld=C, vt_ld=S, o_ld=C, scale=d ** -0.5, name=tb + ".attn1")
+        p.free(q, k, vt)
+        t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0)
+        p.free(a1, t0)
+        # cross-attention over the text context (k, v^T precomputed once per prompt)
+        n2 = self.layer_norm(t1, tb + ".norm2")
+        q2 = self.conv(n2, tb + ".attn2.to_q", C, bias=False)
+        p.free(n2)
+        kc, vtc, tp = ctx_kv[tb + ".attn2"]
+        a2 = p.act(B, H, Wd, C)
+        p.rec(ops.attention, q=q2.buf, k=kc, vt=vtc, out=a2.buf, batch=B, heads=heads, head_dim=d, s=S, t=ctx_len, q_ld=C,
+              k_ld=C, vt_ld=tp, o_ld=C, scale=d ** -0.5, name=tb + ".attn2")
+        p.free(q2)
+        t2 = self.conv(a2, tb + ".attn2.to_out.0", C, residual=t1)
+        p.free(a2, t1)
+        # feed-forward: GEGLU fused into the first GEMM's epilogue
+        n3 = self.layer_norm(t2, tb + ".norm3")
+        ff = self.conv(n3, tb + ".ff.net.0.proj", 8 * C, act=ops.ACT_GEGLU)
+        p.free(n3)
+        t3 = self.conv(ff, tb + ".ff.net.2", C, residual=t2)
+        p.free(ff, t2)
+        out = self.conv(t3, name + ".proj_out", C, residual=x)
+        p.free(t3)
+        if free_input:
+            p.free(x)
+        return out
+
+
+# ----------------------------------------------------------------------------- networks
+def emit_context_kv(e: Emitter, ctx: Act, attn_names: Sequence[Tuple[str, int]], persistent: Plan):
+    """K and V^T of the text context for every cross-attention layer (constant over all steps).
+    ctx: bf16 [NB][T][768] as an Act with H=T, W=1.  Buffers come from `persistent` (never recycled)."""
+    out = {}
+    T = ctx.H
+    tp = (T + 7) // 8 * 8
+    for name, C in attn_names:
+        kb = persistent.alloc(ctx.B * T * C * 2)
+        vb = persistent.alloc(ctx.B * C * tp * 2)
+        e.conv(ctx, name + ".kv", 2 * C, bias=False, split=(0, C, None, kb, vb, tp))
+        out[name] = (kb, vb, tp)
+    return out
+
+
+UNET_ATTN_LAYERS: List[Tuple[str, int]] = []
+for _lvl, _ch in enumerate(wtab.UNET_CH[:3]):
+    for _r in range(2):
+        UNET_ATTN_LAYERS.append((f"down_blocks.{_lvl}.attentions.{_r}.transformer_blocks.0.attn2", _ch))
+UNET_ATTN_LAYERS.append(("mid_block.attentions.0.transformer_blocks.0.attn2", 1280))
+ENCODER_ATTN_LAYERS = list(UNET_ATTN_LAYERS)
+for _ui, _lvl in enumerate((3, 2, 1, 0)):
+    if _lvl < 3:
+        for _r in range(3):
+            UNET_ATTN_LAYERS.append((f"up_blocks.{_ui}.attentions.{_r}.transformer_blocks.0.attn2", wtab.UNET_CH[_lvl]))
+
+
+def resblock_names(encoder_only: bool) -> List[Tuple[str, int]]:
+    """(name, c_out) of every ResBlock in weight-table order: column layout of the time-projection table."""
+    out = []
+    for lvl, ch in enumerate(wtab.UNET_CH):
+        for r in range(2):
+            out.append((f"down_blocks.{lvl}.resnets.{r}", ch))
+    out += [("mid_block.resnets.0", 1280), ("mid_block.resnets.1", 1280)]
+    if not encoder_only:
+        for ui, lvl in enumerate((3, 2, 1, 0)):
+            for r in range(3):
+                out.append((f"up_blocks.{ui}.resnets.{r}", wtab.UNET_CH[lvl]))
+    return out
+
+
+def emit_time_embedding(e: Emitter, t_emb_f32, rows: int, out_table, encoder_only: bool):
+    """time_embedding MLP + every ResBlock's time_emb_proj for `rows` embeddings at once
+    (diffusion_model.py:184-188,30,47).  fp32 throughout (vector-FMA path)."""
+    p = e.p
+    total = sum(c for _, c in resblock_names(encoder_only))
+    h1 = p.alloc(rows * 1280 * 4)
+    h2 = p.alloc(rows * 1280 * 4)
+    common = dict(batch=rows, h_in=1, w_in=1, ksize=1, in_dtype=ops.OUT_F32, out_dtype=ops.OUT_F32)
+    p.rec(ops.conv_direct, x=t_emb_f32, w=e.W["time_embedding.linear_1.w"], bias=e.W["time_embedding.linear_1.b"], out=h1,
+          c_in=320, c_out=1280, act=ops.ACT_SILU, name="time_embedding.linear_1", **common)
+    p.rec(ops.conv_direct, x=h1, w=e.W["time_embedding.linear_2.w"], bias=e.W["time_embedding.linear_2.b"], out=h2,
+          c_in=1280, c_out=1280, act=ops.ACT_SILU, name="time_embedding.linear_2", **common)
+    p.rec(ops.conv_direct, x=h2, w=e.W["time_emb_proj_cat.w"], bias=e.W["time_emb_proj_cat.b"], out=out_table,
+          c_in=1280, c_out=total, name="time_emb_proj_cat", **common)
+    p.free(h1, h2)
+    return total
+
+
+def temb_columns(encoder_only: bool) -> Dict[str, int]:
+    cols, off = {}, 0
+    for name, c in resblock_names(encoder_only):
+        cols[name] = off
+        off += c
+    return cols
+
+
+def _emit_encoder(e: Emitter, x: Act, temb_of, ctx_kv, ctx_len, outputs: List[Act]) -> Act:
+    """Down path + mid block shared by the UNet (diffusion_model.py:193-229) and the ControlNet."""
+    for lvl, ch in enumerate(wtab.UNET_CH):
+        for r in range(2):
+            name = f"down_blocks.{lvl}.resnets.{r}"
+            x = e.res_block(x, name, ch, temb=temb_of(name))
+            if lvl < 3:
+                x = e.attentions(x, f"down_blocks.{lvl}.attentions.{r}", ctx_kv, ctx_len, free_input=True)
+            outputs.append(x)
+        if lvl < 3:
+            x = e.conv(x, f"down_blocks.{lvl}.downsamplers.0.conv", ch, ksize=3, stride=2)
+            outputs.append(x)
+    x = e.res_block(x, "mid_block.resnets.0", 1280, temb=temb_of("mid_block.resnets.0"))
+    x = e.attentions(x, "mid_block.attentions.0", ctx_kv, ctx_len, free_input=True)
+    x = e.res_block(x, "mid_block.resnets.1", 1280, temb=temb_of("mid_block.resnets.1"), free_input=True)
+    return x
+
+
+def emit_unet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w: int, temb, ctx_kv, ctx_len: int,
+              eps_out_f32, controls: Optional[List[Act]] = None) -> None:
+    """DiffusionModel graph (diffusion_model.py:184-279).
+
+    latent_f32: fp32 [latent_batch_mod][h][w][4] (sample b reads row b % latent_batch_mod);
+    temb = (table, step_stride, batch_stride, {resblock: column}); eps_out_f32: fp32 [NB][h][w][4]."""
+    p = e.p
+    table, sstride, bstride, cols = temb
+
+    def temb_of(name):
+        return (table.at(cols[name] * 4), sstride, bstride)
+
+    x = p.act(NB, h, w, 320)
+    p.rec(ops.conv_direct, x=latent_f32, w=e.W["conv_in.w"], bias=e.W["conv_in.b"], out=x.buf, batch=NB,
+          in_batch_mod=latent_batch_mod, h_in=h, w_in=w, c_in=4, c_out=320, ksize=3, in_dtype=ops.OUT_F32,
+          out_dtype=ops.OUT_BF16, name="conv_in")
+    outputs: List[Act] = [x]
+    x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs)
+    if controls is not None:  # diffusion_model.py:230-234, after the down path is complete
+        assert len(outputs) == 12 and len(controls) == 13
+        p.rec(ops.add_bf16, a=x.buf, b=controls[12].buf, out=x.buf, n=x.M * x.C, name="control.12")
+        for i, (o, c) in enumerate(zip(outputs, controls[:12])):
+            assert (o.B, o.H, o.W, o.C) == (c.B, c.H, c.W, c.C)
+            p.rec(ops.add_bf16, a=o.buf, b=c.buf, out=o.buf, n=o.M * o.C, name=f"control.{i}")
+    for ui, lvl in enumerate((3, 2, 1, 0)):
+        ch = wtab.UNET_CH[lvl]
+        for r in range(3):
+            skip = outputs.pop()
+            name = f"up_blocks.{ui}.resnets.{r}"
+            x = e.res_block((x, skip), name, ch, temb=temb_of(name), free_input=True)
+            if lvl < 3:
+                x = e.attentions(x, f"up_blocks.{ui}.attentions.{r}", ctx_kv, ctx_len, free_input=True)
+        if lvl > 0:
+            y = e.conv(x, f"up_blocks.{ui}.upsamplers.0.conv", ch, ksize=3, upsample=True)
+            p.free(x)
+            x = y
+    g = e.group_norm(x, "conv_norm_out", silu=True)
+    p.free(x)
+    p.rec(ops.conv_direct, x=g.buf, w=e.W["conv_out.w"], bias=e.W["conv_out.b"], out=eps_out_f32, batch=NB, h_in=h, w_in=w,
+          c_in=320, c_out=4, ksize=3, in_dtype=ops.OUT_BF16, out_dtype=ops.OUT_F32, name="conv_out")
+    p.free(g)
+
+
+def emit_controlnet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w: int, temb, ctx_kv, ctx_len: int,
+                    hint: Act, outs: List[Act]) -> None:
+    """ControlNet (control_net.py:45-107): conv_in(latent)+hint, encoder, 13 1x1 'zero' convs."""
+    p = e.p
+    table, sstride, bstride, cols = temb
+
+    def temb_of(name):
+        return (table.at(cols[name] * 4), sstride, bstride)
+
+    x = p.act(NB, h, w, 320)
+    p.rec(ops.conv_direct, x=latent_f32, w=e.W["conv_in.w"], bias=e.W["conv_in.b"], residual=hint.buf, out=x.buf, batch=NB,
+          in_batch_mod=latent_batch_mod, h_in=h, w_in=w, c_in=4, c_out=320, ksize=3, in_dtype=ops.OUT_F32,
+          out_dtype=ops.OUT_BF16, name="conv_in+hint")
+    outputs: List[Act] = [x]
+    x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs)
+    outputs.append(x)
+    assert len(outputs) == 13 and len(outs) == 13
+    for i, (o, dst) in enumerate(zip(outputs, outs)):
+        e.conv(o, f"zero_convs.{i}", o.C, ksize=1, out=dst)
+    for o in outputs:
+        p.free(o)
+
+
+def emit_hintnet(e: Emitter, image_f32, B: int, H: int, W: int, out: Act) -> None:
+    """HintNet (control_net.py:10-31): 8 convs with swish between; last conv (256->320) on MFMA."""
+    p = e.p
+    x_buf, x_f32 = image_f32, True
+    h, w = H, W
+    cur: Optional[Act] = None
+    for i, (cin, cout, s) in enumerate(wtab.HINT_CH):
+        ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        if i < 7:
+            nxt = p.act(B, ho, wo, cout)
+            p.rec(ops.conv_direct, x=x_buf, w=e.W[f"input_hint_block.{i}.w"], bias=e.W[f"input_hint_block.{i}.b"], out=nxt.buf,
+                  batch=B, h_in=h, w_in=w, c_in=cin, c_out=cout, ksize=3, stride=s,
+                  in_dtype=ops.OUT_F32 if x_f32 else ops.OUT_BF16, out_dtype=ops.OUT_BF16, act=ops.ACT_SILU,
+                  name=f"input_hint_block.{i}")
+            if cur is not None:
+                p.free(cur)
+            cur, x_buf, x_f32 = nxt, nxt.buf, False
+        else:
+            e.conv(cur, f"input_hint_block.{i}", cout, ksize=3, out=out)
+            p.free(cur)
+        h, w = ho, wo
+
+
+def emit_vae_attention(e: Emitter, x: Act, name: str) -> Act:
+    """AttentionBlock (layers.py:28-59): single head, d = C = 512, scale 1/sqrt(C); q/k/v/proj
+    Dense with bias.  d=512 does not fit the fused kernel's register budget, so the scores of this
+    one layer are materialised (fp32) per sample: S = Q K^T on MFMA, row softmax, O = P V on MFMA."""
+    p = e.p
+    B, H, Wd, C = x.B, x.H, x.W, x.C
+    S = H * Wd
+    g = e.group_norm(x, name + ".group_norm", silu=False)
+    q, k = p.act(B, H, Wd, C), p.act(B, H, Wd, C)
+    vt = p.alloc(B * C * S * 2)
+    e.conv(g, name + ".qkv", 3 * C, split=(C, C, q.buf, k.buf, vt, S))
+    p.free(g)
+    o = p.act(B, H, Wd, C)
+    scores = p.alloc(S * S * 4)
+    probs = p.alloc(S * S * 2)
+    for b in range(B):
+        # scores[s, t] = q[b, s, :] . k[b, t, :]   (k rows act as the [N][K] "weight" operand)
+        p.rec(ops.conv_gemm, a0=q.buf.at(b * S * C * 2), w=k.buf.at(b * S * C * 2), out=scores, batch=1, h_in=S, w_in=1, c0=C,
+              N=S, out_dtype=ops.OUT_F32, name=name + ".qk")
+        p.rec(ops.softmax_rows, x=scores, out=probs, rows=S, cols=S, ld_in=S, ld_out=S, scale=1.0 / float(np.sqrt(C)),
+              name=name + ".softmax")
+        p.rec(ops.conv_gemm, a0=probs, w=vt.at(b * C * S * 2), out=o.buf.at(b * S * C * 2), batch=1, h_in=S, w_in=1, c0=S,
+              N=C, name=name + ".pv")
+    p.free(q, k, vt, scores, probs)
+    out = e.conv(o, name + ".proj_attn", C, residual=x)
+    p.free(o, x)
+    return out
+
+
+def emit_decoder(e: Emitter, latent_f32, B: int, h: int, w: int, out_buf, out_dtype: int) -> None:
+    """ImageDecoder (image_decoder.py:22-55). out: fp32 or uint8 [B][8h][8w][3]."""
+    p = e.p
+    z = p.alloc(B * h * w * 4 * 4)
+    p.rec(ops.conv_direct, x=latent_f32, w=e.W["post_quant_conv.w"], bias=e.W["post_quant_conv.b"], out=z, batch=B, h_in=h,
+          w_in=w, c_in=4, c_out=4, ksize=1, in_dtype=ops.OUT_F32, out_dtype=ops.OUT_F32, in_scale=1.0 / 0.18215,
+          name="post_quant_conv")
+    x = p.act(B, h, w, 512)
+    p.rec(ops.conv_direct, x=z, w=e.W["decoder.conv_in.w"], bias=e.W["decoder.conv_in.b"], out=x.buf, batch=B, h_in=h, w_in=w,
+          c_in=4, c_out=512, ksize=3, in_dtype=ops.OUT_F32, out_dtype=ops.OUT_BF16, name="decoder.conv_in")
+    p.free(z)
+    x = e.res_block(x, "decoder.mid_block.resnets.0", 512, free_input=True)
+    x = emit_vae_attention(e, x, "decoder.mid_block.attentions.0")
+    x = e.res_block(x, "decoder.mid_block.resnets.1", 512, free_input=True)
+    for bi, (cin, cout, up) in enumerate(wtab.VAE_DEC_BLOCKS):
+        for r in range(3):
+            x = e.res_block(x, f"decoder.up_blocks.{bi}.resnets.{r}", cout, free_input=True)
+        if up:
+            y = e.conv(x, f"decoder.up_blocks.{bi}.upsamplers.0.conv", cout, ksize=3, upsample=True)
+            p.free(x)
+            x = y
+    g = e.group_norm(x, "decoder.conv_norm_out", silu=True)
+    p.free(x)
+    p.rec(ops.conv_direct, x=g.buf, w=e.W["decoder.conv_out.w"], bias=e.W["decoder.conv_out.b"], out=out_buf, batch=B,
+          h_in=g.H, w_in=g.W, c_in=128, c_out=3, ksize=3, in_dtype=ops.OUT_BF16, out_dtype=out_dtype, name="decoder.conv_out")
+    p.free(g)

@@ -1,0 +1,407 @@
+"""Drop-in model objects: the duck type ``StableDiffusion`` uses for its Keras models.
+
+The reference pipeline only touches its models through ``ctor(...)``, ``.compile(jit_compile=True)``,
+``.predict_on_batch(x)`` and — from the checkpoint loader — ``.name``, ``.weights`` (ordered, Keras
+layout, with ``.shape`` / ``.name``) and ``.set_weights(list)`` (reference
+``stable_diffusion.py:650-725``, ``ckpt_loader.py:2136-2193``).  The classes below provide exactly
+that surface over the HIP library:
+
+=================  =============================================  ==========================
+class              replaces (reference)                           predict_on_batch
+=================  =============================================  ==========================
+DiffusionModel     diffusion_model.py:163-296                     [latent, t_emb, context(, 13 controls)] -> (B,h,w,4)
+ImageDecoder       image_decoder.py:22-66                         latent -> (B,8h,8w,3)
+ControlNet         control_net.py:45-118                          [latent, t_emb, context, hint] -> 13 arrays
+HintNet            control_net.py:10-42                           (B,H,W,3) -> (B,H/8,W/8,320)
+=================  =============================================  ==========================
+
+Inputs / outputs at this boundary are host numpy arrays like the reference's; the fused,
+device-resident loop (``minsdtf_amd/pipeline.py``) bypasses the boundary and keeps everything in
+HBM.  There is no CPU fallback: constructing a model without a GPU + built library raises.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, engine, ops, packing
+from . import weights as wtab
+
+
+class WeightVar:
+    """What ``model.weights[i]`` needs to be for the positional loader: a name and a Keras shape."""
+    __slots__ = ("name", "shape")
+
+    def __init__(self, name, shape):
+        self.name, self.shape = name, tuple(shape)
+
+    def __repr__(self):
+        return f"<WeightVar {self.name} {self.shape}>"
+
+
+def default_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.HipExtensionError("no HIP device visible: the MI355X path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+# names whose convs / denses run on the fp32 vector-FMA path (channel counts below an MFMA tile)
+_DIRECT = {
+    "conv_in", "conv_out", "time_embedding.linear_1", "time_embedding.linear_2",
+    "post_quant_conv", "decoder.conv_in", "decoder.conv_out",
+} | {f"input_hint_block.{i}" for i in range(7)}
+
+
+class HipModel:
+    kind = ""  # weight-table kind
+
+    def __init__(self, name=None, device=None):
+        self.name = name or type(self).__name__.lower()
+        self.device = device if device is not None else default_device()
+        lib = _lib.load()
+        _lib.check(lib.msd_init(), "msd_init")
+        self._specs = wtab.table(self.kind)
+        self.weights: List[WeightVar] = [
+            WeightVar(s.name + (".kernel" if s.kind.endswith("_w") else "." + s.kind), s.shape) for s in self._specs]
+        self._W: Optional[Dict[str, torch.Tensor]] = None
+        self._plans: Dict[tuple, "_BoundPlan"] = {}
+        self._use_graph = False
+
+    # ---- Keras-like surface
+    def compile(self, jit_compile=True, **_):
+        """The reference calls ``compile(jit_compile=True)``; here it switches predict_on_batch to
+        hipGraph replay (captured on first use per input shape)."""
+        self._use_graph = bool(jit_compile)
+        self._plans.clear()
+
+    def count_params(self) -> int:
+        return wtab.param_count(self.kind)
+
+    def set_weights(self, arrays: Sequence[np.ndarray]) -> None:
+        if len(arrays) != len(self._specs):
+            raise ValueError(f"{self.name}: expected {len(self._specs)} weight arrays, got {len(arrays)}")
+        named = {}
+        for s, a in zip(self._specs, arrays):
+            a = np.asarray(a)
+            if tuple(a.shape) != tuple(s.shape):
+                raise ValueError(f"{self.name}: {s.name} has shape {a.shape}, expected {s.shape}")
+            named[(s.name, s.kind)] = a
+        self._W = self._pack(named)
+        self._plans.clear()
+
+    def load_synthetic(self, seed=0, bias_scale=0.0) -> List[np.ndarray]:
+        """Fill with the seeded synthetic checkpoint; returns the Keras-layout list."""
+        arrays = wtab.synth_keras_weights(self.kind, seed=seed, bias_scale=bias_scale)
+        self.set_weights(arrays)
+        return arrays
+
+    def _maybe_load(self, ckpt_path, lora_dict=None):
+        """Reference constructors load a local checkpoint if given one; no network download here."""
+        if ckpt_path is not None and os.path.exists(ckpt_path):
+            wtab.load_weights_from_file(self, ckpt_path, self.kind, lora_dict=lora_dict)
+
+    # ---- packing
+    def _pack(self, named) -> Dict[str, torch.Tensor]:
+        d = self.device
+        W: Dict[str, torch.Tensor] = {}
+        get = lambda n, k: named.get((n, k))  # noqa: E731
+        names = []
+        for s in self._specs:
+            if s.name not in names:
+                names.append(s.name)
+        tproj_w, tproj_b = [], []
+        for n in names:
+            cw, dw = get(n, "conv_w"), get(n, "dense_w")
+            b, g, beta = get(n, "bias"), get(n, "gamma"), get(n, "beta")
+            if g is not None:
+                W[n + ".g"], W[n + ".b"] = packing.dev_f32(g, d), packing.dev_f32(beta, d)
+                continue
+            if n.endswith(".time_emb_proj"):
+                tproj_w.append(dw)
+                tproj_b.append(b)
+                continue
+            if n in _DIRECT:
+                w = cw if cw is not None else dw.reshape(1, 1, *dw.shape)
+                W[n + ".w"] = packing.dev_f32(w, d)
+                W[n + ".b"] = packing.dev_f32(b, d)
+                continue
+            if n.endswith(".ff.net.0.proj"):
+                W[n + ".w"], W[n + ".b"] = packing.pack_geglu(dw, b, d)
+                continue
+            if n.endswith((".attn1.to_q", ".attn1.to_k", ".attn1.to_v", ".attn2.to_k", ".attn2.to_v",
+                           ".query", ".key", ".value")):
+                continue  # stacked below
+            if cw is not None:
+                W[n + ".w"] = packing.pack_conv(cw, d)
+            else:
+                W[n + ".w"] = packing.pack_dense(dw, d)
+            if b is not None:
+                W[n + ".b"] = packing.dev_f32(b, d)
+        for n in names:
+            if n.endswith(".attn1.to_q"):
+                base = n[: -len(".to_q")]
+                W[base + ".qkv.w"] = packing.pack_dense_stack(
+                    [get(base + ".to_q", "dense_w"), get(base + ".to_k", "dense_w"), get(base + ".to_v", "dense_w")], d)
+            elif n.endswith(".attn2.to_k"):
+                base = n[: -len(".to_k")]
+                W[base + ".kv.w"] = packing.pack_dense_stack([get(base + ".to_k", "dense_w"), get(base + ".to_v", "dense_w")], d)
+            elif n.endswith(".query"):
+                base = n[: -len(".query")]
+                W[base + ".qkv.w"] = packing.pack_dense_stack([get(base + "." + k, "dense_w") for k in ("query", "key", "value")], d)
+                W[base + ".qkv.b"] = packing.dev_f32(np.concatenate([get(base + "." + k, "bias") for k in ("query", "key", "value")]), d)
+        if tproj_w:
+            W["time_emb_proj_cat.w"] = packing.dev_f32(np.concatenate(tproj_w, axis=1).reshape(1, 1, 1280, -1), d)
+            W["time_emb_proj_cat.b"] = packing.dev_f32(np.concatenate(tproj_b), d)
+        return W
+
+    def _require_weights(self):
+        if self._W is None:
+            raise RuntimeError(f"{self.name}: no weights set (pass ckpt_path=, call set_weights() or load_synthetic())")
+
+    # ---- plan cache
+    def _bound(self, key, builder) -> "_BoundPlan":
+        bp = self._plans.get(key)
+        if bp is None:
+            self._require_weights()
+            bp = builder()
+            self._plans[key] = bp
+        return bp
+
+
+class _BoundPlan:
+    """A finalised plan + its boundary tensors, optionally captured into a hipGraph."""
+
+    def __init__(self, plan: engine.Plan, use_graph: bool):
+        self.plan = plan
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.use_graph = use_graph
+        self.io: Dict[str, torch.Tensor] = {}
+
+    def run(self):
+        if not self.use_graph:
+            self.plan.run(torch.cuda.current_stream().cuda_stream)
+            return
+        if self.graph is None:
+            # warm-up run outside capture (first-touch of code objects), then capture
+            self.plan.run(torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(g, stream=s):
+                    self.plan.run(torch.cuda.current_stream().cuda_stream)
+            torch.cuda.current_stream().wait_stream(s)
+            self.graph = g
+        self.graph.replay()
+
+
+def _np32(x) -> np.ndarray:
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+
+
+def _stage_inputs(plan: engine.Plan, shapes: Dict[str, tuple]) -> Dict[str, engine.Buf]:
+    return {k: plan.alloc(int(np.prod(s)) * 4) for k, s in shapes.items()}
+
+
+class DiffusionModel(HipModel):
+    """SD1.5 UNet (reference diffusion_model.py:163-296) on the HIP path."""
+    kind = "civitai_model"
+
+    def __init__(self, img_height=512, img_width=512, apply_control_net=False, name=None, ckpt_path=None, lora_dict=None,
+                 device=None):
+        super().__init__(name or "diffusion_model", device)
+        if img_height % 64 or img_width % 64:
+            raise ValueError("img_height / img_width must be multiples of 64 (three stride-2 levels after the /8 VAE)")
+        self.h, self.w = img_height // 8, img_width // 8
+        self.apply_control_net = apply_control_net
+        self._maybe_load(ckpt_path, lora_dict)
+
+    def _build(self, B: int, T: int, with_controls: bool) -> _BoundPlan:
+        h, w = self.h, self.w
+        plan = engine.Plan(self.device)
+        e = engine.Emitter(plan, self._W)
+        ins = _stage_inputs(plan, dict(latent=(B, h, w, 4), t_emb=(B, 320), context=(B, T, 768)))
+        ctx16 = engine.Act(plan.alloc(B * T * 768 * 2), B, T, 1, 768)
+        plan.rec(ops.cast_f32_to_bf16, x=ins["context"], out=ctx16.buf, n=B * T * 768, name="context.bf16")
+        ctx_kv = engine.emit_context_kv(e, ctx16, engine.UNET_ATTN_LAYERS, plan)
+        cols = engine.temb_columns(False)
+        total = sum(c for _, c in engine.resblock_names(False))
+        table = plan.alloc(B * total * 4)
+        engine.emit_time_embedding(e, ins["t_emb"], B, table, encoder_only=False)
+        controls, cstage = None, []
+        if with_controls:
+            controls = []
+            for i, ch in enumerate(wtab.UNET_SKIP_CH + (1280,)):
+                hh, ww = _skip_hw(i, h, w)
+                st = plan.alloc(B * hh * ww * ch * 4)
+                a = plan.act(B, hh, ww, ch)
+                plan.rec(ops.cast_f32_to_bf16, x=st, out=a.buf, n=B * hh * ww * ch, name=f"control.{i}.bf16")
+                cstage.append((st, (B, hh, ww, ch)))
+                controls.append(a)
+        eps = plan.alloc(B * h * w * 4 * 4)
+        engine.emit_unet(e, ins["latent"], B, B, h, w, (table, 0, total, cols), ctx_kv, T, eps, controls)
+        plan.finalize()
+        bp = _BoundPlan(plan, self._use_graph)
+        bp.io = {k: b.tensor(torch.float32, s) for (k, b), s in
+                 zip(ins.items(), [(B, h, w, 4), (B, 320), (B, T, 768)])}
+        bp.io["eps"] = eps.tensor(torch.float32, (B, h, w, 4))
+        for i, (st, shp) in enumerate(cstage):
+            bp.io[f"control.{i}"] = st.tensor(torch.float32, shp)
+        return bp
+
+    def predict_on_batch(self, x):
+        latent, t_emb, context = _np32(x[0]), _np32(x[1]), _np32(x[2])
+        controls = [_np32(c) for c in x[3:]]
+        if controls and len(controls) != 13:
+            raise ValueError("expected 13 control tensors")
+        B, T = latent.shape[0], context.shape[1]
+        if latent.shape[1:] != (self.h, self.w, 4):
+            raise ValueError(f"latent shape {latent.shape} does not match the model ({self.h},{self.w},4)")
+        bp = self._bound((B, T, bool(controls)), lambda: self._build(B, T, bool(controls)))
+        bp.io["latent"].copy_(torch.from_numpy(latent))
+        bp.io["t_emb"].copy_(torch.from_numpy(t_emb))
+        bp.io["context"].copy_(torch.from_numpy(context))
+        for i, c in enumerate(controls):
+            bp.io[f"control.{i}"].copy_(torch.from_numpy(c))
+        bp.run()
+        return bp.io["eps"].cpu().numpy()
+
+    __call__ = predict_on_batch
+
+
+def _skip_hw(i: int, h: int, w: int):
+    """Spatial size of skip / control tensor i (index 12 = mid block output)."""
+    lvl = (0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 3)[i]
+    return h >> lvl, w >> lvl
+
+
+class ImageDecoder(HipModel):
+    """VAE decoder (reference image_decoder.py:22-66) on the HIP path."""
+    kind = "decoder"
+
+    def __init__(self, name=None, ckpt_path=None, device=None):
+        super().__init__(name or "image_decoder", device)
+        self._maybe_load(ckpt_path)
+
+    def _build(self, B, h, w, out_u8: bool) -> _BoundPlan:
+        plan = engine.Plan(self.device)
+        e = engine.Emitter(plan, self._W)
+        lat = plan.alloc(B * h * w * 4 * 4)
+        out = plan.alloc(B * 8 * h * 8 * w * 3 * (1 if out_u8 else 4))
+        engine.emit_decoder(e, lat, B, h, w, out, ops.OUT_U8 if out_u8 else ops.OUT_F32)
+        plan.finalize()
+        bp = _BoundPlan(plan, self._use_graph)
+        bp.io["latent"] = lat.tensor(torch.float32, (B, h, w, 4))
+        bp.io["image"] = out.tensor(torch.uint8 if out_u8 else torch.float32, (B, 8 * h, 8 * w, 3))
+        return bp
+
+    def predict_on_batch(self, x):
+        latent = _np32(x)
+        B, h, w, _ = latent.shape
+        bp = self._bound((B, h, w, False), lambda: self._build(B, h, w, False))
+        bp.io["latent"].copy_(torch.from_numpy(latent))
+        bp.run()
+        return bp.io["image"].cpu().numpy()
+
+    def decode_to_uint8(self, latent_dev: torch.Tensor) -> torch.Tensor:
+        """Device-resident variant used by the fused pipeline: fp32 latent tensor on the GPU ->
+        uint8 image tensor on the GPU with the reference's truncating conversion fused in."""
+        B, h, w, _ = latent_dev.shape
+        bp = self._bound((B, h, w, True), lambda: self._build(B, h, w, True))
+        bp.io["latent"].copy_(latent_dev)
+        bp.run()
+        return bp.io["image"]
+
+    __call__ = predict_on_batch
+
+
+class ControlNet(HipModel):
+    """ControlNet (reference control_net.py:45-118) on the HIP path."""
+    kind = "controlnet"
+
+    def __init__(self, img_height=512, img_width=512, name=None, controlnet_path=None, device=None):
+        super().__init__(name or "control_net", device)
+        self.h, self.w = img_height // 8, img_width // 8
+        self._maybe_load(controlnet_path)
+
+    def _build(self, B: int, T: int) -> _BoundPlan:
+        h, w = self.h, self.w
+        plan = engine.Plan(self.device)
+        e = engine.Emitter(plan, self._W)
+        ins = _stage_inputs(plan, dict(latent=(B, h, w, 4), t_emb=(B, 320), context=(B, T, 768), hint=(B, h, w, 320)))
+        ctx16 = engine.Act(plan.alloc(B * T * 768 * 2), B, T, 1, 768)
+        plan.rec(ops.cast_f32_to_bf16, x=ins["context"], out=ctx16.buf, n=B * T * 768, name="context.bf16")
+        hint16 = plan.act(B, h, w, 320)
+        plan.rec(ops.cast_f32_to_bf16, x=ins["hint"], out=hint16.buf, n=B * h * w * 320, name="hint.bf16")
+        ctx_kv = engine.emit_context_kv(e, ctx16, engine.ENCODER_ATTN_LAYERS, plan)
+        cols = engine.temb_columns(True)
+        total = sum(c for _, c in engine.resblock_names(True))
+        table = plan.alloc(B * total * 4)
+        engine.emit_time_embedding(e, ins["t_emb"], B, table, encoder_only=True)
+        outs, outs32 = [], []
+        for i, ch in enumerate(wtab.UNET_SKIP_CH + (1280,)):
+            hh, ww = _skip_hw(i, h, w)
+            outs.append(plan.act(B, hh, ww, ch))
+        engine.emit_controlnet(e, ins["latent"], B, B, h, w, (table, 0, total, cols), ctx_kv, T, hint16, outs)
+        for i, a in enumerate(outs):
+            o32 = plan.alloc(a.M * a.C * 4)
+            plan.rec(ops.cast_bf16_to_f32, x=a.buf, out=o32, n=a.M * a.C, name=f"control.{i}.f32")
+            outs32.append((o32, (a.B, a.H, a.W, a.C)))
+        plan.finalize()
+        bp = _BoundPlan(plan, self._use_graph)
+        shapes = dict(latent=(B, h, w, 4), t_emb=(B, 320), context=(B, T, 768), hint=(B, h, w, 320))
+        bp.io = {k: ins[k].tensor(torch.float32, s) for k, s in shapes.items()}
+        for i, (o32, shp) in enumerate(outs32):
+            bp.io[f"out.{i}"] = o32.tensor(torch.float32, shp)
+        return bp
+
+    def predict_on_batch(self, x):
+        latent, t_emb, context, hint = (_np32(v) for v in x)
+        B, T = latent.shape[0], context.shape[1]
+        bp = self._bound((B, T), lambda: self._build(B, T))
+        for k, v in (("latent", latent), ("t_emb", t_emb), ("context", context), ("hint", hint)):
+            bp.io[k].copy_(torch.from_numpy(v))
+        bp.run()
+        return [bp.io[f"out.{i}"].cpu().numpy() for i in range(13)]
+
+    __call__ = predict_on_batch
+
+
+class HintNet(HipModel):
+    """HintNet (reference control_net.py:10-42) on the HIP path."""
+    kind = "hintnet"
+
+    def __init__(self, img_height=512, img_width=512, name=None, controlnet_path=None, device=None):
+        super().__init__(name or "hint_net", device)
+        self.H, self.W = img_height, img_width
+        self._maybe_load(controlnet_path)
+
+    def _build(self, B: int) -> _BoundPlan:
+        plan = engine.Plan(self.device)
+        e = engine.Emitter(plan, self._W)
+        img = plan.alloc(B * self.H * self.W * 3 * 4)
+        out = plan.act(B, self.H // 8, self.W // 8, 320)
+        engine.emit_hintnet(e, img, B, self.H, self.W, out)
+        o32 = plan.alloc(out.M * 320 * 4)
+        plan.rec(ops.cast_bf16_to_f32, x=out.buf, out=o32, n=out.M * 320, name="hint.f32")
+        plan.finalize()
+        bp = _BoundPlan(plan, self._use_graph)
+        bp.io["image"] = img.tensor(torch.float32, (B, self.H, self.W, 3))
+        bp.io["hint"] = o32.tensor(torch.float32, (B, self.H // 8, self.W // 8, 320))
+        return bp
+
+    def predict_on_batch(self, x):
+        img = _np32(x)
+        B = img.shape[0]
+        bp = self._bound((B,), lambda: self._build(B))
+        bp.io["image"].copy_(torch.from_numpy(img))
+        bp.run()
+        return bp.io["hint"].cpu().numpy()
+
+    __call__ = predict_on_batch

@@ -1,0 +1,468 @@
+"""``StableDiffusion`` — the reference's public pipeline API over the MI355X path.
+
+Mirrors reference ``stable_diffusion/stable_diffusion.py`` (class ``StableDiffusionBase`` :47-568 and
+``StableDiffusion`` :575-725): same constructor arguments, same ``text_to_image`` /
+``image_to_image`` / ``generate_image`` signatures and defaults, same lazily-built model
+properties, same return value (``uint8 (B, H, W, 3)``).  What differs is where the loop runs:
+
+* ``generate_image`` keeps the whole denoise loop on the GPU (:class:`DenoiseEngine`): the
+  cond + uncond UNet passes of one step run as ONE batch-2B forward (no op couples samples, so
+  this is the same arithmetic as the reference's two ``predict_on_batch`` calls, uncond rows
+  first), CFG + rescale + the sampler step are one kernel, and the step (or the whole loop when no
+  per-step callback is installed) is replayed from a hipGraph.  The latent never leaves HBM.
+* ``host_loop=True`` runs the reference's own control flow instead — numpy CFG / rescale /
+  ``Scheduler.step`` around ``predict_on_batch`` calls (stable_diffusion.py:442-479) — which is
+  what a maintainer gets by only swapping the model classes; tests use it to check that both
+  routes agree.
+
+Out of scope here: the CLIP text front-end (prompts must arrive as embeddings, or
+through a user-supplied ``text_frontend``), the VAE encoder for img2img, inpainting, TCD.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import engine, ops
+from . import weights as wtab
+from .models import ControlNet, DiffusionModel, HintNet, ImageDecoder, _BoundPlan, _skip_hw, default_device
+from .scheduler import Scheduler
+
+MAX_PROMPT_LENGTH = 77
+
+
+def get_timestep_embedding(timestep, batch_size, dim=320, max_period=10000):
+    """Sinusoidal embedding, [cos | sin] (reference stable_diffusion.py:543-553)."""
+    half = dim // 2
+    freqs = np.exp(-np.log(max_period) * np.asarray(range(0, half), dtype=np.float32) / half)
+    args = np.asarray([timestep], dtype=np.float32) * freqs
+    embedding = np.concatenate([np.cos(args), np.sin(args)], axis=0)
+    embedding = np.reshape(embedding, [1, -1])
+    return np.repeat(embedding, batch_size, axis=0)
+
+
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0, epsilon=1e-05):
+    """Host version of the guidance rescale (reference stable_diffusion.py:304-315)."""
+    axes = tuple(range(1, len(noise_pred_text.shape)))
+    std_text = np.std(noise_pred_text, axis=axes, keepdims=True)
+    std_cfg = np.std(noise_cfg, axis=axes, keepdims=True) + epsilon
+    noise_pred_rescaled = noise_cfg * (std_text / std_cfg)
+    return guidance_rescale * noise_pred_rescaled + (1.0 - guidance_rescale) * noise_cfg
+
+
+class DenoiseEngine:
+    """Device-resident denoise loop for a fixed (batch, context lengths, steps, guidance) shape."""
+
+    def __init__(self, unet: DiffusionModel, B: int, t_cond: int, t_uncond: int, num_steps: int, guidance: float,
+                 guidance_rescale: float, control_net: Optional[ControlNet] = None, hint_net: Optional[HintNet] = None,
+                 use_graph: bool = True):
+        unet._require_weights()
+        self.unet, self.B, self.num_steps = unet, B, num_steps
+        self.h, self.w = unet.h, unet.w
+        self.use_graph = use_graph
+        dev = unet.device
+        cfg = guidance > 0.0
+        self.cfg = cfg
+        h, w = self.h, self.w
+        fuse = cfg and (t_cond == t_uncond)
+        # passes: list of (rows in eps, NB, context length); fused = uncond rows then cond rows
+        if not cfg:
+            passes = [(0, B, t_cond, "cond")]
+        elif fuse:
+            passes = [(0, 2 * B, t_cond, "both")]
+        else:
+            passes = [(0, B, t_uncond, "uncond"), (B, B, t_cond, "cond")]
+        self.passes = passes
+        self.has_control = control_net is not None
+
+        # ---- per-call preparation plan: contexts -> K/V^T, time-embedding tables, hint --------
+        prep = engine.Plan(dev)
+        e_u = engine.Emitter(prep, unet._W)
+        self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.latent = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
+        self.coef = torch.zeros(num_steps, 4, dtype=torch.float32, device=dev)
+        self.temb_in = torch.zeros(num_steps, 320, dtype=torch.float32, device=dev)
+        total_u = sum(c for _, c in engine.resblock_names(False))
+        table_u = prep.alloc(num_steps * total_u * 4)
+        engine.emit_time_embedding(e_u, self.temb_in, num_steps, table_u, encoder_only=False)
+        self.ctx_in: Dict[str, torch.Tensor] = {}
+        ctx_kv_u, ctx_kv_c = {}, {}
+        e_c = None
+        table_c = total_c = None
+        if self.has_control:
+            control_net._require_weights()
+            hint_net._require_weights()
+            e_c = engine.Emitter(prep, control_net._W)
+            total_c = sum(c for _, c in engine.resblock_names(True))
+            table_c = prep.alloc(num_steps * total_c * 4)
+            engine.emit_time_embedding(e_c, self.temb_in, num_steps, table_c, encoder_only=True)
+        for (_row0, nb, t, tag) in passes:
+            st = torch.zeros(nb, t, 768, dtype=torch.float32, device=dev)
+            self.ctx_in[tag] = st
+            c16 = engine.Act(prep.alloc(nb * t * 768 * 2), nb, t, 1, 768)
+            prep.rec(ops.cast_f32_to_bf16, x=st, out=c16.buf, n=nb * t * 768, name=f"context.{tag}.bf16")
+            ctx_kv_u[tag] = engine.emit_context_kv(e_u, c16, engine.UNET_ATTN_LAYERS, prep)
+            if self.has_control:
+                ctx_kv_c[tag] = engine.emit_context_kv(e_c, c16, engine.ENCODER_ATTN_LAYERS, prep)
+        self.hint_img = None
+        hint_act = None
+        if self.has_control:
+            # hint computed once per image batch (stable_diffusion.py:427-441), tiled to both halves
+            nb_max = max(nb for (_r, nb, _t, _g) in passes)
+            self.hint_img = torch.zeros(nb_max, 8 * h, 8 * w, 3, dtype=torch.float32, device=dev)
+            e_h = engine.Emitter(prep, hint_net._W)
+            hint_act = prep.act(nb_max, h, w, 320)
+            engine.emit_hintnet(e_h, self.hint_img, nb_max, 8 * h, 8 * w, hint_act)
+        prep.finalize()
+        self.prep = prep
+
+        # ---- per-step plan --------------------------------------------------------------------
+        step = engine.Plan(dev)
+        n = h * w * 4
+        self.eps = torch.zeros((2 * B if cfg else B), n, dtype=torch.float32, device=dev)
+        cols_u = engine.temb_columns(False)
+        cols_c = engine.temb_columns(True)
+        s_u = engine.Emitter(step, unet._W, step_ptr=self.step_ptr)
+        s_c = engine.Emitter(step, control_net._W, step_ptr=self.step_ptr) if self.has_control else None
+        for (row0, nb, t, tag) in passes:
+            controls = None
+            if self.has_control:
+                controls = [step.act(nb, *_skip_hw(i, h, w), ch) for i, ch in enumerate(wtab.UNET_SKIP_CH + (1280,))]
+                hint_nb = engine.Act(hint_act.buf, nb, h, w, 320)  # first nb rows of the tiled hint
+                engine.emit_controlnet(s_c, self.latent, B, nb, h, w, (table_c, total_c, 0, cols_c), ctx_kv_c[tag], t,
+                                       hint_nb, controls)
+            eps_view = _Ptr(self.eps.data_ptr() + row0 * n * 4)
+            engine.emit_unet(s_u, self.latent, B, nb, h, w, (table_u, total_u, 0, cols_u), ctx_kv_u[tag], t, eps_view, controls)
+            if controls is not None:
+                step.free(*controls)
+        step.rec(ops.cfg_step, eps=self.eps, latent=self.latent, coef=self.coef, step_ptr=self.step_ptr, batch=B, n=n,
+                 num_steps=num_steps, guidance=guidance, guidance_rescale=guidance_rescale, advance=True)
+        step.finalize()
+        self.step = step
+        self._step_graph: Optional[torch.cuda.CUDAGraph] = None
+        self._loop_graph: Optional[torch.cuda.CUDAGraph] = None
+        self._loop_graph_steps = 0
+        self._warmed = False
+
+    # ---- graphs
+    def _capture(self, fn) -> torch.cuda.CUDAGraph:
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                fn(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.current_stream().wait_stream(s)
+        return g
+
+    def _warm(self) -> None:
+        """One eager step before the first capture (code objects load on first launch, which must
+        not happen inside a stream capture); the latent and step counter are restored."""
+        if self._warmed:
+            return
+        saved = (self.latent.clone(), self.step_ptr.clone())
+        self.step.run(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        self.latent.copy_(saved[0])
+        self.step_ptr.copy_(saved[1])
+        self._warmed = True
+
+    def run_steps(self, count: int, callback: Optional[Callable[[int], None]] = None) -> None:
+        """Advance the latent by `count` sampler steps from the current device step counter."""
+        if not self.use_graph:
+            st = torch.cuda.current_stream().cuda_stream
+            for i in range(count):
+                self.step.run(st)
+                if callback is not None:
+                    callback(i + 1)
+            return
+        if callback is None:
+            if self._loop_graph is None or self._loop_graph_steps != count:
+                def whole(stream):
+                    for _ in range(count):
+                        self.step.run(stream)
+                self._warm()
+                self._loop_graph = self._capture(whole)  # capture records, it does not execute
+                self._loop_graph_steps = count
+            self._loop_graph.replay()
+            return
+        if self._step_graph is None:
+            self._warm()
+            self._step_graph = self._capture(self.step.run)
+        for i in range(count):
+            self._step_graph.replay()
+            callback(i + 1)
+
+    def prepare(self, contexts: Dict[str, np.ndarray], noise: np.ndarray, scheduler: Scheduler, timesteps,
+                start_index: int = 0, hint_image: Optional[np.ndarray] = None) -> None:
+        """Upload the per-call inputs and run the preparation plan."""
+        for tag, arr in contexts.items():
+            self.ctx_in[tag].copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)))
+        self.latent.copy_(torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float32)))
+        self.coef.copy_(torch.from_numpy(scheduler.coefficient_table()))
+        temb = np.concatenate([get_timestep_embedding(int(t), 1) for t in scheduler.timesteps], axis=0)
+        self.temb_in.copy_(torch.from_numpy(np.ascontiguousarray(temb, dtype=np.float32)))
+        self.step_ptr.fill_(int(start_index))
+        if self.has_control:
+            hi = np.ascontiguousarray(hint_image, dtype=np.float32)
+            reps = self.hint_img.shape[0] // hi.shape[0]
+            self.hint_img.copy_(torch.from_numpy(np.tile(hi, (reps, 1, 1, 1))))
+        self.prep.run(torch.cuda.current_stream().cuda_stream)
+
+
+class _Ptr:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
+class StableDiffusionBase:
+    """Base class for the stable diffusion 1.5 pipeline (reference stable_diffusion.py:47-568)."""
+
+    def __init__(self, img_height=512, img_width=512, jit_compile=False, active_tcd=False):
+        self.img_height = img_height
+        self.img_width = img_width
+        self._image_encoder = None
+        self._text_encoder = None
+        self._hint_net = None
+        self._control_net = None
+        self._text_clip_embedding = None
+        self._diffusion_model = None
+        self._image_decoder = None
+        self._tokenizer = None
+        self.jit_compile = jit_compile
+        self.active_tcd = active_tcd
+        self.scheduler = Scheduler(active_tcd=active_tcd)
+        self._engines: Dict[tuple, DenoiseEngine] = {}
+        self.text_frontend = None
+        self.unconditional_context = None  # (77, 768) embedding of the empty prompt, supplied by the caller
+
+    # ---- public entry points (reference :84-139)
+    def text_to_image(self, prompt, negative_prompt=None, batch_size=1, num_steps=50, unconditional_guidance_scale=7.5,
+                      embedding=None, negative_embedding=None, seed=None, control_net_image=None, guidance_rescale=0.7,
+                      callback=None, **kw):
+        encoded_text = self.encode_text(prompt, embedding)
+        return self.generate_image(encoded_text, negative_prompt=negative_prompt, batch_size=batch_size, num_steps=num_steps,
+                                   unconditional_guidance_scale=unconditional_guidance_scale, seed=seed,
+                                   negative_embedding=negative_embedding, control_net_image=control_net_image,
+                                   guidance_rescale=guidance_rescale, callback=callback, **kw)
+
+    def image_to_image(self, prompt, negative_prompt=None, batch_size=1, num_steps=50, unconditional_guidance_scale=7.5,
+                       embedding=None, negative_embedding=None, seed=None, control_net_image=None, reference_image=None,
+                       reference_image_strength=0.8, guidance_rescale=0.7, callback=None, **kw):
+        encoded_text = self.encode_text(prompt, embedding)
+        return self.generate_image(encoded_text, negative_prompt=negative_prompt, batch_size=batch_size, num_steps=num_steps,
+                                   unconditional_guidance_scale=unconditional_guidance_scale, seed=seed,
+                                   negative_embedding=negative_embedding, control_net_image=control_net_image,
+                                   reference_image=reference_image, reference_image_strength=reference_image_strength,
+                                   guidance_rescale=guidance_rescale, callback=callback, **kw)
+
+    def encode_text(self, prompt, embedding_data=None):
+        """Prompt -> context (77k, 768).  The CLIP front-end is outside the accelerated path
+        (SURVEY.md §8f rank 3): pass an embedding array, or install ``text_frontend`` (any object
+        with ``encode(prompt, embedding_data) -> ndarray``)."""
+        if isinstance(prompt, (np.ndarray, torch.Tensor)):
+            return np.asarray(prompt, dtype=np.float32)
+        if self.text_frontend is not None:
+            return np.asarray(self.text_frontend.encode(prompt, embedding_data), dtype=np.float32)
+        raise NotImplementedError(
+            "string prompts need the CLIP text front-end, which this path does not accelerate; pass the "
+            "(77k,768) text embedding instead of a string, or set StableDiffusion.text_frontend")
+
+    def _get_unconditional_context(self):
+        if self.unconditional_context is None:
+            if self.text_frontend is not None:
+                self.unconditional_context = np.asarray(self.text_frontend.encode("", None), dtype=np.float32)
+            else:
+                raise NotImplementedError(
+                    "the unconditional context is CLIP's embedding of the empty prompt; set "
+                    "StableDiffusion.unconditional_context to a (77,768) array or install text_frontend")
+        u = np.asarray(self.unconditional_context, dtype=np.float32)
+        return u[None] if u.ndim == 2 else u
+
+    def _expand_tensor(self, text_embedding, batch_size):
+        """Reference :495-503."""
+        text_embedding = np.squeeze(text_embedding)
+        if len(text_embedding.shape) == 2:
+            text_embedding = np.repeat(np.expand_dims(text_embedding, axis=0), batch_size, axis=0)
+        return text_embedding
+
+    _get_timestep_embedding = staticmethod(lambda timestep, batch_size, dim=320, max_period=10000:
+                                           get_timestep_embedding(timestep, batch_size, dim, max_period))
+    rescale_noise_cfg = staticmethod(rescale_noise_cfg)
+
+    def _get_initial_diffusion_noise(self, batch_size, seed):
+        """The reference draws keras.random.normal(seed) (backend RNG, :555-557); here the noise is
+        numpy's PCG64 standard normal for the GLOBAL batch, so a sharded run slices the same draw."""
+        rng = np.random.default_rng(seed)
+        return rng.standard_normal((batch_size, self.img_height // 8, self.img_width // 8, 4)).astype(np.float32)
+
+    @staticmethod
+    def resize(image_array, new_h=None, new_w=None):
+        """Bilinear resize with align-corners sampling (reference :242-275)."""
+        h, w, _c = image_array.shape
+        if new_h == h and new_w == w:
+            return image_array
+        y = np.expand_dims(np.linspace(0, h - 1, new_h), axis=-1)
+        x = np.expand_dims(np.linspace(0, w - 1, new_w), axis=0)
+        x0, x1 = np.clip(np.floor(x).astype(int), 0, w - 1), np.clip(np.ceil(x).astype(int), 0, w - 1)
+        y0, y1 = np.clip(np.floor(y).astype(int), 0, h - 1), np.clip(np.ceil(y).astype(int), 0, h - 1)
+        dx, dy = np.expand_dims(x - x0, -1), np.expand_dims(y - y0, -1)
+        top = image_array[y0, x0, :] * (1.0 - dx) + image_array[y0, x1, :] * dx
+        bot = image_array[y1, x0, :] * (1.0 - dx) + image_array[y1, x1, :] * dx
+        return top * (1.0 - dy) + bot * dy
+
+    # ---- the loop (reference :317-486)
+    def generate_image(self, encoded_text, negative_prompt=None, batch_size=1, num_steps=50, unconditional_guidance_scale=7.5,
+                       diffusion_noise=None, seed=None, negative_embedding=None, control_net_image=None, inpaint_mask=None,
+                       mask_blur_strength=None, reference_image=None, reference_image_strength=0.8, guidance_rescale=0.0,
+                       callback=None, host_loop=False, return_latent=False):
+        if diffusion_noise is not None and seed is not None:
+            raise ValueError("`diffusion_noise` and `seed` should not both be passed to `generate_image`. `seed` is only "
+                             "used to generate diffusion noise when it's not already user-specified.")
+        if inpaint_mask is not None:
+            raise NotImplementedError("inpainting is outside the accelerated path (SURVEY.md §8f rank 4)")
+        if reference_image is not None and (0.0 < reference_image_strength < 1.0):
+            raise NotImplementedError("image_to_image needs the VAE encoder (SURVEY.md §8f rank 1), not built yet")
+        context = self._expand_tensor(encoded_text, batch_size)
+        if negative_prompt is None and negative_embedding is None:
+            unconditional_context = np.repeat(self._get_unconditional_context(), batch_size, axis=0)
+        else:
+            if isinstance(negative_prompt, (np.ndarray, torch.Tensor)):
+                unconditional_context = np.asarray(negative_prompt, dtype=np.float32)
+            else:
+                unconditional_context = self.encode_text("" if negative_prompt is None else negative_prompt, negative_embedding)
+            unconditional_context = self._expand_tensor(unconditional_context, batch_size)
+        if diffusion_noise is not None:
+            diffusion_noise = np.squeeze(diffusion_noise)
+            if len(diffusion_noise.shape) == 3:
+                diffusion_noise = np.repeat(np.expand_dims(diffusion_noise, axis=0), batch_size, axis=0)
+        else:
+            diffusion_noise = self._get_initial_diffusion_noise(batch_size, seed)
+        self.scheduler.set_timesteps(num_steps)
+        hint_image = None
+        if control_net_image is not None:
+            if isinstance(control_net_image, np.ndarray):
+                image_array = self.resize(control_net_image, self.img_height, self.img_width)
+            else:
+                from PIL import Image
+
+                image_array = Image.open(control_net_image).convert("RGB").resize((self.img_width, self.img_height))
+            hint_image = np.tile(np.expand_dims(np.array(image_array, dtype=np.float32) / 255.0, axis=0), (batch_size, 1, 1, 1))
+
+        if host_loop:
+            latent = self._host_loop(context, unconditional_context, diffusion_noise, unconditional_guidance_scale,
+                                     guidance_rescale, hint_image, callback)
+            if return_latent:
+                return np.asarray(latent, dtype=np.float32)
+            decoded = self.image_decoder.predict_on_batch(latent)
+            decoded = np.array(((decoded + 1.0) * 0.5), dtype=np.float32)
+            return np.clip(decoded * 255.0, 0, 255).astype("uint8")
+
+        eng = self._engine(batch_size, context.shape[1], unconditional_context.shape[1], num_steps,
+                           float(unconditional_guidance_scale), float(guidance_rescale), hint_image is not None)
+        if eng.cfg and len(eng.passes) == 1:
+            ctxs = {"both": np.concatenate([unconditional_context, context], axis=0)}
+        elif eng.cfg:
+            ctxs = {"uncond": unconditional_context, "cond": context}
+        else:
+            ctxs = {"cond": context}
+        eng.prepare(ctxs, diffusion_noise, self.scheduler, self.scheduler.timesteps, 0, hint_image)
+        eng.run_steps(num_steps, callback)
+        if return_latent:
+            return eng.latent.cpu().numpy()
+        return self.image_decoder.decode_to_uint8(eng.latent).cpu().numpy()
+
+    def _engine(self, B, tc, tu, steps, g, phi, control) -> DenoiseEngine:
+        key = (B, tc, tu, steps, g, phi, control)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = DenoiseEngine(self.diffusion_model, B, tc, tu, steps, g, phi,
+                                control_net=self.control_net if control else None,
+                                hint_net=self.hint_net if control else None, use_graph=self.jit_compile)
+            self._engines = {key: eng}  # one resident engine: its arenas are the big allocations
+        return eng
+
+    def _host_loop(self, context, unconditional_context, latent, g, phi, hint_image, callback):
+        """The reference's own loop over predict_on_batch (stable_diffusion.py:442-479)."""
+        timesteps = self.scheduler.timesteps[::-1]
+        batch_size = latent.shape[0]
+        hint = self.hint_net.predict_on_batch(hint_image) if hint_image is not None else None
+        iteration = 0
+        for _index, timestep in list(enumerate(timesteps))[::-1]:
+            latent_prev = latent
+            t_emb = get_timestep_embedding(timestep, batch_size)
+            if g > 0.0:
+                if hint is not None:
+                    uc = self.control_net.predict_on_batch([latent, t_emb, unconditional_context, hint])
+                    u = self.diffusion_model.predict_on_batch([latent, t_emb, unconditional_context] + list(uc))
+                    cc = self.control_net.predict_on_batch([latent, t_emb, context, hint])
+                    c = self.diffusion_model.predict_on_batch([latent, t_emb, context] + list(cc))
+                else:
+                    u = self.diffusion_model.predict_on_batch([latent, t_emb, unconditional_context])
+                    c = self.diffusion_model.predict_on_batch([latent, t_emb, context])
+                latent = u + g * (c - u)
+                if phi > 0.0:
+                    latent = rescale_noise_cfg(latent, c, guidance_rescale=phi)
+            else:
+                if hint is not None:
+                    cc = self.control_net.predict_on_batch([latent, t_emb, context, hint])
+                    latent = self.diffusion_model.predict_on_batch([latent, t_emb, context] + list(cc))
+                else:
+                    latent = self.diffusion_model.predict_on_batch([latent, t_emb, context])
+            latent = self.scheduler.step(latent, timestep, latent_prev)
+            iteration += 1
+            if callback is not None:
+                callback(iteration)
+        return latent
+
+
+class StableDiffusion(StableDiffusionBase):
+    """Reference ``StableDiffusion`` (stable_diffusion.py:575-725) with HIP-backed models."""
+
+    def __init__(self, img_height=512, img_width=512, jit_compile=False, clip_skip=-1, unet_ckpt=None, text_encoder_ckpt=None,
+                 vae_ckpt=None, lora_path=None, controlnet_path=None, active_tcd=False, device=None):
+        super().__init__(img_height, img_width, jit_compile, active_tcd)
+        self.clip_skip = clip_skip
+        self.unet_ckpt = unet_ckpt
+        self.text_encoder_ckpt = text_encoder_ckpt
+        self.vae_ckpt = vae_ckpt
+        self.controlnet_path = controlnet_path
+        self.lora_path = lora_path
+        self.unet_lora_dict = None
+        self.device = device if device is not None else default_device()
+
+    @property
+    def diffusion_model(self):
+        if self._diffusion_model is None:
+            self._diffusion_model = DiffusionModel(self.img_height, self.img_width, ckpt_path=self.unet_ckpt,
+                                                   apply_control_net=self.controlnet_path is not None,
+                                                   lora_dict=self.unet_lora_dict, device=self.device)
+            if self.jit_compile:
+                self._diffusion_model.compile(jit_compile=True)
+        return self._diffusion_model
+
+    @property
+    def image_decoder(self):
+        if self._image_decoder is None:
+            self._image_decoder = ImageDecoder(ckpt_path=self.vae_ckpt, device=self.device)
+            if self.jit_compile:
+                self._image_decoder.compile(jit_compile=True)
+        return self._image_decoder
+
+    @property
+    def control_net(self):
+        if self._control_net is None:
+            self._control_net = ControlNet(self.img_height, self.img_width, controlnet_path=self.controlnet_path, device=self.device)
+            if self.jit_compile:
+                self._control_net.compile(jit_compile=True)
+        return self._control_net
+
+    @property
+    def hint_net(self):
+        if self._hint_net is None:
+            self._hint_net = HintNet(self.img_height, self.img_width, controlnet_path=self.controlnet_path, device=self.device)
+            if self.jit_compile:
+                self._hint_net.compile(jit_compile=True)
+        return self._hint_net
