@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512x512 images/sec (whole node), SD1.5 25-step txt2img on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one full pass of the hot path over this rank's batch: the 25-step cond+uncond denoise
+loop (50 UNet forwards per image, CFG 7.5, rescale 0.7) + the VAE decode to uint8, on synthetic
+inputs already resident in HBM (random-init SD1.5 weights of the reference's architecture, seeded;
+N(0,1) text contexts and noise).  Multi-GPU = batch sharding: per-GPU work is fixed (weak scaling),
+the text contexts + global noise are broadcast from rank 0 and the images all-gathered inside the
+timed region (RCCL), nothing crosses GPUs inside a step.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline      the dominant kernel (implicit-GEMM conv/dense on MFMA): algorithmic FLOP per launch
+                / its average launch duration measured here with HIP events on the launch stream
+  cpu_baseline  the oracle (fp32 CPU restatement of the reference path; Keras itself is not
+                installable here) timed on this box's host cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+UNET_TFLOP = 0.8033   # per UNet forward, 512x512, ctx 77, per sample
+VAE_TFLOP = 2.5145    # per decode
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--denoise-steps", type=int, default=25)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from minsdtf_amd import dist as mdist
+    from minsdtf_amd import weights as Wt
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+
+    rank, local_rank, world = mdist.env_rank()
+    if world != args.gpus:
+        log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    mdist.init("nccl")
+
+    size, nsteps, b = args.size, args.denoise_steps, args.batch_per_gpu
+    h = size // 8
+    gb = b * world
+    t0 = time.time()
+    sd = StableDiffusion(size, size, jit_compile=not args.no_graph, device=dev)
+    unet_arrays = sd.diffusion_model.load_synthetic(seed=0)
+    vae_arrays = sd.image_decoder.load_synthetic(seed=0)
+    if rank != 0 or args.no_cpu_baseline:
+        unet_arrays = vae_arrays = None
+    log(f"[rank {rank}] weights generated + packed in {time.time() - t0:.1f}s")
+
+    rng = np.random.default_rng(1234)
+    ctx = rng.standard_normal((gb, 77, 768)).astype(np.float32)
+    unc = rng.standard_normal((gb, 77, 768)).astype(np.float32)
+    noise = np.random.default_rng(0).standard_normal((gb, h, h, 4)).astype(np.float32)
+
+    def one_job():
+        """contexts/noise broadcast -> local denoise loop + decode -> all-gather of uint8 images"""
+        def local(c, u, z):
+            eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, False)
+            eng.prepare({"both": np.concatenate([u, c], axis=0)}, z, sd.scheduler, None, 0, None)
+            eng.run_steps(nsteps, None)
+            return sd.image_decoder.decode_to_uint8(eng.latent)
+        sd.scheduler.set_timesteps(nsteps)
+        return mdist.generate_sharded(local, ctx, unc, noise, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        img = one_job()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        img = one_job()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert tuple(img.shape) == (gb, size, size, 3) and img.dtype == torch.uint8
+
+    images = gb * args.steps
+    value = images / elapsed
+    tflop_per_image = 2 * nsteps * UNET_TFLOP * (size / 512) ** 2 + VAE_TFLOP * (size / 512) ** 2
+    out = {
+        "metric": "512x512 images/sec (whole node), SD1.5 25-step txt2img",
+        "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SD1.5 {size}x{size} {nsteps}-step txt2img, CFG 7.5 + rescale 0.7, batch {b}/GPU, "
+                               f"UNet+VAE HIP path, random-init weights", "global_batch": gb,
+                   "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph},
+        "tflops_per_gpu": round(tflop_per_image * b * args.steps / elapsed, 2),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        out["roofline"], extra = kernel_roofline(sd, b, nsteps)
+        out["kernel_breakdown_ms_per_unet_step"] = extra
+    if rank == 0 and world == 1:
+        out["psnr_db_vs_oracle_golden"] = golden_psnr(sd, size, nsteps)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(unet_arrays, vae_arrays, ctx[:1], unc[:1], noise[:1], nsteps)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def kernel_roofline(sd, b, nsteps):
+    """Eager, event-timed pass over one denoise step: per-call durations on the launch stream."""
+    import torch
+
+    from minsdtf_amd import _lib
+
+    eng = sd._engine(b, 77, 77, nsteps, 7.5, 0.7, False)
+    calls = eng.step.calls
+    st = torch.cuda.current_stream()
+    reps = 3
+    per_name = {}
+    for rep in range(reps + 1):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(calls) + 1)]
+        evs[0].record(st)
+        for i, c in enumerate(calls):
+            c(st.cuda_stream)
+            evs[i + 1].record(st)
+        torch.cuda.synchronize()
+        if rep == 0:
+            continue  # warm
+        for i, c in enumerate(calls):
+            fn = c.fn.__name__ if hasattr(c.fn, "__name__") else str(c.fn)
+            ms = evs[i].elapsed_time(evs[i + 1])
+            d = per_name.setdefault(fn, {"ms": 0.0, "n": 0, "flop": 0.0})
+            d["ms"] += ms / reps
+            d["n"] += 1.0 / reps
+            if isinstance(c.keep, _lib.MsdConvGemm):
+                s = c.keep
+                M = s.batch * s.h_out * s.w_out
+                K = s.ksize * s.ksize * (s.c0 + s.c1)
+                d["flop"] += 2.0 * M * s.N * K / reps
+    eng.step_ptr.zero_()
+    g = per_name.get("msd_conv_gemm", {"ms": 1e-9, "n": 1, "flop": 0.0})
+    n = max(g["n"], 1.0)
+    avg_ms = g["ms"] / n
+    flop_per_launch = g["flop"] / n
+    achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
+            "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+            "traffic": None, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
+            "gflop_per_launch": round(flop_per_launch / 1e9, 3)}
+    extra = {k: round(v["ms"], 3) for k, v in sorted(per_name.items(), key=lambda kv: -kv[1]["ms"])}
+    return roof, extra
+
+
+def golden_psnr(sd, size, nsteps):
+    """Final-latent PSNR against the committed fp32-oracle latent for this exact configuration."""
+    path = os.path.join(ROOT, "tests", "golden", f"oracle_latent_{size}_{nsteps}.npz")
+    if not os.path.exists(path):
+        return None
+    from oracle import sd_oracle as O
+
+    g = np.load(path)
+    got = sd.generate_image(g["context"][0], negative_prompt=g["uncond"][0], batch_size=1, num_steps=nsteps,
+                            unconditional_guidance_scale=7.5, diffusion_noise=g["noise"][0], guidance_rescale=0.7,
+                            return_latent=True)
+    return round(O.psnr(got, g["latent"]), 2)
+
+
+def cpu_baseline(unet_arrays, vae_arrays, ctx, unc, noise, nsteps):
+    """Oracle ("port": fp32 CPU restatement of the reference path) on the host cores, bounded
+    sample: ONE denoise step (uncond + cond UNet forward, B=1) + ONE VAE decode; a full image is
+    nsteps such steps + the decode."""
+    import torch
+
+    from minsdtf_amd import weights as Wt
+    from oracle import sd_oracle as O
+
+    Wu = O.named_weights(Wt.table("civitai_model"), unet_arrays)
+    Wv = O.named_weights(Wt.table("decoder"), vae_arrays)
+    te = O.timestep_embedding(960, 1)
+    t0 = time.perf_counter()
+    u = O.unet_forward(Wu, noise, te, unc)
+    c = O.unet_forward(Wu, noise, te, ctx)
+    t_step = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.decoder_forward(Wv, noise * 0.18215)
+    t_dec = time.perf_counter() - t0
+    per_image = nsteps * t_step + t_dec
+    del u, c
+    return {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 of {nsteps} denoise steps (2 UNet forwards, B=1) = {t_step:.2f}s + 1 VAE decode = {t_dec:.2f}s, "
+                      f"extrapolated to {nsteps} steps + decode = {per_image:.1f}s/image; torch fp32 CPU, "
+                      f"os.cpu_count()={os.cpu_count()}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -134,15 +134,20 @@ int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
  * 277-278; layers.py:32,66-68,78-79; image_decoder.py:51-52) and the Concatenate in front of it
  * (reads x0|x1 through two base pointers, never materialised).
  *   x0: bf16 [batch][hw][c0], x1: bf16 [batch][hw][c1] or NULL;  out: bf16 [batch][hw][c0+c1]
- *   stats: fp32 [batch][32][2] scratch, MUST be zero on entry (sum, sum of squares accumulate
- *          with atomics); one slot per call site, cleared by one memset per forward pass.
+ *   stats:    fp32 [batch][32][2] scratch; receives {mean, rstd} per group
+ *   partials: fp32 scratch for per-workgroup partial moments, >= batch * MSD_GN_MAX_CHUNKS * 64
+ *             floats is always enough; summed in a fixed order (no atomics: results are
+ *             bit-reproducible run to run)
  */
+#define MSD_GN_MAX_CHUNKS 1024
 typedef struct MsdGroupNorm {
     const void* x0;
     const void* x1;
     const float* gamma; /* [c0+c1] */
     const float* beta;  /* [c0+c1] */
     float* stats;
+    float* partials;
+    int64_t partials_floats;
     void* out;
     int32_t batch, hw, c0, c1;
     int32_t silu; /* 0/1 */
@@ -162,8 +167,8 @@ int msd_layer_norm(const void* x, const float* gamma, const float* beta, void* o
  * (B,heads,S,T) score tensor never exists in HBM.
  *   q:  bf16 [batch][s][q_ld], head h at columns [h*d, (h+1)*d)
  *   k:  bf16 [batch][t][k_ld]
- *   vt: bf16 [batch][heads*d][vt_ld]  (V transposed: key index contiguous; vt_ld % 8 == 0;
- *       columns >= t must hold finite values, e.g. zeros)
+ *   vt: bf16 [batch][heads*d][vt_ld]  (V transposed: key index contiguous; vt_ld % 8 == 0,
+ *       vt_ld >= t; columns >= t are padding and are ignored)
  *   out: bf16 [batch][s][o_ld]
  *   softmax(scale * q k^T) v, scale applied to the scores (diffusion_model.py:105,123).
  * head_dim in {40, 80, 160}.

@@ -48,6 +48,7 @@ class MsdConvDirect(C.Structure):
 class MsdGroupNorm(C.Structure):
     _fields_ = [
         ("x0", C.c_void_p), ("x1", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("stats", C.c_void_p),
+        ("partials", C.c_void_p), ("partials_floats", C.c_int64),
         ("out", C.c_void_p), ("batch", C.c_int32), ("hw", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
         ("silu", C.c_int32), ("eps", C.c_float),
     ]

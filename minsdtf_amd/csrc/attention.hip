@@ -83,7 +83,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
             const int d = idx >> 3, ch = idx & 7;
             const int key0 = t0 + ch * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (key0 + 8 <= p.vt_ld && key0 < p.t) v = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + key0);
+            if (key0 + 8 <= p.vt_ld && key0 < p.t) {
+                v = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + key0);
+                const int valid = p.t - key0;  // keys >= t are padding of unspecified content: force to 0
+                if (valid < 8) {
+                    uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (2 * j >= valid) u[j] = 0;
+                        else if (2 * j + 1 >= valid) u[j] &= 0xFFFFu;
+                    }
+                }
+            }
             *reinterpret_cast<uint4*>(sV + d * VROW + ch * 16) = v;
         }
         __syncthreads();

@@ -11,7 +11,7 @@
 struct GNArgs {
     const bf16_t* x0; const bf16_t* x1;
     const float* gamma; const float* beta;
-    float* stats; bf16_t* out;
+    float* stats; float* partials; bf16_t* out;
     int batch, hw, c0, c1, C, cv, tpp, pl, ppb, silu;
     float eps;
 };
@@ -77,9 +77,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs p) {
         const int cpg = p.C / 32;
         float a = 0.f, q = 0.f;
         for (int c = t * cpg; c < (t + 1) * cpg; ++c) { a += chan[c * 2]; q += chan[c * 2 + 1]; }
-        atomicAdd(p.stats + ((size_t)b * 32 + t) * 2 + 0, a);
-        atomicAdd(p.stats + ((size_t)b * 32 + t) * 2 + 1, q);
+        // per-workgroup partial moments; summed in a fixed order by gn_finalize_kernel (deterministic)
+        float* dst = p.partials + (((size_t)b * gridDim.x + blockIdx.x) * 32 + t) * 2;
+        dst[0] = a;
+        dst[1] = q;
     }
+}
+
+// one 64-thread workgroup per sample: ordered sum of the partials -> {mean, rstd} per group
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const GNArgs p, int nchunks) {
+    const int b = blockIdx.x, t = threadIdx.x;  // t = group*2 + {0: sum, 1: sum of squares}
+    const float* src = p.partials + (size_t)b * nchunks * 64 + t;
+    float acc = 0.f;
+    for (int c = 0; c < nchunks; ++c) acc += src[(size_t)c * 64];
+    const float other = __shfl_xor(acc, 1);
+    const float sum = (t & 1) ? other : acc, sq = (t & 1) ? acc : other;
+    const float cnt = (float)p.hw * (float)(p.C / 32);
+    const float mean = sum / cnt;
+    const float var = fmaxf(sq / cnt - mean * mean, 0.f);
+    p.stats[(size_t)b * 64 + t] = (t & 1) ? rsqrtf(var + p.eps) : mean;
 }
 
 template <int VPT>
@@ -87,13 +103,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p) {
     __shared__ float s_mean[32], s_rstd[32];
     const int t = threadIdx.x, b = blockIdx.y;
     if (t < 32) {
-        const float cnt = (float)p.hw * (float)(p.C / 32);
-        const float sum = p.stats[((size_t)b * 32 + t) * 2 + 0];
-        const float sq = p.stats[((size_t)b * 32 + t) * 2 + 1];
-        const float mean = sum / cnt;
-        const float var = fmaxf(sq / cnt - mean * mean, 0.f);
-        s_mean[t] = mean;
-        s_rstd[t] = rsqrtf(var + p.eps);
+        s_mean[t] = p.stats[((size_t)b * 32 + t) * 2 + 0];
+        s_rstd[t] = p.stats[((size_t)b * 32 + t) * 2 + 1];
     }
     __syncthreads();
     const int cvi = t % p.tpp, pli = t / p.tpp;
@@ -141,7 +152,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p) {
 
 extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!q || !q->x0 || !q->gamma || !q->beta || !q->stats || !q->out) MSD_FAIL(MSD_E_ARG, "group_norm: null pointer");
+    if (!q || !q->x0 || !q->gamma || !q->beta || !q->stats || !q->partials || !q->out)
+        MSD_FAIL(MSD_E_ARG, "group_norm: null pointer");
     if (q->batch <= 0 || q->hw <= 0 || q->c0 <= 0 || q->c1 < 0 || (q->c1 > 0 && !q->x1))
         MSD_FAIL(MSD_E_ARG, "group_norm: bad dims");
     const int C = q->c0 + q->c1;
@@ -151,7 +163,7 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
         MSD_FAIL(MSD_E_ALIGN, "group_norm: pointers must be 16-byte aligned");
     GNArgs a;
     a.x0 = (const bf16_t*)q->x0; a.x1 = (const bf16_t*)q->x1; a.gamma = q->gamma; a.beta = q->beta;
-    a.stats = q->stats; a.out = (bf16_t*)q->out;
+    a.stats = q->stats; a.partials = q->partials; a.out = (bf16_t*)q->out;
     a.batch = q->batch; a.hw = q->hw; a.c0 = q->c0; a.c1 = q->c1; a.C = C; a.cv = C / 8;
     a.tpp = a.cv < 256 ? a.cv : 256;
     a.pl = 256 / a.tpp;
@@ -166,14 +178,21 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     if (ppb > q->hw) ppb = q->hw;
     a.ppb = ppb;
     const int nchunks = (q->hw + ppb - 1) / ppb;
+    if (q->partials_floats < (long long)q->batch * nchunks * 64)
+        MSD_FAIL(MSD_E_WORKSPACE, "group_norm: partials scratch too small (%lld < %lld floats)",
+                 (long long)q->partials_floats, (long long)q->batch * nchunks * 64);
     dim3 grid(nchunks, q->batch);
     const size_t lds = ((size_t)a.pl * C * 2 + (size_t)C * 2) * sizeof(float);
     if (vpt == 1) {
         hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), lds, stream, a);
         MSD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(64), 0, stream, a, nchunks);
+        MSD_CHECK_LAUNCH();
         hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), lds, stream, a);
+        MSD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(64), 0, stream, a, nchunks);
         MSD_CHECK_LAUNCH();
         hipLaunchKernelGGL(gn_apply_kernel<2>, grid, dim3(256), 0, stream, a);
     }

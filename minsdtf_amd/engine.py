@@ -134,6 +134,7 @@ class Plan:
         self.ws_floats = 0
         self._ws_buf: Optional[Buf] = None
         self._stats_buf: Optional[Buf] = None
+        self._gn_part_buf: Optional[Buf] = None
         self.keep: list = []  # device tensors that must outlive the plan
 
     # -- memory
@@ -166,6 +167,10 @@ class Plan:
     def ws(self):
         return _Lazy(lambda: self._ws_buf.ptr if self._ws_buf is not None else None)
 
+    @property
+    def gn_partials(self):
+        return _Lazy(lambda: self._gn_part_buf.ptr)
+
     def gn_stats_slot(self, batch: int):
         slot = self.gn_slots
         self.gn_slots += 1
@@ -177,13 +182,11 @@ class Plan:
         # scratch that is live across the whole plan goes ABOVE every recycled range
         if self.ws_floats:
             self._ws_buf = self._alloc_tail(self.ws_floats * 4)
-        head: List[ops.Call] = []
         if self.gn_slots:
             self._stats_buf = self._alloc_tail(self.gn_slots * self.gn_batch * 64 * 4)
+            self._gn_part_buf = self._alloc_tail(self.gn_batch * ops.GN_MAX_CHUNKS * 64 * 4)
         self.arena.materialize(self.device, self.high_water)
-        if self.gn_slots:
-            head.append(ops.memset_zero(ptr=self._stats_buf, nbytes=self.gn_slots * self.gn_batch * 64 * 4))
-        self.calls = head + [r() for r in self.recs]
+        self.calls = [r() for r in self.recs]
         self.recs = []
 
     def run(self, stream: int) -> None:
@@ -262,7 +265,7 @@ class Emitter:
         C = x0.C + (x1.C if x1 is not None else 0)
         out = p.act(x0.B, x0.H, x0.W, C)
         p.rec(ops.group_norm, x0=x0.buf, x1=None if x1 is None else x1.buf, c1=0 if x1 is None else x1.C,
-              gamma=self.W[name + ".g"], beta=self.W[name + ".b"], stats=p.gn_stats_slot(x0.B), out=out.buf, batch=x0.B,
+              gamma=self.W[name + ".g"], beta=self.W[name + ".b"], stats=p.gn_stats_slot(x0.B), partials=p.gn_partials, out=out.buf, batch=x0.B,
               hw=x0.H * x0.W, c0=x0.C, silu=silu, eps=EPS, name=name)
         return out
 
@@ -310,12 +313,13 @@ class Emitter:
         # self-attention: fused q|k|v projection, v written transposed for the PV product
         n1 = self.layer_norm(t0, tb + ".norm1")
         q, k = p.act(B, H, Wd, C), p.act(B, H, Wd, C)
-        vt = p.alloc(B * C * S * 2)
-        self.conv(n1, tb + ".attn1.qkv", 3 * C, bias=False, split=(C, C, q.buf, k.buf, vt, S))
+        sp = (S + 7) // 8 * 8  # V^T rows are read in 16-byte chunks
+        vt = p.alloc(B * C * sp * 2)
+        self.conv(n1, tb + ".attn1.qkv", 3 * C, bias=False, split=(C, C, q.buf, k.buf, vt, sp))
         p.free(n1)
         a1 = p.act(B, H, Wd, C)
         p.rec(ops.attention, q=q.buf, k=k.buf, vt=vt, out=a1.buf, batch=B, heads=heads, head_dim=d, s=S, t=S, q_ld=C,
-              k_ld=C, vt_ld=S, o_ld=C, scale=d ** -0.5, name=tb + ".attn1")
+              k_ld=C, vt_ld=sp, o_ld=C, scale=d ** -0.5, name=tb + ".attn1")
         p.free(q, k, vt)
         t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0)
         p.free(a1, t0)

@@ -211,8 +211,9 @@ def test_group_norm(gpu, case):
     if case["silu"]:
         ref = ref * torch.sigmoid(ref)
     out = torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=gpu)
-    stats = torch.zeros(B * 64, dtype=torch.float32, device=gpu)
-    call = ops.group_norm(x0=x0.to(torch.bfloat16).to(gpu), x1=None if x1 is None else x1.to(torch.bfloat16).to(gpu),
+    stats = torch.full((B * 64,), float("nan"), dtype=torch.float32, device=gpu)
+    partials = torch.full((B * ops.GN_MAX_CHUNKS * 64,), float("nan"), dtype=torch.float32, device=gpu)
+    call = ops.group_norm(partials=partials, x0=x0.to(torch.bfloat16).to(gpu), x1=None if x1 is None else x1.to(torch.bfloat16).to(gpu),
                           gamma=gamma.to(gpu), beta=beta.to(gpu), stats=stats, out=out, batch=B, hw=hw, c0=c0, c1=c1,
                           silu=case["silu"])
     run_calls(call)
