@@ -170,6 +170,17 @@ def kernel_roofline(sd, b, nsteps):
                 K = s.ksize * s.ksize * (s.c0 + s.c1)
                 d["flop"] += 2.0 * M * s.N * K / reps
     eng.step_ptr.zero_()
+    dump = os.environ.get("MSD_DUMP_CALLS")
+    if dump:  # per-call table of the last repetition (shape, duration, achieved TFLOP/s)
+        with open(dump, "w") as f:
+            for i, c in enumerate(calls):
+                ms = evs[i].elapsed_time(evs[i + 1])
+                line = f"{i:4d} {c.name:62s} {ms * 1e3:9.1f} us"
+                if isinstance(c.keep, _lib.MsdConvGemm):
+                    s = c.keep
+                    M, K = s.batch * s.h_out * s.w_out, s.ksize * s.ksize * (s.c0 + s.c1)
+                    line += f"  M={M:6d} N={s.N:6d} K={K:6d} splitk={s.splitk:2d} {2.0 * M * s.N * K / (ms * 1e-3) / 1e12:8.1f} TF/s"
+                f.write(line + "\n")
     g = per_name.get("msd_conv_gemm", {"ms": 1e-9, "n": 1, "flop": 0.0})
     n = max(g["n"], 1.0)
     avg_ms = g["ms"] / n

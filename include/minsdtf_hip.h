@@ -41,6 +41,8 @@ int msd_abi_version(void);
 const char* msd_last_error(void);
 /* One-time per-process set-up (raises the dynamic-LDS limits of the kernels). Idempotent. */
 int msd_init(void);
+/* Tuning / A-B switches, e.g. ("conv_impl", 0|1). Returns MSD_E_ARG for an unknown key. */
+int msd_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------
  * msd_conv_gemm — implicit-GEMM convolution / dense layer on MFMA (bf16 in, fp32 accumulate).

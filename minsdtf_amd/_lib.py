@@ -75,6 +75,7 @@ SYMBOLS = {
     "msd_abi_version": (C.c_int, []),
     "msd_last_error": (C.c_char_p, []),
     "msd_init": (C.c_int, []),
+    "msd_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "msd_conv_gemm": (C.c_int, [C.POINTER(MsdConvGemm), C.c_void_p]),
     "msd_conv_direct": (C.c_int, [C.POINTER(MsdConvDirect), C.c_void_p]),
     "msd_group_norm": (C.c_int, [C.POINTER(MsdGroupNorm), C.c_void_p]),

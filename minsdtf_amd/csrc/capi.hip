@@ -22,3 +22,14 @@ extern "C" int msd_init(void) {
     if (rc) return rc;
     return msd_attention_init();
 }
+
+void msd_set_conv_impl(int v);
+/* Tuning / A-B switches (not needed for normal use). Known keys: "conv_impl" (1 = LDS-DMA ring
+ * [default], 0 = first-generation register-staged kernel). */
+extern "C" int msd_set_option(const char* key, int value) {
+    if (key && strcmp(key, "conv_impl") == 0) {
+        msd_set_conv_impl(value);
+        return MSD_OK;
+    }
+    MSD_FAIL(MSD_E_ARG, "set_option: unknown key");
+}

@@ -80,6 +80,75 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const CDArgs p) {
     }
 }
 
+// ---- few-output-channel specialisation (UNet conv_out 320->4, VAE conv_out 128->3) -------------
+// 4 lanes share one output pixel: lane s reads the 16-byte channel vectors cv = s, s+4, ... of each
+// tap (so a wave's loads stay contiguous per pixel), the whole fp32 filter sits in LDS as
+// [tap*c_in + c] -> float4 (c_out padded to 4; every lane of a wave with the same s reads the same
+// address, which LDS broadcasts), and the 4 partial sums are combined with two lane shuffles.
+__global__ __launch_bounds__(256) void conv_pix4_kernel(const CDArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* wl = reinterpret_cast<float4*>(smem_raw);
+    const int nk = p.ksize * p.ksize * p.c_in;
+    for (int i = threadIdx.x; i < nk; i += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wr = p.w + (size_t)i * p.c_out;
+        v.x = wr[0];
+        if (p.c_out > 1) v.y = wr[1];
+        if (p.c_out > 2) v.z = wr[2];
+        if (p.c_out > 3) v.w = wr[3];
+        wl[i] = v;
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 3;
+    const long long pix = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const long long npix = (long long)p.batch * p.h_out * p.w_out;
+    const bool live = pix < npix;
+    const long long pc = live ? pix : npix - 1;  // keep all lanes in the shuffles
+    const int hw = p.h_out * p.w_out;
+    const int b = (int)(pc / hw);
+    const int rem = (int)(pc - (long long)b * hw);
+    const int y = rem / p.w_out, x = rem - y * p.w_out;
+    const int bi = b % p.in_batch_mod;
+    const int ncv = p.c_in >> 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ky = 0; ky < p.ksize; ++ky) {
+        const int iy = y * p.stride + ky - p.pad;
+        if ((unsigned)iy >= (unsigned)p.h_in) continue;
+        for (int kx = 0; kx < p.ksize; ++kx) {
+            const int ix = x * p.stride + kx - p.pad;
+            if ((unsigned)ix >= (unsigned)p.w_in) continue;
+            const bf16_t* ip = reinterpret_cast<const bf16_t*>(p.in) + ((size_t)(bi * p.h_in + iy) * p.w_in + ix) * p.c_in;
+            const float4* wt = wl + (size_t)(ky * p.ksize + kx) * p.c_in;
+            for (int cv = sub; cv < ncv; cv += 4) {
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(ip + cv * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xv = f[e] * p.in_scale;
+                    if (p.act_in) xv = silu_f(xv);
+                    const float4 w4 = wt[cv * 8 + e];
+                    a0 += xv * w4.x; a1 += xv * w4.y; a2 += xv * w4.z; a3 += xv * w4.w;
+                }
+            }
+        }
+    }
+    a0 += __shfl_xor(a0, 1); a1 += __shfl_xor(a1, 1); a2 += __shfl_xor(a2, 1); a3 += __shfl_xor(a3, 1);
+    a0 += __shfl_xor(a0, 2); a1 += __shfl_xor(a1, 2); a2 += __shfl_xor(a2, 2); a3 += __shfl_xor(a3, 2);
+    if (!live || sub >= p.c_out) return;
+    float v = sub == 0 ? a0 : (sub == 1 ? a1 : (sub == 2 ? a2 : a3));  // lane s writes channel s
+    if (p.bias) v += p.bias[sub];
+    if (p.act == MSD_ACT_SILU) v = silu_f(v);
+    const size_t o = (size_t)pix * p.c_out + sub;
+    if (p.residual) v += bf2f(p.residual[o]);
+    if (p.out_dtype == MSD_OUT_F32) reinterpret_cast<float*>(p.out)[o] = v;
+    else if (p.out_dtype == MSD_OUT_BF16) reinterpret_cast<bf16_t*>(p.out)[o] = f2bf(v);
+    else {
+        float u = ((v + 1.0f) * 0.5f) * 255.0f;  // stable_diffusion.py:483-486, truncating cast
+        u = fminf(fmaxf(u, 0.0f), 255.0f);
+        reinterpret_cast<uint8_t*>(p.out)[o] = (uint8_t)u;
+    }
+}
+
 extern "C" int msd_conv_direct(const MsdConvDirect* q, msd_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!q || !q->in || !q->w || !q->out) MSD_FAIL(MSD_E_ARG, "conv_direct: null pointer");
@@ -102,6 +171,16 @@ extern "C" int msd_conv_direct(const MsdConvDirect* q, msd_stream_t stream_) {
     a.in_f32 = q->in_dtype == MSD_OUT_F32; a.out_dtype = q->out_dtype; a.act = q->act; a.act_in = q->act_in ? 1 : 0;
     a.in_scale = q->in_scale;
     const int cg = q->c_out <= 4 ? 4 : 8;
+    {
+        const long long nk = (long long)q->ksize * q->ksize * q->c_in;
+        if (q->c_out <= 4 && !a.in_f32 && (q->c_in % 32) == 0 && nk * 16 <= 64 * 1024 && msd_aligned16(q->in)) {
+            const long long npix = (long long)q->batch * q->h_out * q->w_out;
+            a.ncg = 1; a.total = npix;
+            hipLaunchKernelGGL(conv_pix4_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(256), (size_t)nk * 16, stream, a);
+            MSD_CHECK_LAUNCH();
+            return MSD_OK;
+        }
+    }
     a.ncg = (q->c_out + cg - 1) / cg;
     a.total = (long long)q->batch * q->h_out * q->w_out * a.ncg;
     const unsigned blocks = (unsigned)((a.total + 255) / 256);

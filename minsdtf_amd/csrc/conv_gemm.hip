@@ -3,15 +3,19 @@
 // Replaces PaddedConv2D / Dense / UpSampling2D+conv / Concatenate+conv / GEGLU of the reference
 // (layers.py:17-25, diffusion_model.py:22-153) — see include/minsdtf_hip.h for the contract.
 //
-// Structure (one 256-thread workgroup = 4 waves, one BM x BN output tile):
-//   * K is walked in 64-channel tiles of one filter tap at a time, so the A tile is a gather of BM
+// Structure (one workgroup = one 128 x BN output tile, every wave owns a 64 x 32 sub-tile):
+//   * K is walked in 64-channel tiles of one filter tap at a time, so the A tile is a gather of 128
 //     pixel rows x 128 contiguous bytes (NHWC): 8 lanes fetch one pixel's 128 B -> coalesced;
 //     zero padding, stride 2, nearest x2 upsampling and the channel concat of two tensors are all
 //     address generation in the loader, nothing is materialised in HBM;
-//   * A and W tiles are staged registers -> LDS (double buffered, one barrier per K tile); the LDS
-//     image is [row][8 x 16 B] with the 16-byte chunk index XOR-swizzled by (row>>1)&7, which makes
-//     both the ds_write_b128 (8 lanes = one row) and the MFMA fragment ds_read_b128 (16 rows x one
-//     chunk per 16-lane group) bank-conflict free;
+//   * tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into a ring
+//     of S stages; S-1 tiles are in flight while one is consumed, retired with a COUNTED
+//     s_waitcnt vmcnt(N) + one raw s_barrier per K tile.  (The first version staged through
+//     registers one tile ahead and was bound by the L2 round trip: ~1.3 us per K tile against
+//     ~0.1 us of MFMA work.)  Out-of-image / out-of-range rows read a 128-byte page of zeros;
+//   * the LDS image is [row][8 x 16 B]; LDS-DMA writes are lane-linear, so the bank swizzle
+//     (16-byte chunk index XOR (row>>1)&7) is applied to the per-lane SOURCE address and undone in
+//     the fragment reads: ds_read_b128 of 16 rows x one chunk is conflict-free;
 //   * the MFMA is issued "swapped" (A operand = weights, B operand = activations) so each lane's
 //     accumulator holds 4 CONSECUTIVE output channels of one pixel: the epilogue reads bias /
 //     time-embedding / residual and writes the result with 8- or 16-byte vectors;
@@ -28,6 +32,8 @@ struct CGArgs {
     int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
     int split_mode, ns0, ns1, out1_ld, out2_ld;
 };
+
+__device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows
 
 // ---- epilogue for one group of 4 consecutive output columns of one row -----------------------
 __device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, int step, float v[4]) {
@@ -75,6 +81,216 @@ __device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, 
     }
 }
 
+// Whole-wave epilogue: lane (r = lane&15, g = lane>>4) holds, per (j, i), output channels
+// n..n+3 (n = nbase + 16j + 4g) of pixel m (= mbase + 16i + r).
+template <int MI, int NJ>
+__device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI], int mbase, int nbase, int r, int g) {
+    if (gridDim.y > 1) {
+        float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mbase + i * 16 + r;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nbase + j * 16 + 4 * g;
+                if (n >= p.N) continue;
+                *reinterpret_cast<float4*>(ws + (size_t)m * p.N + n) =
+                    make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+            }
+        }
+        return;
+    }
+    const int step = p.step_ptr ? *p.step_ptr : 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = mbase + i * 16 + r;
+        if (m >= p.M) continue;
+        const int b = m / p.hw_out;
+        if (p.act == MSD_ACT_GEGLU) {
+#pragma unroll
+            for (int j = 0; j < NJ; j += 2) {
+                const int nb = nbase + j * 16;  // multiple of 32: x columns nb+[0,16), gate nb+16+[0,16)
+                const int n = nb + 4 * g;
+                if (n >= p.N) continue;
+                float v[4];
+                float4 bx = make_float4(0, 0, 0, 0), bg = bx;
+                if (p.bias) {
+                    bx = *reinterpret_cast<const float4*>(p.bias + n);
+                    bg = *reinterpret_cast<const float4*>(p.bias + n + 16);
+                }
+                v[0] = geglu_f(acc[j][i][0] + bx.x, acc[j + 1][i][0] + bg.x);
+                v[1] = geglu_f(acc[j][i][1] + bx.y, acc[j + 1][i][1] + bg.y);
+                v[2] = geglu_f(acc[j][i][2] + bx.z, acc[j + 1][i][2] + bg.z);
+                v[3] = geglu_f(acc[j][i][3] + bx.w, acc[j + 1][i][3] + bg.w);
+                const int no = (nb >> 1) + 4 * g;
+                if (p.residual) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.res_ld + no);
+                    v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+                }
+                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nbase + j * 16 + 4 * g;
+                if (n >= p.N) continue;
+                float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+                cg_store4(p, m, b, n, step, v);
+            }
+        }
+    }
+}
+
+// ---- LDS-DMA helpers (compiler-invisible on purpose: see cdna_hip_programming.md §5.7) ---------
+// One wave instruction copies 64 x 16 B from per-lane global addresses to LDS bytes
+// [lds_dst, lds_dst + 1024) in lane order.  M0 carries the LDS base and is restored.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// BN = 128: 8 waves (2 x 4);  BN = 64: 4 waves (2 x 2).  Wave tile is always 64(m) x 32(n).
+template <int BN, int S>
+__global__ __launch_bounds__(BN * 4) void conv_gemm_dma_kernel(const CGArgs p) {
+    constexpr int BM = 128;
+    constexpr int NW = BN / 16;                 // waves per workgroup
+    constexpr int NT = NW * 64;                 // threads
+    constexpr int WGN = BN / 32;                // waves along n
+    constexpr int MI = 4, NJ = 2;
+    constexpr int AR = BM * 8 / NT, BR = BN * 8 / NT;   // 16-byte pieces per thread per tile
+    constexpr int L = AR + BR;                  // DMA instructions per thread per tile
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int RPP = NT / 8;                 // rows covered by one pass of the workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int r = lane & 15, g = lane >> 4;
+    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kt_begin = blockIdx.y * p.nk_per;
+    const int kt_end = min(p.nk, kt_begin + p.nk_per);
+    const int nkt = kt_end - kt_begin;
+
+    // ---- loader coordinates: thread -> (row = lrow + RPP*i, LDS chunk position = tid&7) ----------
+    const int cpos = tid & 7, lrow = tid >> 3;
+    const int Hl = p.upsample ? 2 * p.h_in : p.h_in;
+    const int Wl = p.upsample ? 2 * p.w_in : p.w_in;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page) + cpos * 16;
+    int ab[AR], ay[AR], ax[AR], asrc[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int row = lrow + RPP * i;
+        const int m = m0 + row;
+        asrc[i] = (cpos ^ ((row >> 1) & 7)) * 8;  // swizzle on the SOURCE chunk (LDS-DMA writes linearly)
+        if (m < p.M) {
+            const int b = m / p.hw_out;
+            const int rem = m - b * p.hw_out;
+            const int y = rem / p.w_out;
+            const int x = rem - y * p.w_out;
+            ab[i] = b * p.h_in * p.w_in;
+            ay[i] = y * p.stride - p.pad;
+            ax[i] = x * p.stride - p.pad;
+        } else {
+            ab[i] = 0; ay[i] = -(1 << 20); ax[i] = -(1 << 20);
+        }
+    }
+    const bf16_t* wsrc[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+        const int row = lrow + RPP * i;
+        const int n = n0 + row;
+        wsrc[i] = (n < p.N) ? (p.w + (size_t)n * p.K + (cpos ^ ((row >> 1) & 7)) * 8) : nullptr;
+    }
+    // LDS destination of this wave's pass i: 8 rows x 128 B, lane-linear
+    const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
+
+    auto issue_tile = [&](int kt, int stage) {
+        const int tap = kt / p.nkc;
+        const int c = (kt - tap * p.nkc) * 64;
+        const int ky = tap / p.ksize;
+        const int kx = tap - ky * p.ksize;
+        const bf16_t* src; int csrc, coff;
+        if (c < p.c0) { src = p.a0; csrc = p.c0; coff = c; } else { src = p.a1; csrc = p.c1; coff = c - p.c0; }
+        const uint32_t sbase = lds_wave + (uint32_t)stage * ST_BYTES;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            int iy = ay[i] + ky, ix = ax[i] + kx;
+            const bool ok = ((unsigned)iy < (unsigned)Hl) && ((unsigned)ix < (unsigned)Wl);
+            if (p.upsample) { iy >>= 1; ix >>= 1; }
+            const void* gp = ok ? static_cast<const void*>(src + (size_t)(ab[i] + iy * p.w_in + ix) * csrc + coff + asrc[i])
+                                : static_cast<const void*>(zero);
+            dma16(gp, sbase + (uint32_t)(RPP * i) * 128u);
+        }
+#pragma unroll
+        for (int i = 0; i < BR; ++i) {
+            const void* gp = wsrc[i] ? static_cast<const void*>(wsrc[i] + (size_t)kt * 64) : static_cast<const void*>(zero);
+            dma16(gp, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
+        }
+    };
+
+    f32x4 acc[NJ][MI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < nkt) issue_tile(kt_begin + s, s);
+
+    const int swz = r >> 1;  // (row>>1)&7 for row = 16*q + r
+    int stage = 0;
+    for (int it = 0; it < nkt; ++it) {
+        // retire tile `it`: all but the tiles issued after it may stay in flight
+        const int later = min(nkt, it + S - 1) - (it + 1);
+        if (later >= S - 2) wait_vmcnt<(S - 2) * L>();
+        else if (S > 3 && later == 1) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // tile `it` visible to all waves; stage (it-1)%S free for reuse
+        if (it + S - 1 < nkt) {
+            int st = stage + S - 1;
+            if (st >= S) st -= S;
+            issue_tile(kt_begin + it + S - 1, st);
+        }
+        const char* bA = smem + stage * ST_BYTES + (wm * 64 + r) * 128;
+        const char* bB = smem + stage * ST_BYTES + A_BYTES + (wn * 32 + r) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + g) ^ swz) << 4;
+            bf16x8 af[MI], wf[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (++stage == S) stage = 0;
+    }
+    cg_epilogue<MI, NJ>(p, acc, m0 + wm * 64, n0 + wn * 32, r, g);
+}
+
+// ---- first-generation kernel: register-staged, one tile ahead (kept for A/B runs) --------------
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const CGArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2;      // 2 x 2 waves
@@ -195,64 +411,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CGArgs p) {
         if (more) store_tile(buf ^ 1);
         __syncthreads();
     }
-
-    // ---- epilogue: lane holds, per (j, i), channels n..n+3 (n = ..+4g) of pixel m (= ..+r) ----
-    if (gridDim.y > 1) {
-        float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * WM + i * 16 + r;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * WN + j * 16 + 4 * g;
-                if (n >= p.N) continue;
-                *reinterpret_cast<float4*>(ws + (size_t)m * p.N + n) =
-                    make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-            }
-        }
-        return;
-    }
-    const int step = p.step_ptr ? *p.step_ptr : 0;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * WM + i * 16 + r;
-        if (m >= p.M) continue;
-        const int b = m / p.hw_out;
-        if (p.act == MSD_ACT_GEGLU) {
-#pragma unroll
-            for (int j = 0; j < NJ; j += 2) {
-                const int nb = n0 + wn * WN + j * 16;  // multiple of 32: x columns nb+[0,16), gate nb+16+[0,16)
-                const int n = nb + 4 * g;
-                if (n >= p.N) continue;
-                float v[4];
-                float4 bx = make_float4(0, 0, 0, 0), bg = bx;
-                if (p.bias) {
-                    bx = *reinterpret_cast<const float4*>(p.bias + n);
-                    bg = *reinterpret_cast<const float4*>(p.bias + n + 16);
-                }
-                v[0] = geglu_f(acc[j][i][0] + bx.x, acc[j + 1][i][0] + bg.x);
-                v[1] = geglu_f(acc[j][i][1] + bx.y, acc[j + 1][i][1] + bg.y);
-                v[2] = geglu_f(acc[j][i][2] + bx.z, acc[j + 1][i][2] + bg.z);
-                v[3] = geglu_f(acc[j][i][3] + bx.w, acc[j + 1][i][3] + bg.w);
-                const int no = (nb >> 1) + 4 * g;
-                if (p.residual) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.res_ld + no);
-                    v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
-                }
-                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * WN + j * 16 + 4 * g;
-                if (n >= p.N) continue;
-                float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-                cg_store4(p, m, b, n, step, v);
-            }
-        }
-    }
+    cg_epilogue<MI, NJ>(p, acc, m0 + wm * WM, n0 + wn * WN, r, g);
 }
 
 // split-K: sum the fp32 slabs in slice order, then the same epilogue (plain mode only)
@@ -271,16 +430,28 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, in
     cg_store4(p, m, m / p.hw_out, n, step, v);
 }
 
+constexpr int DMA_STAGES_128 = 3, DMA_STAGES_64 = 3;
+constexpr int dma_lds_bytes(int bn, int s) { return s * (128 + bn) * 128; }
+
 static bool g_cg_attr_done = false;
+static int g_conv_impl = 1;  // 1 = LDS-DMA ring (default), 0 = register-staged first-generation kernel
+void msd_set_conv_impl(int v) { g_conv_impl = v; }
+
 int msd_conv_gemm_init() {
     if (g_cg_attr_done) return MSD_OK;
     hipError_t e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 128>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128);
-    if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_gemm<128,128>): %s", hipGetErrorString(e));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 64>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128);
-    if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_gemm<128,64>): %s", hipGetErrorString(e));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<128, DMA_STAGES_128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds_bytes(128, DMA_STAGES_128));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<64, DMA_STAGES_64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds_bytes(64, DMA_STAGES_64));
+    if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_gemm): %s", hipGetErrorString(e));
     g_cg_attr_done = true;
     return MSD_OK;
 }
@@ -361,10 +532,19 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     const int tiles_m = (a.M + 127) / 128;
     a.tiles_n = (a.N + bn - 1) / bn;
     dim3 grid(tiles_m * a.tiles_n, slices);
-    if (bn == 128)
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 2 * (128 + 128) * 128, stream, a);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 64>), grid, dim3(256), 2 * (128 + 64) * 128, stream, a);
+    if (g_conv_impl == 1) {
+        if (bn == 128)
+            hipLaunchKernelGGL((conv_gemm_dma_kernel<128, DMA_STAGES_128>), grid, dim3(512), dma_lds_bytes(128, DMA_STAGES_128),
+                               stream, a);
+        else
+            hipLaunchKernelGGL((conv_gemm_dma_kernel<64, DMA_STAGES_64>), grid, dim3(256), dma_lds_bytes(64, DMA_STAGES_64), stream,
+                               a);
+    } else {
+        if (bn == 128)
+            hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 2 * (128 + 128) * 128, stream, a);
+        else
+            hipLaunchKernelGGL((conv_gemm_kernel<128, 64>), grid, dim3(256), 2 * (128 + 64) * 128, stream, a);
+    }
     MSD_CHECK_LAUNCH();
     if (slices > 1) {
         const long long quads = (long long)a.M * (a.N / 4);

@@ -85,11 +85,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs p) {
 }
 
 // one 64-thread workgroup per sample: ordered sum of the partials -> {mean, rstd} per group
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const GNArgs p, int nchunks) {
-    const int b = blockIdx.x, t = threadIdx.x;  // t = group*2 + {0: sum, 1: sum of squares}
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const GNArgs p, int nchunks) {
+    // 16 row groups x 64 columns: each thread sums every 16th chunk, then the 16 partial sums are
+    // added in a fixed order -> same bits every run
+    __shared__ float red[16][64];
+    const int b = blockIdx.x, t = threadIdx.x & 63, rg = threadIdx.x >> 6;  // t = group*2 + {0: sum, 1: sumsq}
     const float* src = p.partials + (size_t)b * nchunks * 64 + t;
+    float part = 0.f;
+    for (int c = rg; c < nchunks; c += 16) part += src[(size_t)c * 64];
+    red[rg][t] = part;
+    __syncthreads();
+    if (rg != 0) return;
     float acc = 0.f;
-    for (int c = 0; c < nchunks; ++c) acc += src[(size_t)c * 64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += red[i][t];
     const float other = __shfl_xor(acc, 1);
     const float sum = (t & 1) ? other : acc, sq = (t & 1) ? acc : other;
     const float cnt = (float)p.hw * (float)(p.C / 32);
@@ -186,13 +195,13 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     if (vpt == 1) {
         hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), lds, stream, a);
         MSD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(64), 0, stream, a, nchunks);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(1024), 0, stream, a, nchunks);
         MSD_CHECK_LAUNCH();
         hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), lds, stream, a);
         MSD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(64), 0, stream, a, nchunks);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(1024), 0, stream, a, nchunks);
         MSD_CHECK_LAUNCH();
         hipLaunchKernelGGL(gn_apply_kernel<2>, grid, dim3(256), 0, stream, a);
     }

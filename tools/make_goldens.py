@@ -1,0 +1,220 @@
+"""Capture golden vectors from the importable parts of the reference (run in the build container,
+where /root/reference exists; the outputs under tests/golden/ are data, the reference sources never
+leave this container).
+
+What the reference lets us pin without Keras:
+  G1 scheduler.py (numpy only, imported by path): schedule constants, timestep lists, step() outputs
+  G2 StableDiffusionBase.generate_image (imported with a stub `keras` module, numpy fake models):
+     call order / arguments of the model calls, CFG + rescale + scheduler composition, final-step
+     branch, batch tiling, uint8 conversion
+  G3 _get_timestep_embedding table     G4 rescale_noise_cfg      G7 resize (bilinear)
+  G6 ckpt_loader tables: ordered (key, perm) lists -> counts + SHA-256 digests
+  G5 long_prompt_weighting.parse_prompt_attention doctest cases (host text munging, informative)
+
+    python tools/make_goldens.py
+"""
+import hashlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def install_keras_stub():
+    """Inert `keras` so that `import stable_diffusion` succeeds; nothing numeric is provided."""
+    import torch  # noqa: F401  (must be imported before the stub: torch inspects modules at import)
+
+    class _Inert:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return self
+
+    class _Mod(types.ModuleType):
+        def __getattr__(self, item):
+            if item.startswith("__"):
+                raise AttributeError(item)
+            return _Inert
+
+    names = ["keras", "keras.layers", "keras.utils", "keras.random", "keras.activations", "keras.ops"]
+    mods = {n: _Mod(n) for n in names}
+    for n, m in mods.items():
+        m.__file__ = "<stub>"
+        m.__path__ = []
+        sys.modules[n] = m
+    k = mods["keras"]
+    for sub in ("layers", "utils", "random", "activations", "ops"):
+        setattr(k, sub, mods["keras." + sub])
+    k.Model = _Inert
+    k.Sequential = _Inert
+    mods["keras.layers"].Layer = _Inert
+
+    class Progbar:
+        def __init__(self, *a, **k):
+            pass
+
+        def update(self, *a, **k):
+            pass
+
+    mods["keras.utils"].Progbar = Progbar
+    mods["keras.utils"].get_file = lambda *a, **k: "/nonexistent"
+
+    def _no_rng(*a, **k):
+        raise RuntimeError("keras.random is backend specific: inject diffusion_noise")
+
+    mods["keras.random"].normal = _no_rng
+
+
+def fake_unet(latent, t_emb, context):
+    """Deterministic numpy stand-in for DiffusionModel.predict_on_batch (depends on all 3 inputs)."""
+    latent = np.asarray(latent, dtype=np.float32)
+    c = np.asarray(context, dtype=np.float32).mean(axis=(1, 2))[:, None, None, None]
+    t = np.asarray(t_emb, dtype=np.float32)[:, :8].mean(axis=1)[:, None, None, None]
+    return (0.6 * latent + 0.25 * np.sin(3.0 * latent) + 0.2 * c + 0.1 * t).astype(np.float32)
+
+
+def fake_decoder(latent):
+    latent = np.asarray(latent, dtype=np.float32)
+    up = np.repeat(np.repeat(latent[..., :3], 8, axis=1), 8, axis=2)
+    return np.tanh(up * 0.7).astype(np.float32)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # ---------------------------------------------------------------- G1 scheduler
+    sch_mod = by_path("ref_scheduler", "stable_diffusion/scheduler.py")
+    S = sch_mod.Scheduler(active_tcd=False)
+    g1 = {"alphas_cumprod_idx": np.array([0, 1, 500, 999]), "alphas_cumprod": S.alphas_cumprod[[0, 1, 500, 999]],
+          "signal_rates_full": S.signal_rates, "noise_rates_full": S.noise_rates}
+    for n in (1, 4, 25, 50):
+        S.set_timesteps(n)
+        g1[f"timesteps_{n}"] = np.asarray(S.timesteps)
+    rng = np.random.default_rng(42)
+    for n in (4, 25):
+        S = sch_mod.Scheduler(active_tcd=False)
+        S.set_timesteps(n)
+        lat = rng.standard_normal((1, 8, 8, 4)).astype(np.float32)
+        g1[f"run{n}_latent0"] = lat
+        x = lat
+        outs, eps_all = [], []
+        for t in S.timesteps:
+            eps = rng.standard_normal((1, 8, 8, 4)).astype(np.float32)
+            x = S.step(eps, t, x)
+            outs.append(np.asarray(x, dtype=np.float64))
+            eps_all.append(eps)
+        g1[f"run{n}_eps"] = np.stack(eps_all)
+        g1[f"run{n}_out"] = np.stack(outs)
+    np.savez_compressed(os.path.join(OUT, "g1_scheduler.npz"), **g1)
+
+    # ---------------------------------------------------------------- G6 checkpoint tables
+    ck = by_path("ref_ckpt_loader", "stable_diffusion/ckpt_loader.py")
+    g6 = {}
+    for kind, tab in ck.CKPT_MAPPING.items():
+        h = hashlib.sha256()
+        for key, perm in tab:
+            h.update(repr((key, tuple(perm) if perm is not None else None)).encode())
+        g6[kind] = {"count": len(tab), "sha256": h.hexdigest()}
+    h = hashlib.sha256()
+    for k, v in ck.UNET_KEY_MAPPING.items():
+        h.update(repr((k, v)).encode())
+    g6["UNET_KEY_MAPPING"] = {"count": len(ck.UNET_KEY_MAPPING), "sha256": h.hexdigest()}
+    json.dump(g6, open(os.path.join(OUT, "g6_ckpt_tables.json"), "w"), indent=1, sort_keys=True)
+
+    # ---------------------------------------------------------------- G5 prompt parser
+    lpw = by_path("ref_lpw", "stable_diffusion/long_prompt_weighting.py")
+    cases = ["normal text", "an (important) word", "(unbalanced", "\\(literal\\]", "(unnecessary)(parens)",
+             "a (((house:1.3)) [on] a (hill:0.5), sun, (((sky)))."]
+    json.dump([{"prompt": c, "parsed": lpw.parse_prompt_attention(c)} for c in cases],
+              open(os.path.join(OUT, "g5_prompt_attention.json"), "w"), indent=1)
+
+    # ---------------------------------------------------------------- G2/G3/G4/G7 host loop (stub keras)
+    install_keras_stub()
+    sys.path.insert(0, REF)
+    import stable_diffusion.stable_diffusion as ref_sd
+
+    trace = []
+
+    class FakeModel:
+        def __init__(self, fn, tag):
+            self.fn, self.tag = fn, tag
+
+        def predict_on_batch(self, x):
+            if self.tag == "unet":
+                trace.append(("unet", float(np.asarray(x[1])[0, 0]), float(np.asarray(x[2]).mean())))
+                return self.fn(*x[:3])
+            trace.append(("decoder",))
+            return self.fn(x)
+
+    class RefPipe(ref_sd.StableDiffusionBase):
+        @property
+        def diffusion_model(self):
+            return FakeModel(fake_unet, "unet")
+
+        @property
+        def image_decoder(self):
+            return FakeModel(fake_decoder, "decoder")
+
+    g2 = {}
+    rng = np.random.default_rng(7)
+    ctx = rng.standard_normal((77, 768)).astype(np.float32)
+    unc = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    RefPipe._get_unconditional_context = lambda self: unc
+    g2["context"], g2["uncond"] = ctx, unc
+    runs = {"a": dict(batch_size=1, num_steps=25, unconditional_guidance_scale=7.5, guidance_rescale=0.7),
+            "b": dict(batch_size=2, num_steps=4, unconditional_guidance_scale=5.0, guidance_rescale=0.0),
+            "c": dict(batch_size=1, num_steps=3, unconditional_guidance_scale=0.0, guidance_rescale=0.0)}
+    traces = {}
+    for tag, kw in runs.items():
+        pipe = RefPipe(64, 64)
+        noise = rng.standard_normal((kw["batch_size"], 8, 8, 4)).astype(np.float32)
+        del trace[:]
+        img = pipe.generate_image(ctx, diffusion_noise=noise, **kw)
+        g2[f"{tag}_noise"], g2[f"{tag}_image"] = noise, img
+        traces[tag] = {"kwargs": kw, "calls": list(trace)}
+        # the final latent is not returned by the reference; recover it by re-running its own loop pieces
+    np.savez_compressed(os.path.join(OUT, "g2_host_loop.npz"), **g2)
+    json.dump(traces, open(os.path.join(OUT, "g2_host_loop_trace.json"), "w"), indent=0)
+
+    pipe = RefPipe(64, 64)
+    pipe.scheduler.set_timesteps(25)
+    emb = np.stack([np.asarray(pipe._get_timestep_embedding(int(t), 1))[0] for t in pipe.scheduler.timesteps])
+    g3 = {"timesteps": np.asarray(pipe.scheduler.timesteps), "table": emb, "dtype": np.array(str(emb.dtype)),
+          "batch3": np.asarray(pipe._get_timestep_embedding(960, 3))}
+    np.savez_compressed(os.path.join(OUT, "g3_timestep_embedding.npz"), **g3)
+
+    g4 = {}
+    a = rng.standard_normal((2, 8, 8, 4)).astype(np.float32)
+    b = (a * 0.4 + 0.3 * rng.standard_normal((2, 8, 8, 4))).astype(np.float32)
+    g4["noise_cfg"], g4["noise_text"] = a, b
+    for phi in (0.3, 0.7, 1.0):
+        g4[f"out_{phi}"] = pipe.rescale_noise_cfg(a, b, guidance_rescale=phi)
+    np.savez_compressed(os.path.join(OUT, "g4_rescale.npz"), **g4)
+
+    img = rng.uniform(0, 255, (13, 9, 3)).astype(np.float32)
+    g7 = {"image": img, "resized_16_24": ref_sd.StableDiffusionBase.resize(img, 16, 24),
+          "resized_5_4": ref_sd.StableDiffusionBase.resize(img, 5, 4),
+          "expand_in": ctx[:5, :6], "expand_out": pipe._expand_tensor(ctx[:5, :6], 3),
+          "expand_in_b": ctx[None, :5, :6], "expand_out_b": pipe._expand_tensor(ctx[None, :5, :6], 1)}
+    np.savez_compressed(os.path.join(OUT, "g7_host_utils.npz"), **g7)
+    print("goldens written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        print(f"  {f:36s} {os.path.getsize(os.path.join(OUT, f)):8d} B")
+
+
+if __name__ == "__main__":
+    main()
