@@ -202,9 +202,14 @@ def golden_psnr(sd, size, nsteps):
     from oracle import sd_oracle as O
 
     g = np.load(path)
-    got = sd.generate_image(g["context"][0], negative_prompt=g["uncond"][0], batch_size=1, num_steps=nsteps,
-                            unconditional_guidance_scale=7.5, diffusion_noise=g["noise"][0], guidance_rescale=0.7,
-                            return_latent=True)
+    rng = np.random.default_rng(int(g["context_seed"]))
+    h = size // 8
+    ctx = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    unc = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    noise = np.random.default_rng(int(g["noise_seed"])).standard_normal((1, h, h, 4)).astype(np.float32)
+    got = sd.generate_image(ctx[0], negative_prompt=unc[0], batch_size=1, num_steps=nsteps,
+                            unconditional_guidance_scale=float(g["guidance"]), diffusion_noise=noise[0],
+                            guidance_rescale=float(g["guidance_rescale"]), return_latent=True)
     return round(O.psnr(got, g["latent"]), 2)
 
 

@@ -180,3 +180,47 @@ def test_generate_image_uint8(gpu, unet_pair, decoder_pair):
     assert img.shape == (2, 64, 64, 3) and img.dtype == np.uint8
     img2 = sd.text_to_image(ctx, batch_size=2, num_steps=3, seed=5)
     assert np.mean(np.abs(img.astype(int) - img2.astype(int)) <= 2) > 0.99
+
+
+def test_full_size_latent_vs_oracle_golden(gpu):
+    """BASELINE configuration (512x512, 25 steps, CFG 7.5, rescale 0.7, batch 1) against the fp32
+    oracle's final latent committed in tests/golden/oracle_latent_512_25.npz (generated by
+    tools/make_oracle_latent.py; inputs are regenerated from the recorded seeds).  >= 40 dB on the
+    final latent, and the error curve over the recorded intermediate steps stays above the bar."""
+    import os
+
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+    from oracle import sd_oracle as O
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "oracle_latent_512_25.npz")
+    g = np.load(path)
+    size, steps = int(g["size"]), int(g["steps"])
+    sd = StableDiffusion(size, size, jit_compile=True, device=gpu)
+    sd.diffusion_model.load_synthetic(seed=int(g["weight_seed"]))
+    rng = np.random.default_rng(int(g["context_seed"]))
+    ctx = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    unc = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    noise = np.random.default_rng(int(g["noise_seed"])).standard_normal((1, size // 8, size // 8, 4)).astype(np.float32)
+    sd.unconditional_context = unc[0]
+    snaps = {}
+    eng_box = {}
+
+    def cb(i):
+        if (i - 1) in set(int(s) for s in g["trace_steps"]):
+            snaps[i - 1] = eng_box["eng"].latent.cpu().numpy()
+
+    # install the callback after the engine exists: first call builds it
+    orig_engine = sd._engine
+
+    def _engine(*a):
+        eng_box["eng"] = orig_engine(*a)
+        return eng_box["eng"]
+
+    sd._engine = _engine
+    got = sd.generate_image(ctx[0], batch_size=1, num_steps=steps, unconditional_guidance_scale=float(g["guidance"]),
+                            diffusion_noise=noise[0], guidance_rescale=float(g["guidance_rescale"]), return_latent=True, callback=cb)
+    p = O.psnr(got, g["latent"])
+    curve = {int(s): round(O.psnr(snaps[int(s)], g["trace"][i]), 1) for i, s in enumerate(g["trace_steps"]) if int(s) in snaps}
+    print(f"512x512x25 final-latent PSNR {p:.1f} dB; per-step curve {curve}")
+    assert p >= PSNR_MIN
+    assert all(v >= PSNR_MIN for v in curve.values())
