@@ -41,8 +41,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // 1-D grid, XCD-aware: all query tiles of one (batch, head) run on one XCD so its K / V^T
+    // (655 KB at S=4096, d=40) stay in that XCD's L2 instead of every XCD streaming all heads
+    const int qtiles = (p.s + 127) / 128;
+    const int wi = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = wi / qtiles;
+    const int h = bh % p.heads, b = bh / p.heads;
+    const int q0 = (wi - bh * qtiles) * 128 + wave * 32;
 
     // zero the whole LDS image once: pad columns / pad rows are never written afterwards
     for (int off = tid * 16; off < 64 * KROW + DF * 16 * VROW; off += 256 * 16)
@@ -234,7 +239,7 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     a.batch = q->batch; a.heads = q->heads; a.s = q->s; a.t = q->t;
     a.q_ld = q->q_ld; a.k_ld = q->k_ld; a.vt_ld = q->vt_ld; a.o_ld = q->o_ld;
     a.sl2 = q->scale * 1.4426950408889634f;
-    dim3 grid((q->s + 127) / 128, q->heads, q->batch);
+    dim3 grid(((q->s + 127) / 128) * q->heads * q->batch);
     switch (q->head_dim) {
         case 40: hipLaunchKernelGGL(attention_kernel<40>, grid, dim3(256), attn_lds_bytes<40>(), stream, a); break;
         case 80: hipLaunchKernelGGL(attention_kernel<80>, grid, dim3(256), attn_lds_bytes<80>(), stream, a); break;

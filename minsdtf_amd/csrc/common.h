@@ -52,6 +52,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Bijective XCD-aware remap of a linear workgroup id (cdna_hip_programming.md T1): ids b and b+8
+// share an XCD, so XCD x gets the contiguous work items [start(x), start(x+1)).
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
 // ---- host side ---------------------------------------------------------------------------
 void msd_set_error(const char* fmt, ...);
 #define MSD_FAIL(code, ...)          \

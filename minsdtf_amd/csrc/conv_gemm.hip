@@ -163,15 +163,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// BN = 128: 8 waves (2 x 4);  BN = 64: 4 waves (2 x 2).  Wave tile is always 64(m) x 32(n).
-template <int BN, int S>
-__global__ __launch_bounds__(BN * 4) void conv_gemm_dma_kernel(const CGArgs p) {
-    constexpr int BM = 128;
-    constexpr int NW = BN / 16;                 // waves per workgroup
+// Tile configurations (BM x BN output tile, WGM x WGN waves, each wave (BM/WGM) x (BN/WGN)):
+//   128x128 / 2x4 waves (64x32 per wave)   128x64 / 2x2 (64x32)   64x64 / 2x2 (32x32)
+//   64x128 / 2x2 (32x64)                   256x128 / 4x2 (64x64)
+// Smaller tiles put more workgroups on the chip for the small-M layers of the 16x16 / 8x8 levels;
+// larger tiles move fewer L2->LDS bytes per FLOP (the per-CU LDS-DMA rate is what bounds this
+// kernel).  The host picks per layer shape (measured table, minsdtf_amd/tuning.py).
+template <int BM, int BN, int WGM, int WGN, int S>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGArgs p) {
+    constexpr int NW = WGM * WGN;               // waves per workgroup
     constexpr int NT = NW * 64;                 // threads
-    constexpr int WGN = BN / 32;                // waves along n
-    constexpr int MI = 4, NJ = 2;
+    constexpr int WMT = BM / WGM, WNT = BN / WGN;   // wave tile
+    constexpr int MI = WMT / 16, NJ = WNT / 16;
     constexpr int AR = BM * 8 / NT, BR = BN * 8 / NT;   // 16-byte pieces per thread per tile
+    static_assert(AR >= 1 && BR >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0 && (NJ % 2) == 0, "tile config");
     constexpr int L = AR + BR;                  // DMA instructions per thread per tile
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, ST_BYTES = A_BYTES + B_BYTES;
     constexpr int RPP = NT / 8;                 // rows covered by one pass of the workgroup
@@ -182,7 +187,12 @@ __global__ __launch_bounds__(BN * 4) void conv_gemm_dma_kernel(const CGArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 15, g = lane >> 4;
-    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one),
+    // so give each XCD a CONTIGUOUS run of tiles: neighbouring tiles re-read the same pixel rows
+    // (9 taps, all n-tiles) and then hit that XCD's private 4 MiB L2 instead of the Infinity Cache.
+    // Pure speed: any placement computes the same result.
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kt_begin = blockIdx.y * p.nk_per;
     const int kt_end = min(p.nk, kt_begin + p.nk_per);
@@ -269,8 +279,8 @@ __global__ __launch_bounds__(BN * 4) void conv_gemm_dma_kernel(const CGArgs p) {
             if (st >= S) st -= S;
             issue_tile(kt_begin + it + S - 1, st);
         }
-        const char* bA = smem + stage * ST_BYTES + (wm * 64 + r) * 128;
-        const char* bB = smem + stage * ST_BYTES + A_BYTES + (wn * 32 + r) * 128;
+        const char* bA = smem + stage * ST_BYTES + (wm * WMT + r) * 128;
+        const char* bB = smem + stage * ST_BYTES + A_BYTES + (wn * WNT + r) * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = ((ks * 4 + g) ^ swz) << 4;
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(BN * 4) void conv_gemm_dma_kernel(const CGArgs p) {
         }
         if (++stage == S) stage = 0;
     }
-    cg_epilogue<MI, NJ>(p, acc, m0 + wm * 64, n0 + wn * 32, r, g);
+    cg_epilogue<MI, NJ>(p, acc, m0 + wm * WMT, n0 + wn * WNT, r, g);
 }
 
 // ---- first-generation kernel: register-staged, one tile ahead (kept for A/B runs) --------------
@@ -430,8 +440,20 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, in
     cg_store4(p, m, m / p.hw_out, n, step, v);
 }
 
-constexpr int DMA_STAGES_128 = 3, DMA_STAGES_64 = 3;
-constexpr int dma_lds_bytes(int bn, int s) { return s * (128 + bn) * 128; }
+// ---- tile configurations of the LDS-DMA kernel ------------------------------------------------
+struct TileCfg { int bm, bn, threads, lds; };
+#define MSD_TILE_CFGS(X) \
+    X(0, 128, 128, 2, 4, 3) \
+    X(1, 128, 64, 2, 2, 3)  \
+    X(2, 64, 64, 2, 2, 4)   \
+    X(3, 64, 128, 2, 2, 3)  \
+    X(4, 256, 128, 4, 2, 3)
+static const TileCfg g_cfgs[] = {
+#define X(id, bm, bn, wgm, wgn, st) {bm, bn, wgm * wgn * 64, st * (bm + bn) * 128},
+    MSD_TILE_CFGS(X)
+#undef X
+};
+constexpr int NUM_TILE_CFGS = 5;
 
 static bool g_cg_attr_done = false;
 static int g_conv_impl = 1;  // 1 = LDS-DMA ring (default), 0 = register-staged first-generation kernel
@@ -445,12 +467,12 @@ int msd_conv_gemm_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<128, DMA_STAGES_128>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds_bytes(128, DMA_STAGES_128));
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<64, DMA_STAGES_64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds_bytes(64, DMA_STAGES_64));
+#define X(id, bm, bn, wgm, wgn, st)                                                                          \
+    if (e == hipSuccess)                                                                                     \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<bm, bn, wgm, wgn, st>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, st * (bm + bn) * 128);
+    MSD_TILE_CFGS(X)
+#undef X
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_gemm): %s", hipGetErrorString(e));
     g_cg_attr_done = true;
     return MSD_OK;
@@ -526,19 +548,28 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
             MSD_FAIL(MSD_E_WORKSPACE, "conv_gemm: split-K workspace too small (%lld < %lld floats)",
                      (long long)q->workspace_floats, (long long)slices * a.M * a.N);
     }
-    int bn = q->tile_n;
+    // tile configuration: explicit (tile_m, tile_n) or the size heuristic
+    int bm = q->tile_m, bn = q->tile_n;
     if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
-    if (bn != 64 && bn != 128) MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_n must be 0, 64 or 128");
-    const int tiles_m = (a.M + 127) / 128;
+    if (bm == 0) bm = 128;
+    int cfg = -1;
+    for (int i = 0; i < NUM_TILE_CFGS; ++i)
+        if (g_cfgs[i].bm == bm && g_cfgs[i].bn == bn) cfg = i;
+    if (cfg < 0 || (g_conv_impl != 1 && bm != 128))
+        MSD_FAIL(MSD_E_ARG, "conv_gemm: unsupported tile %dx%d (have 128x128 128x64 64x64 64x128 256x128)", bm, bn);
+    const int tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = (a.N + bn - 1) / bn;
     dim3 grid(tiles_m * a.tiles_n, slices);
     if (g_conv_impl == 1) {
-        if (bn == 128)
-            hipLaunchKernelGGL((conv_gemm_dma_kernel<128, DMA_STAGES_128>), grid, dim3(512), dma_lds_bytes(128, DMA_STAGES_128),
-                               stream, a);
-        else
-            hipLaunchKernelGGL((conv_gemm_dma_kernel<64, DMA_STAGES_64>), grid, dim3(256), dma_lds_bytes(64, DMA_STAGES_64), stream,
-                               a);
+        switch (cfg) {
+#define X(id, bm_, bn_, wgm, wgn, st)                                                                                   \
+    case id:                                                                                                            \
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st>), grid, dim3(wgm * wgn * 64), st * (bm_ + bn_) * 128, \
+                           stream, a);                                                                                  \
+        break;
+            MSD_TILE_CFGS(X)
+#undef X
+        }
     } else {
         if (bn == 128)
             hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 2 * (128 + 128) * 128, stream, a);

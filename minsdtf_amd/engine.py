@@ -21,7 +21,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import ops, packing
+from . import ops, packing, tuning
 from . import weights as wtab
 
 EPS = 1e-5  # every normalisation layer of the reference uses epsilon=1e-5
@@ -212,9 +212,10 @@ def _tile_n(N: int) -> int:
 def pick_splitk(M: int, N: int, nk: int) -> int:
     """Spread small-M layers over the chip: aim at >= ~256 workgroups, >= 4 K-tiles per slice."""
     tiles = ((M + 127) // 128) * ((N + _tile_n(N) - 1) // _tile_n(N))
-    if tiles >= 160 or nk < 8:
+    # every split costs a second launch (slab reduction, ~5 us): only worth it for long K loops
+    if tiles >= 160 or nk < 32:
         return 1
-    s = min((256 + tiles - 1) // tiles, nk // 4, 16)
+    s = min((256 + tiles - 1) // tiles, nk // 8, 16)
     return max(1, s)
 
 
@@ -238,7 +239,8 @@ class Emitter:
         n_out = N // 2 if act == ops.ACT_GEGLU else N
         M = x0.B * ho * wo
         nk = ksize * ksize * (cin // 64)
-        sk = 1 if (split is not None or act == ops.ACT_GEGLU) else pick_splitk(M, N, nk)
+        can_split = not (split is not None or act == ops.ACT_GEGLU)
+        tile_m, tile_n, sk = tuning.lookup(x0.B, x0.H, x0.W, cin, N, ksize, stride, upsample, M, nk, can_split)
         if sk > 1:
             p.ws_floats = max(p.ws_floats, sk * M * N)
         if out is None and split is None:
@@ -250,6 +252,7 @@ class Emitter:
                   bias=self.W[(wkey or name) + ".b"] if bias else None, act=act, out_dtype=out_dtype,
                   residual=None if residual is None else residual.buf, res_ld=None if residual is None else residual.C,
                   workspace=p.ws if sk > 1 else None, workspace_floats=sk * M * N if sk > 1 else 0, splitk=sk,
+                  tile_m=tile_m, tile_n=tile_n,
                   step_ptr=self.step_ptr if rowvec is not None else None, name=name)
         if rowvec is not None:
             kw.update(rowvec=rowvec[0], rv_step_stride=rowvec[1], rv_batch_stride=rowvec[2])

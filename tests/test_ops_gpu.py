@@ -49,6 +49,11 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=8, W=8, c0=256, N=128, ks=3, splitk=4),              # split-K slabs + finalize
     dict(B=1, H=8, W=8, c0=1280, N=1280, ks=3, splitk=9),            # 8x8-level shape
     dict(B=2, H=16, W=16, c0=64, N=128, ks=3, f32out=True, act="silu"),
+    dict(B=2, H=12, W=20, c0=64, N=192, ks=3, tile_m=64, tile_n=64),     # every tile configuration, ragged edges
+    dict(B=2, H=12, W=20, c0=128, N=192, ks=3, tile_m=64, tile_n=128),
+    dict(B=3, H=12, W=20, c0=64, N=192, ks=3, tile_m=256, tile_n=128),
+    dict(B=1, H=8, W=8, c0=256, N=320, ks=3, tile_m=64, tile_n=64, splitk=3),
+    dict(B=2, H=16, W=16, c0=128, c1=64, N=128, ks=3, tile_m=256, tile_n=128, upsample=True),
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing
@@ -87,7 +92,7 @@ def test_conv_gemm(gpu, case):
                          upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N, rv_batch_stride=N,
                          step_ptr=step, residual=resid.to(torch.bfloat16).to(d), act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
                          out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, workspace=ws, workspace_floats=ws.numel(),
-                         splitk=splitk, tile_n=case.get("tile_n", 0))
+                         splitk=splitk, tile_n=case.get("tile_n", 0), tile_m=case.get("tile_m", 0))
     run_calls(call)
     close(out.reshape(B, Ho, Wo, N), ref, what=str(case))
 

@@ -1,0 +1,160 @@
+"""Measure the fastest (tile, split-K) configuration of msd_conv_gemm for every conv / dense shape the
+SD1.5 UNet / ControlNet / VAE decoder plans emit, and write minsdtf_amd/conv_tuning.json.
+
+    python tools/tune_conv.py [--out minsdtf_amd/conv_tuning.json] [--quick]
+
+Shapes are collected by walking the launch plans with a recording hook (no weights needed).  Each
+candidate is timed with HIP events on random bf16 data; weight buffers are rotated through > 256 MiB
+of copies so that small-M (weight streaming) layers are measured from HBM, not from the Infinity
+Cache, as they run in the real pipeline where 1.7 GB of weights stream through every step."""
+import argparse
+import collections
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def collect_shapes(quick=False):
+    from minsdtf_amd import engine, tuning
+    from minsdtf_amd import weights as wtab
+
+    rec = []
+    orig = tuning.lookup
+
+    def hook(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split):
+        rec.append((batch, h_in, w_in, cin, N, ksize, stride, bool(upsample), bool(allow_split)))
+        return tuning.heuristic(M, N, nk, allow_split)
+
+    tuning.lookup = hook
+    engine.tuning.lookup = hook
+    W = collections.defaultdict(lambda: None)
+
+    class _T:  # stands in for device tensors / buffers while walking the topology
+        ptr = 0
+
+        def at(self, off):
+            return self
+
+    def unet(nb, h, T=77):
+        p = engine.Plan("cpu")
+        e = engine.Emitter(p, W)
+        ctx = engine.Act(p.alloc(nb * T * 768 * 2), nb, T, 1, 768)
+        kv = engine.emit_context_kv(e, ctx, engine.UNET_ATTN_LAYERS, p)
+        cols = engine.temb_columns(False)
+        engine.emit_unet(e, _T(), nb, nb, h, h, (_T(), 0, 0, cols), kv, T, _T(), None)
+
+    def controlnet(nb, h, T=77):
+        p = engine.Plan("cpu")
+        e = engine.Emitter(p, W)
+        ctx = engine.Act(p.alloc(nb * T * 768 * 2), nb, T, 1, 768)
+        kv = engine.emit_context_kv(e, ctx, engine.ENCODER_ATTN_LAYERS, p)
+        cols = engine.temb_columns(True)
+        outs = [p.act(nb, h >> l, h >> l, ch) for l, ch in zip((0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 3), wtab.UNET_SKIP_CH + (1280,))]
+        engine.emit_controlnet(e, _T(), nb, nb, h, h, (_T(), 0, 0, cols), kv, T, p.act(nb, h, h, 320), outs)
+
+    def vae(b, h):
+        p = engine.Plan("cpu")
+        e = engine.Emitter(p, W)
+        engine.emit_decoder(e, _T(), b, h, h, _T(), 0)
+
+    unet(2, 64)
+    vae(1, 64)
+    if not quick:
+        for nb in (4, 8):
+            unet(nb, 64)
+        unet(2, 96)
+        unet(1, 64)
+        vae(4, 64)
+        vae(1, 96)
+        controlnet(2, 64)
+    tuning.lookup = orig
+    engine.tuning.lookup = orig
+    uniq = []
+    for r in rec:
+        if r not in uniq:
+            uniq.append(r)
+    return uniq
+
+
+def tune_one(shape, iters=10):
+    from minsdtf_amd import ops, tuning
+
+    batch, h_in, w_in, cin, N, ks, stride, ups, allow_split = shape
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream()
+    pad = 1 if ks == 3 else 0
+    hl, wl = (2 * h_in, 2 * w_in) if ups else (h_in, w_in)
+    ho, wo = (hl + 2 * pad - ks) // stride + 1, (wl + 2 * pad - ks) // stride + 1
+    M, K = batch * ho * wo, ks * ks * cin
+    nk = K // 64
+    x = torch.randn(batch, h_in, w_in, cin, device=dev).to(torch.bfloat16)
+    wbytes = N * K * 2
+    ncopy = max(1, min(16, (300 << 20) // wbytes))
+    ws_ = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(ncopy)]
+    bias = torch.randn(N, device=dev)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    best = None
+    results = []
+    for (bm, bn) in tuning.TILES:
+        if bm == 256 and M < 1024:
+            continue
+        if bn == 128 and N <= 64:
+            continue
+        sks = [1]
+        if allow_split:
+            tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+            sks += [s for s in (2, 3, 4, 6, 8, 12, 16) if s <= nk // 4 and tiles * s <= 2048 and tiles < 512]
+        for sk in sks:
+            wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32) if sk > 1 else None
+            calls = [ops.conv_gemm(a0=x, w=w, out=out, batch=batch, h_in=h_in, w_in=w_in, c0=cin, N=N, ksize=ks, stride=stride,
+                                   upsample=ups, bias=bias, workspace=wsf, workspace_floats=0 if wsf is None else wsf.numel(),
+                                   splitk=sk, tile_m=bm, tile_n=bn) for w in ws_]
+            for c in calls[:2]:
+                c(st.cuda_stream)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for i in range(iters):
+                calls[i % ncopy](st.cuda_stream)
+            e1.record(st)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            results.append((us, bm, bn, sk))
+            if best is None or us < best[0]:
+                best = (us, bm, bn, sk)
+            del wsf
+    return best, sorted(results)[:4], 2.0 * M * N * K
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "minsdtf_amd",
+                                                  "conv_tuning.json"))
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    from minsdtf_amd import _lib, tuning
+
+    shapes = collect_shapes(args.quick)
+    print(f"{len(shapes)} distinct conv/dense shapes", flush=True)
+    lib = _lib.load()
+    lib.msd_init()
+    table = {}
+    t0 = time.time()
+    for s in shapes:
+        best, top, flop = tune_one(s)
+        key = tuning.shape_key(*s)
+        table[key] = [best[1], best[2], best[3], round(best[0], 1)]
+        alt = " ".join(f"{bm}x{bn}/k{sk}:{us:.0f}" for us, bm, bn, sk in top)
+        print(f"{key:44s} -> {best[1]}x{best[2]} splitk {best[3]:2d}  {best[0]:7.1f} us {flop / best[0] / 1e6:7.1f} TF/s   [{alt}]", flush=True)
+    with open(args.out, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
+    print(f"wrote {args.out} ({len(table)} entries) in {time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    main()
