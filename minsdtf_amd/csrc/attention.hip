@@ -27,7 +27,7 @@ struct AArgs {
     float sl2;  // scale * log2(e)
 };
 
-template <int D>
+template <int D, bool PIPE>
 __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     constexpr int DPAD = ((D + 31) / 32) * 32;
     constexpr int KS = DPAD / 32;        // k-steps of QK^T
@@ -35,9 +35,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     constexpr int KROW = DPAD * 2 + 16;  // bytes; odd number of 16-B slots -> conflict-free fragment reads
     constexpr int VROW = 64 * 2 + 16;
     constexpr int DCH = D / 8;           // 16-byte chunks per K row
+    constexpr int BUF_BYTES = 64 * KROW + DF * 16 * VROW;   // one K tile [64][KROW] + one V^T tile [DF*16][VROW]
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                      // [64][KROW]
-    char* sV = smem + 64 * KROW;          // [DF*16][VROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -50,7 +49,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     const int q0 = (wi - bh * qtiles) * 128 + wave * 32;
 
     // zero the whole LDS image once: pad columns / pad rows are never written afterwards
-    for (int off = tid * 16; off < 64 * KROW + DF * 16 * VROW; off += 256 * 16)
+    for (int off = tid * 16; off < (PIPE ? 2 : 1) * BUF_BYTES; off += 256 * 16)
         *reinterpret_cast<uint4*>(smem + off) = make_uint4(0, 0, 0, 0);
 
     bf16x8 qf[2][KS];
@@ -75,34 +74,78 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
     const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
     const int ntiles = (p.t + 63) / 64;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int t0 = tile * 64;
-        __syncthreads();  // previous tile fully consumed (also orders the zero fill on the first pass)
-        for (int idx = tid; idx < 64 * DCH; idx += 256) {
-            const int row = idx / DCH, ch = idx - row * DCH;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (t0 + row < p.t) v = *reinterpret_cast<const uint4*>(kbase + (size_t)(t0 + row) * p.k_ld + ch * 8);
-            *reinterpret_cast<uint4*>(sK + row * KROW + ch * 16) = v;
-        }
-        for (int idx = tid; idx < D * 8; idx += 256) {
-            const int d = idx >> 3, ch = idx & 7;
-            const int key0 = t0 + ch * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (key0 + 8 <= p.vt_ld && key0 < p.t) {
-                v = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + key0);
-                const int valid = p.t - key0;  // keys >= t are padding of unspecified content: force to 0
-                if (valid < 8) {
-                    uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+
+    // K / V^T tile staging: global -> registers (issued one tile ahead when PIPE) -> LDS
+    constexpr int KCH = (64 * DCH + 255) / 256, VCH = (D * 8 + 255) / 256;
+    uint4 rk[KCH], rv[VCH];
+    auto gload = [&](int t0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (2 * j >= valid) u[j] = 0;
-                        else if (2 * j + 1 >= valid) u[j] &= 0xFFFFu;
+        for (int i = 0; i < KCH; ++i) {
+            const int idx = tid + 256 * i;
+            rk[i] = make_uint4(0, 0, 0, 0);
+            if (idx < 64 * DCH) {
+                const int row = idx / DCH, ch = idx - row * DCH;
+                if (t0 + row < p.t) rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)(t0 + row) * p.k_ld + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int idx = tid + 256 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < D * 8) {
+                const int d = idx >> 3, ch = idx & 7;
+                const int key0 = t0 + ch * 8;
+                if (key0 + 8 <= p.vt_ld && key0 < p.t) {
+                    v = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + key0);
+                    const int valid = p.t - key0;  // keys >= t are padding of unspecified content: force to 0
+                    if (valid < 8) {
+                        uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (2 * j >= valid) u[j] = 0;
+                            else if (2 * j + 1 >= valid) u[j] &= 0xFFFFu;
+                        }
                     }
                 }
             }
-            *reinterpret_cast<uint4*>(sV + d * VROW + ch * 16) = v;
+            rv[i] = v;
         }
-        __syncthreads();
+    };
+    auto lstore = [&](char* dK, char* dV) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 64 * DCH) {
+                const int row = idx / DCH, ch = idx - row * DCH;
+                *reinterpret_cast<uint4*>(dK + row * KROW + ch * 16) = rk[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < D * 8) *reinterpret_cast<uint4*>(dV + (idx >> 3) * VROW + (idx & 7) * 16) = rv[i];
+        }
+    };
+
+    if (PIPE) {
+        __syncthreads();  // zero fill done
+        gload(0);
+        lstore(smem, smem + 64 * KROW);
+    }
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int t0 = tile * 64;
+        const int buf = PIPE ? (tile & 1) : 0;
+        char* sK = smem + buf * BUF_BYTES;
+        char* sV = sK + 64 * KROW;
+        if (PIPE) {
+            __syncthreads();  // tile `tile` staged by every wave; buffer buf^1 no longer read by anyone
+            if (tile + 1 < ntiles) gload(t0 + 64);  // next tile's loads fly while this tile is computed
+        } else {
+            __syncthreads();  // previous tile fully consumed (also orders the zero fill on the first pass)
+            gload(t0);
+            lstore(sK, sV);
+            __syncthreads();
+        }
 
         // ---- S^T = K Q^T ------------------------------------------------------------------
         f32x4 sacc[4][2];
@@ -174,6 +217,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                 oacc[df][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[kk][1], oacc[df][1], 0, 0, 0);
             }
         }
+        if (PIPE && tile + 1 < ntiles) {
+            char* nK = smem + (buf ^ 1) * BUF_BYTES;
+            lstore(nK, nK + 64 * KROW);
+        }
     }
 
 #pragma unroll
@@ -200,21 +247,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 }
 
 template <int D>
+static constexpr bool attn_pipe() { return D <= 80; }  // D=160 has no registers left for the prefetch
+template <int D>
 static constexpr int attn_lds_bytes() {
-    return 64 * (((D + 31) / 32) * 32 * 2 + 16) + ((D + 15) / 16) * 16 * (64 * 2 + 16);
+    return (attn_pipe<D>() ? 2 : 1) * (64 * (((D + 31) / 32) * 32 * 2 + 16) + ((D + 15) / 16) * 16 * (64 * 2 + 16));
 }
 
 static bool g_attn_attr_done = false;
 int msd_attention_init() {
     if (g_attn_attr_done) return MSD_OK;
     hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<40>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<40, attn_pipe<40>()>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<40>());
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<80>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<80, attn_pipe<80>()>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<80>());
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<160>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<160, attn_pipe<160>()>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<160>());
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
     g_attn_attr_done = true;
@@ -241,9 +290,9 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     a.sl2 = q->scale * 1.4426950408889634f;
     dim3 grid(((q->s + 127) / 128) * q->heads * q->batch);
     switch (q->head_dim) {
-        case 40: hipLaunchKernelGGL(attention_kernel<40>, grid, dim3(256), attn_lds_bytes<40>(), stream, a); break;
-        case 80: hipLaunchKernelGGL(attention_kernel<80>, grid, dim3(256), attn_lds_bytes<80>(), stream, a); break;
-        case 160: hipLaunchKernelGGL(attention_kernel<160>, grid, dim3(256), attn_lds_bytes<160>(), stream, a); break;
+        case 40: hipLaunchKernelGGL((attention_kernel<40, attn_pipe<40>()>), grid, dim3(256), attn_lds_bytes<40>(), stream, a); break;
+        case 80: hipLaunchKernelGGL((attention_kernel<80, attn_pipe<80>()>), grid, dim3(256), attn_lds_bytes<80>(), stream, a); break;
+        case 160: hipLaunchKernelGGL((attention_kernel<160, attn_pipe<160>()>), grid, dim3(256), attn_lds_bytes<160>(), stream, a); break;
         default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 80, 160)", q->head_dim);
     }
     MSD_CHECK_LAUNCH();

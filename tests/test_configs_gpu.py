@@ -1,0 +1,89 @@
+"""BASELINE.json configurations beyond C2, at sizes the oracle finishes in seconds:
+C5 ControlNet inside the fused device loop (HintNet once, ControlNet + UNet per step, residual adds),
+C4 shape coverage (latent side not a power of two: 96x96 -> here 24x24 = 192x192 image),
+C3 batch > 1 through the fused loop (per-sample independence: a batch equals its samples run alone)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+PSNR_MIN = 40.0
+
+
+@pytest.fixture(scope="module")
+def nets(gpu):
+    from minsdtf_amd import weights as Wt
+    from minsdtf_amd.models import ControlNet, DiffusionModel, HintNet
+    from oracle import sd_oracle as O
+
+    out = {}
+    u = DiffusionModel(64, 64, device=gpu)
+    out["unet"], out["Wu"] = u, O.named_weights(Wt.table("civitai_model"), u.load_synthetic(seed=0, bias_scale=0.05))
+    c = ControlNet(64, 64, device=gpu)
+    out["cn"], out["Wc"] = c, O.named_weights(Wt.table("controlnet"), c.load_synthetic(seed=0, bias_scale=0.05))
+    h = HintNet(64, 64, device=gpu)
+    out["hn"], out["Wh"] = h, O.named_weights(Wt.table("hintnet"), h.load_synthetic(seed=0, bias_scale=0.05))
+    return out
+
+
+def test_controlnet_fused_loop_vs_oracle(gpu, nets):
+    """C5: stable_diffusion.py:427-452 — hint once per image, then per step control_net -> 13 residuals
+    -> diffusion_model, uncond before cond; here all of it on the device, 3 steps, against the oracle."""
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+    from oracle import sd_oracle as O
+
+    sd = StableDiffusion(64, 64, jit_compile=True, device=gpu, controlnet_path="synthetic")
+    sd._diffusion_model, sd._control_net, sd._hint_net = nets["unet"], nets["cn"], nets["hn"]
+    rng = np.random.default_rng(21)
+    ctx = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    unc = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    noise = rng.standard_normal((1, 8, 8, 4)).astype(np.float32)
+    image = rng.integers(0, 256, (64, 64, 3)).astype(np.float32)
+    hint = O.hintnet_forward(nets["Wh"], image[None] / 255.0)
+    ref = O.denoise_loop(lambda l, t, c, ctl: O.unet_forward(nets["Wu"], l, t, c, controls=ctl), ctx, unc, noise, num_steps=3,
+                         guidance=7.5, guidance_rescale=0.7,
+                         controlnet_fn=lambda l, t, c, h: O.controlnet_forward(nets["Wc"], l, t, c, h), hint=hint)
+    sd.unconditional_context = unc[0]
+    got = sd.generate_image(ctx[0], batch_size=1, num_steps=3, unconditional_guidance_scale=7.5, diffusion_noise=noise[0],
+                            guidance_rescale=0.7, control_net_image=image, return_latent=True)
+    p = O.psnr(got, ref)
+    print(f"ControlNet fused loop: final-latent PSNR {p:.1f} dB")
+    assert p >= PSNR_MIN
+    host = sd.generate_image(ctx[0], batch_size=1, num_steps=3, unconditional_guidance_scale=7.5, diffusion_noise=noise[0],
+                             guidance_rescale=0.7, control_net_image=image, return_latent=True, host_loop=True)
+    assert O.psnr(host, ref) >= PSNR_MIN
+
+
+def test_batch_equals_independent_samples(gpu, nets):
+    """C3: a batch of 3 through the fused loop == each sample run alone (what batch sharding relies on)."""
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+    from oracle import sd_oracle as O
+
+    sd = StableDiffusion(64, 64, jit_compile=True, device=gpu)
+    sd._diffusion_model = nets["unet"]
+    rng = np.random.default_rng(22)
+    ctx = rng.standard_normal((3, 77, 768)).astype(np.float32)
+    sd.unconditional_context = rng.standard_normal((77, 768)).astype(np.float32)
+    noise = rng.standard_normal((3, 8, 8, 4)).astype(np.float32)
+    kw = dict(num_steps=3, unconditional_guidance_scale=7.5, guidance_rescale=0.7, return_latent=True)
+    both = sd.generate_image(ctx, batch_size=3, diffusion_noise=noise, **kw)
+    for i in range(3):
+        one = sd.generate_image(ctx[i], batch_size=1, diffusion_noise=noise[i], **kw)
+        assert O.psnr(both[i:i + 1], one) >= 50.0  # same arithmetic up to split-K / tile choices that depend on M
+
+
+def test_non_power_of_two_latent(gpu):
+    """C4-like geometry: 192x192 image -> 24x24 latent (S = 576, 144, 36, 9 tokens per level)."""
+    from minsdtf_amd import weights as Wt
+    from minsdtf_amd.models import DiffusionModel
+    from oracle import sd_oracle as O
+
+    m = DiffusionModel(192, 192, device=gpu)
+    W = O.named_weights(Wt.table("civitai_model"), m.load_synthetic(seed=1, bias_scale=0.05))
+    rng = np.random.default_rng(23)
+    lat = rng.standard_normal((1, 24, 24, 4)).astype(np.float32)
+    ctx = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    te = O.timestep_embedding(980, 1).astype(np.float32)
+    ref = O.unet_forward(W, lat, te, ctx)
+    got = m.predict_on_batch([lat, te, ctx])
+    assert O.psnr(got, ref) >= PSNR_MIN
