@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     constexpr int VROW = 64 * 2 + 16;
     constexpr int DCH = D / 8;           // 16-byte chunks per K row
     constexpr int BUF_BYTES = 64 * KROW + DF * 16 * VROW;   // one K tile [64][KROW] + one V^T tile [DF*16][VROW]
+    constexpr bool ONES_ROW = (D % 16) != 0;  // a spare padding row of the V^T tile carries the softmax denominator
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,6 +53,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     for (int off = tid * 16; off < (PIPE ? 2 : 1) * BUF_BYTES; off += 256 * 16)
         *reinterpret_cast<uint4*>(smem + off) = make_uint4(0, 0, 0, 0);
 
+    if (ONES_ROW) {
+        __syncthreads();
+        if (tid < 16) {  // 64 keys x bf16(1.0) in row D of each V^T buffer (never overwritten: tiles write rows < D)
+#pragma unroll
+            for (int bufi = 0; bufi < (PIPE ? 2 : 1); ++bufi)
+                *reinterpret_cast<uint2*>(smem + bufi * BUF_BYTES + 64 * KROW + D * VROW + tid * 8) = make_uint2(0x3F803F80u, 0x3F803F80u);
+        }
+    }
+
     bf16x8 qf[2][KS];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -66,6 +76,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         }
     }
 
+    // Retire the Q loads HERE: otherwise hipcc's wait for them lands on their first use inside the
+    // tile loop as vmcnt(0), which also drains the K/V prefetch issued just before it every iteration.
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[f][ks]));
+
     f32x4 oacc[DF][2];
 #pragma unroll
     for (int df = 0; df < DF; ++df) { oacc[df][0] = (f32x4){0, 0, 0, 0}; oacc[df][1] = (f32x4){0, 0, 0, 0}; }
@@ -75,62 +92,88 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
     const int ntiles = (p.t + 63) / 64;
 
-    // K / V^T tile staging: global -> registers (issued one tile ahead when PIPE) -> LDS
+    // K / V^T tile staging: global -> registers (issued one tile ahead when PIPE) -> LDS.
+    // Per-thread source pointers / LDS offsets are fixed for the whole kernel; a full tile
+    // (t0 + 64 <= t, i.e. every self-attention tile) takes a branch-free path, only a ragged last
+    // tile (text context) pays for bounds checks and for zeroing the V^T padding columns.
     constexpr int KCH = (64 * DCH + 255) / 256, VCH = (D * 8 + 255) / 256;
     uint4 rk[KCH], rv[VCH];
+    const bf16_t* kptr[KCH];
+    const bf16_t* vptr[VCH];
+    int klds[KCH], vlds[VCH], krow[KCH], vkey[VCH];
+    bool kin[KCH], vin[VCH];
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int idx = tid + 256 * i;
+        kin[i] = idx < 64 * DCH;
+        const int row = kin[i] ? idx / DCH : 0, ch = kin[i] ? idx - row * DCH : 0;
+        krow[i] = row;
+        kptr[i] = kbase + (size_t)row * p.k_ld + ch * 8;
+        klds[i] = row * KROW + ch * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int idx = tid + 256 * i;
+        vin[i] = idx < D * 8;
+        const int d = vin[i] ? idx >> 3 : 0, ch = idx & 7;
+        vkey[i] = ch * 8;
+        vptr[i] = vbase + (size_t)d * p.vt_ld + ch * 8;
+        vlds[i] = d * VROW + ch * 16;
+    }
     auto gload = [&](int t0) {
+        const size_t koff = (size_t)t0 * p.k_ld;
+        if (t0 + 64 <= p.t) {
 #pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int idx = tid + 256 * i;
-            rk[i] = make_uint4(0, 0, 0, 0);
-            if (idx < 64 * DCH) {
-                const int row = idx / DCH, ch = idx - row * DCH;
-                if (t0 + row < p.t) rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)(t0 + row) * p.k_ld + ch * 8);
+            for (int i = 0; i < KCH; ++i)
+                if (kin[i]) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
+#pragma unroll
+            for (int i = 0; i < VCH; ++i)
+                if (vin[i]) rv[i] = *reinterpret_cast<const uint4*>(vptr[i] + t0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                rk[i] = make_uint4(0, 0, 0, 0);
+                if (kin[i] && t0 + krow[i] < p.t) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            const int idx = tid + 256 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < D * 8) {
-                const int d = idx >> 3, ch = idx & 7;
-                const int key0 = t0 + ch * 8;
-                if (key0 + 8 <= p.vt_ld && key0 < p.t) {
-                    v = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + key0);
-                    const int valid = p.t - key0;  // keys >= t are padding of unspecified content: force to 0
-                    if (valid < 8) {
-                        uint32_t* u = reinterpret_cast<uint32_t*>(&v);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (2 * j >= valid) u[j] = 0;
-                            else if (2 * j + 1 >= valid) u[j] &= 0xFFFFu;
-                        }
-                    }
-                }
+            for (int i = 0; i < VCH; ++i) {
+                rv[i] = make_uint4(0, 0, 0, 0);
+                const int key0 = t0 + vkey[i];
+                if (vin[i] && key0 + 8 <= p.vt_ld && key0 < p.t) rv[i] = *reinterpret_cast<const uint4*>(vptr[i] + t0);
             }
-            rv[i] = v;
         }
     };
-    auto lstore = [&](char* dK, char* dV) {
+    auto lstore = [&](char* dK, char* dV, int t0) {
 #pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < 64 * DCH) {
-                const int row = idx / DCH, ch = idx - row * DCH;
-                *reinterpret_cast<uint4*>(dK + row * KROW + ch * 16) = rk[i];
+        for (int i = 0; i < KCH; ++i)
+            if (kin[i]) *reinterpret_cast<uint4*>(dK + klds[i]) = rk[i];
+        if (t0 + 64 <= p.t) {
+#pragma unroll
+            for (int i = 0; i < VCH; ++i)
+                if (vin[i]) *reinterpret_cast<uint4*>(dV + vlds[i]) = rv[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < VCH; ++i) {
+                if (!vin[i]) continue;
+                uint4 v = rv[i];
+                const int valid = p.t - (t0 + vkey[i]);  // keys >= t are padding of unspecified content: force to 0
+                if (valid < 8) {
+                    uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (2 * j >= valid) u[j] = 0;
+                        else if (2 * j + 1 >= valid) u[j] &= 0xFFFFu;
+                    }
+                }
+                *reinterpret_cast<uint4*>(dV + vlds[i]) = v;
             }
-        }
-#pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < D * 8) *reinterpret_cast<uint4*>(dV + (idx >> 3) * VROW + (idx & 7) * 16) = rv[i];
         }
     };
 
     if (PIPE) {
         __syncthreads();  // zero fill done
         gload(0);
-        lstore(smem, smem + 64 * KROW);
+        lstore(smem, smem + 64 * KROW, 0);
     }
     for (int tile = 0; tile < ntiles; ++tile) {
         const int t0 = tile * 64;
@@ -143,7 +186,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         } else {
             __syncthreads();  // previous tile fully consumed (also orders the zero fill on the first pass)
             gload(t0);
-            lstore(sK, sV);
+            lstore(sK, sV, t0);
             __syncthreads();
         }
 
@@ -161,35 +204,39 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
             }
         }
         // ---- online softmax: lane holds keys t0 + kf*16 + 4g + e of query f*16 + r ----------
-        const bool tail = (t0 + 64 > p.t);
-        bf16x8 pb[2][2];
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            float mx = -1e30f;
+        // Scores stay RAW (unscaled) in the accumulators: the running max is tracked on raw scores
+        // (scale > 0, so the max commutes with it) and the scale is folded into the exponent with
+        // one fma:  p = exp2(s*c - m*c),  c = scale*log2(e).  Per score: 1 fma + 1 exp + 1/2 max + 1/2 cvt.
+        if (t0 + 64 > p.t) {  // ragged key tail (text context): only this tile pays for the masking
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float sv = sacc[kf][f][e] * p.sl2;
-                    if (tail && (t0 + kf * 16 + 4 * g + e >= p.t)) sv = -1e30f;
-                    sacc[kf][f][e] = sv;
-                    mx = fmaxf(mx, sv);
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (t0 + kf * 16 + 4 * g + e >= p.t) { sacc[kf][0][e] = -1e30f; sacc[kf][1][e] = -1e30f; }
+        }
+        bf16x8 pb[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float mx = fmaxf(fmaxf(sacc[0][f][0], sacc[0][f][1]), fmaxf(sacc[0][f][2], sacc[0][f][3]));
+#pragma unroll
+            for (int kf = 1; kf < 4; ++kf)
+                mx = fmaxf(fmaxf(fmaxf(mx, sacc[kf][f][0]), fmaxf(sacc[kf][f][1], sacc[kf][f][2])), sacc[kf][f][3]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[f], mx);
-            const float alpha = __builtin_amdgcn_exp2f(mrun[f] - mnew);
+            const float alpha = __builtin_amdgcn_exp2f((mrun[f] - mnew) * p.sl2);
             mrun[f] = mnew;
+            const float nm = -mnew * p.sl2;
             float ls = 0.f;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(sacc[kf][f][e] - mnew);
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kf][f][e], p.sl2, nm));
                     sacc[kf][f][e] = pv;
-                    ls += pv;
+                    if (!ONES_ROW) ls += pv;
                 }
-            lrun[f] = lrun[f] * alpha + ls;
+            if (!ONES_ROW) lrun[f] = lrun[f] * alpha + ls;
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
                 oacc[df][f][0] *= alpha; oacc[df][f][1] *= alpha; oacc[df][f][2] *= alpha; oacc[df][f][3] *= alpha;
@@ -219,15 +266,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         }
         if (PIPE && tile + 1 < ntiles) {
             char* nK = smem + (buf ^ 1) * BUF_BYTES;
-            lstore(nK, nK + 64 * KROW);
+            lstore(nK, nK + 64 * KROW, t0 + 64);
         }
     }
 
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        float lt = lrun[f];
-        lt += __shfl_xor(lt, 16);
-        lt += __shfl_xor(lt, 32);
+        float lt;
+        if (ONES_ROW) {
+            // row D of V^T is all ones, so O^T[D][q] accumulated sum_k P[k][q] on the matrix core
+            // (same alpha rescaling as O, same bf16-rounded P as the numerator); it sits in lane
+            // group g = (D%16)/4, element (D%4) of the last d-block: broadcast it to the other groups
+            lt = __shfl(oacc[DF - 1][f][D % 4], (lane & 15) + 16 * ((D % 16) / 4));
+        } else {
+            lt = lrun[f];
+            lt += __shfl_xor(lt, 16);
+            lt += __shfl_xor(lt, 32);
+        }
         const float inv = 1.0f / lt;
         const int qrow = q0 + f * 16 + r;
         if (qrow < p.s) {

@@ -14,8 +14,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
     return __builtin_bit_cast(bf16_t, b);
 }
+typedef __bf16 msd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float msd_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const msd_f32x2 v = {lo, hi};  // ONE v_cvt_pk_bf16_f32 (the scalar form costs cvt + cvt + or)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, msd_bf16x2));
 }
 __device__ __forceinline__ float bf_lo(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }

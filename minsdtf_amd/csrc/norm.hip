@@ -107,11 +107,31 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const GNArgs p, int n
     p.stats[(size_t)b * 64 + t] = (t & 1) ? rsqrtf(var + p.eps) : mean;
 }
 
-template <int VPT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p) {
+// FUSED: few chunks (<= 64) -> every workgroup reduces the partial moments itself, in the same fixed
+// order, and the separate finalize launch disappears (small tensors are launch-bound, not byte-bound)
+template <int VPT, bool FUSED>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p, int nchunks) {
     __shared__ float s_mean[32], s_rstd[32];
     const int t = threadIdx.x, b = blockIdx.y;
-    if (t < 32) {
+    if (FUSED) {
+        __shared__ float red[4][64];
+        const int col = t & 63, rg = t >> 6;
+        const float* src = p.partials + (size_t)b * nchunks * 64 + col;
+        float part = 0.f;
+        for (int c = rg; c < nchunks; c += 4) part += src[(size_t)c * 64];
+        red[rg][col] = part;
+        __syncthreads();
+        if (t < 64) {
+            const float acc = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+            const float other = __shfl_xor(acc, 1);
+            const float sum = (t & 1) ? other : acc, sq = (t & 1) ? acc : other;
+            const float cnt = (float)p.hw * (float)(p.C / 32);
+            const float mean = sum / cnt;
+            const float var = fmaxf(sq / cnt - mean * mean, 0.f);
+            if (t & 1) s_rstd[t >> 1] = rsqrtf(var + p.eps);
+            else s_mean[t >> 1] = mean;
+        }
+    } else if (t < 32) {
         s_mean[t] = p.stats[((size_t)b * 32 + t) * 2 + 0];
         s_rstd[t] = p.stats[((size_t)b * 32 + t) * 2 + 1];
     }
@@ -178,8 +198,11 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     a.pl = 256 / a.tpp;
     a.silu = q->silu ? 1 : 0; a.eps = q->eps;
     const int vpt = (a.cv + 255) / 256;  // 1 or 2
-    // pixels per block: aim at >= ~1024 workgroups chip-wide but at least 4 passes of pl pixels each
-    long long target_blocks = 1024 / q->batch;
+    // pixels per block.  Small tensors (the whole UNet) are launch-bound: at most 64 chunks per
+    // sample, which the apply kernel reduces itself (2 launches).  Large tensors (VAE at 256^2 /
+    // 512^2) are byte-bound: ~1024 workgroups chip-wide and a separate ordered finalize (3 launches).
+    const bool small = (long long)q->hw * C <= (4ll << 20);
+    long long target_blocks = small ? 64 : 1024 / q->batch;
     if (target_blocks < 1) target_blocks = 1;
     int ppb = (int)((q->hw + target_blocks - 1) / target_blocks);
     const int min_ppb = a.pl * 4;
@@ -187,23 +210,25 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     if (ppb > q->hw) ppb = q->hw;
     a.ppb = ppb;
     const int nchunks = (q->hw + ppb - 1) / ppb;
+    const bool fused = nchunks <= 64;
     if (q->partials_floats < (long long)q->batch * nchunks * 64)
         MSD_FAIL(MSD_E_WORKSPACE, "group_norm: partials scratch too small (%lld < %lld floats)",
                  (long long)q->partials_floats, (long long)q->batch * nchunks * 64);
     dim3 grid(nchunks, q->batch);
     const size_t lds = ((size_t)a.pl * C * 2 + (size_t)C * 2) * sizeof(float);
+    if (vpt == 1) hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), lds, stream, a);
+    MSD_CHECK_LAUNCH();
+    if (!fused) {
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(1024), 0, stream, a, nchunks);
+        MSD_CHECK_LAUNCH();
+    }
     if (vpt == 1) {
-        hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), lds, stream, a);
-        MSD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(1024), 0, stream, a, nchunks);
-        MSD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_apply_kernel<1>, grid, dim3(256), 0, stream, a);
+        if (fused) hipLaunchKernelGGL((gn_apply_kernel<1, true>), grid, dim3(256), 0, stream, a, nchunks);
+        else hipLaunchKernelGGL((gn_apply_kernel<1, false>), grid, dim3(256), 0, stream, a, nchunks);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), lds, stream, a);
-        MSD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(1024), 0, stream, a, nchunks);
-        MSD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_apply_kernel<2>, grid, dim3(256), 0, stream, a);
+        if (fused) hipLaunchKernelGGL((gn_apply_kernel<2, true>), grid, dim3(256), 0, stream, a, nchunks);
+        else hipLaunchKernelGGL((gn_apply_kernel<2, false>), grid, dim3(256), 0, stream, a, nchunks);
     }
     MSD_CHECK_LAUNCH();
     return MSD_OK;

@@ -201,6 +201,7 @@ def test_conv_direct(gpu, case):
     dict(B=1, hw=64, c0=1280, c1=1280, silu=True),     # C=2560: two channel vectors per thread
     dict(B=1, hw=4096, c0=128, silu=False),            # VAE-like: few channels, many pixels
     dict(B=3, hw=100, c0=512, silu=True),
+    dict(B=2, hw=65536, c0=128, silu=True),            # > 64 chunks: separate ordered finalize launch
 ])
 def test_group_norm(gpu, case):
     from minsdtf_amd import ops

@@ -1,0 +1,60 @@
+"""Micro-benchmark of msd_attention on the UNet's attention shapes (random bf16 data, HIP events).
+
+    python tools/attn_bench.py [--only IDX] [--iters N]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+SHAPES = [
+    ("L0 self  S=4096 d=40", 2, 8, 40, 4096, 4096),
+    ("L0 cross S=4096 T=77 d=40", 2, 8, 40, 4096, 77),
+    ("L1 self  S=1024 d=80", 2, 8, 80, 1024, 1024),
+    ("L2 self  S=256 d=160", 2, 8, 160, 256, 256),
+    ("L0 self  B=8", 8, 8, 40, 4096, 4096),
+    ("768^2 self S=9216 d=40", 2, 8, 40, 9216, 9216),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    from minsdtf_amd import _lib, ops
+
+    lib = _lib.load()
+    lib.msd_init()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream()
+    for idx, (name, B, H, d, S, T) in enumerate(SHAPES):
+        if args.only >= 0 and idx != args.only:
+            continue
+        C = H * d
+        Tp = (T + 7) // 8 * 8
+        q = torch.randn(B, S, C, device=dev).to(torch.bfloat16)
+        k = torch.randn(B, T, C, device=dev).to(torch.bfloat16)
+        vt = torch.randn(B, C, Tp, device=dev).to(torch.bfloat16)
+        out = torch.empty(B, S, C, device=dev, dtype=torch.bfloat16)
+        call = ops.attention(q=q, k=k, vt=vt, out=out, batch=B, heads=H, head_dim=d, s=S, t=T, q_ld=C, k_ld=C, vt_ld=Tp, o_ld=C,
+                             scale=d ** -0.5)
+        for _ in range(3):
+            call(st.cuda_stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(args.iters):
+            call(st.cuda_stream)
+        e1.record(st)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        fl = 4.0 * B * H * S * T * d
+        print(f"{idx} {name:28s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s (algorithmic)")
+
+
+if __name__ == "__main__":
+    main()
