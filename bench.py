@@ -126,7 +126,7 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         out["roofline"], extra = kernel_roofline(sd, b, nsteps)
-        out["kernel_breakdown_ms_per_unet_step"] = extra
+        out["eager_ms_per_unet_step_by_entry_point"] = extra  # event-per-launch pass (includes ~1-2 us of event gap per call)
     if rank == 0 and world == 1:
         out["psnr_db_vs_oracle_golden"] = golden_psnr(sd, size, nsteps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -181,16 +181,30 @@ def kernel_roofline(sd, b, nsteps):
                     M, K = s.batch * s.h_out * s.w_out, s.ksize * s.ksize * (s.c0 + s.c1)
                     line += f"  M={M:6d} N={s.N:6d} K={K:6d} splitk={s.splitk:2d} {2.0 * M * s.N * K / (ms * 1e-3) / 1e12:8.1f} TF/s"
                 f.write(line + "\n")
+    extra = {k: round(v["ms"], 3) for k, v in sorted(per_name.items(), key=lambda kv: -kv[1]["ms"])}
+    # The roofline figure uses a second measurement without an event between every launch: all
+    # conv_gemm calls of the step issued back to back (as they run inside the replayed graph, where
+    # no event packets sit between kernels), bracketed by ONE pair of HIP events, 5 repetitions.
+    conv_calls = [c for c in calls if isinstance(c.keep, _lib.MsdConvGemm)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(6):
+        if rep == 1:
+            e0.record(st)
+        for c in conv_calls:
+            c(st.cuda_stream)
+    e1.record(st)
+    torch.cuda.synchronize()
+    eng.step_ptr.zero_()
     g = per_name.get("msd_conv_gemm", {"ms": 1e-9, "n": 1, "flop": 0.0})
     n = max(g["n"], 1.0)
+    g["ms"] = e0.elapsed_time(e1) / 5.0
     avg_ms = g["ms"] / n
     flop_per_launch = g["flop"] / n
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
+    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
             "traffic": None, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
             "gflop_per_launch": round(flop_per_launch / 1e9, 3)}
-    extra = {k: round(v["ms"], 3) for k, v in sorted(per_name.items(), key=lambda kv: -kv[1]["ms"])}
     return roof, extra
 
 

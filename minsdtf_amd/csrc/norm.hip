@@ -34,21 +34,40 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs p) {
         for (int e = 0; e < 8; ++e) { s[v][e] = 0.f; ss[v][e] = 0.f; }
 
     if (active) {
-        for (int px = p_begin + pli; px < p_end; px += p.pl) {
-            const size_t pix = (size_t)b * p.hw + px;
+        // these tensors are small (launch / latency bound): keep U independent 16-byte loads in
+        // flight per thread instead of one load -> accumulate -> next load
+        constexpr int U = 4;
+        const bf16_t* base[VPT];
+        int cstride[VPT];
+        bool on[VPT];
 #pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                const int cv = cvi + v * p.tpp;
-                if (cv < p.cv) {
-                    const int c = cv * 8;
-                    const bf16_t* src = (c < p.c0) ? (p.x0 + pix * p.c0 + c) : (p.x1 + pix * p.c1 + (c - p.c0));
-                    const uint4 raw = *reinterpret_cast<const uint4*>(src);
+        for (int v = 0; v < VPT; ++v) {
+            const int cv = cvi + v * p.tpp;
+            on[v] = cv < p.cv;
+            const int c = cv * 8;
+            const bool first = c < p.c0;
+            cstride[v] = first ? p.c0 : p.c1;
+            base[v] = (first ? p.x0 + c : p.x1 + (c - p.c0)) + (size_t)b * p.hw * cstride[v];
+        }
+        for (int px = p_begin + pli; px < p_end; px += U * p.pl) {
+            uint4 raw[U][VPT];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    const int q = px + u * p.pl;
+                    raw[u][v] = (on[v] && q < p_end) ? *reinterpret_cast<const uint4*>(base[v] + (size_t)q * cstride[v])
+                                                     : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
                     float f[8];
-                    unpack8(raw, f);
+                    unpack8(raw[u][v], f);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { s[v][e] += f[e]; ss[v][e] += f[e] * f[e]; }
                 }
-            }
         }
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
@@ -112,9 +131,47 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const GNArgs p, int n
 template <int VPT, bool FUSED>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p, int nchunks) {
     __shared__ float s_mean[32], s_rstd[32];
+    __shared__ float red[4][64];
+    constexpr int U = 4;  // pixels in flight per thread
     const int t = threadIdx.x, b = blockIdx.y;
+    const int cvi = t % p.tpp, pli = t / p.tpp;
+    const bool active = pli < p.pl;
+    const int p_begin = blockIdx.x * p.ppb;
+    const int p_end = min(p.hw, p_begin + p.ppb);
+
+    // (1) everything that does not depend on the statistics is issued FIRST, so its latency runs
+    //     under the prologue: the first U pixel vectors, gamma and beta
+    const bf16_t* base[VPT];
+    int cstride[VPT];
+    bool on[VPT];
+    float4 g0[VPT], g1[VPT], b0[VPT], b1[VPT];
+    uint4 raw[U][VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int cv = cvi + v * p.tpp;
+        on[v] = active && cv < p.cv;
+        const int c = on[v] ? cv * 8 : 0;
+        const bool first = c < p.c0;
+        cstride[v] = first ? p.c0 : p.c1;
+        base[v] = (first ? p.x0 + c : p.x1 + (c - p.c0)) + (size_t)b * p.hw * cstride[v];
+        g0[v] = *reinterpret_cast<const float4*>(p.gamma + c);
+        g1[v] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+        b0[v] = *reinterpret_cast<const float4*>(p.beta + c);
+        b1[v] = *reinterpret_cast<const float4*>(p.beta + c + 4);
+    }
+    auto load_batch = [&](int px) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                const int q = px + u * p.pl;
+                if (on[v] && q < p_end) raw[u][v] = *reinterpret_cast<const uint4*>(base[v] + (size_t)q * cstride[v]);
+            }
+    };
+    load_batch(p_begin + pli);
+
+    // (2) statistics: reduce the per-workgroup partial moments in a fixed order (FUSED) or read them
     if (FUSED) {
-        __shared__ float red[4][64];
         const int col = t & 63, rg = t >> 6;
         const float* src = p.partials + (size_t)b * nchunks * 64 + col;
         float part = 0.f;
@@ -136,46 +193,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p, int nchun
         s_rstd[t] = p.stats[((size_t)b * 32 + t) * 2 + 1];
     }
     __syncthreads();
-    const int cvi = t % p.tpp, pli = t / p.tpp;
-    if (pli >= p.pl) return;
+    if (!active) return;
+
+    // (3) per-channel scale / shift
     const int cpg = p.C / 32;
     float ca[VPT][8], cb[VPT][8];
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-        const int cv = cvi + v * p.tpp;
+        const int c0 = (cvi + v * p.tpp) * 8;
+        const float gm[8] = {g0[v].x, g0[v].y, g0[v].z, g0[v].w, g1[v].x, g1[v].y, g1[v].z, g1[v].w};
+        const float bt[8] = {b0[v].x, b0[v].y, b0[v].z, b0[v].w, b1[v].x, b1[v].y, b1[v].z, b1[v].w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            ca[v][e] = 0.f; cb[v][e] = 0.f;
-            if (cv < p.cv) {
-                const int c = cv * 8 + e;
-                const int g = c / cpg;
-                const float a = s_rstd[g] * p.gamma[c];
-                ca[v][e] = a;
-                cb[v][e] = p.beta[c] - s_mean[g] * a;
-            }
+            const int g = on[v] ? (c0 + e) / cpg : 0;
+            const float a = s_rstd[g] * gm[e];
+            ca[v][e] = a;
+            cb[v][e] = bt[e] - s_mean[g] * a;
         }
     }
-    const int p_begin = blockIdx.x * p.ppb;
-    const int p_end = min(p.hw, p_begin + p.ppb);
-    for (int px = p_begin + pli; px < p_end; px += p.pl) {
-        const size_t pix = (size_t)b * p.hw + px;
+    // (4) normalise (+ SiLU) and store, U pixels per trip
+    for (int px = p_begin + pli; px < p_end; px += U * p.pl) {
+        if (px != p_begin + pli) load_batch(px);
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int cv = cvi + v * p.tpp;
-            if (cv < p.cv) {
-                const int c = cv * 8;
-                const bf16_t* src = (c < p.c0) ? (p.x0 + pix * p.c0 + c) : (p.x1 + pix * p.c1 + (c - p.c0));
-                const uint4 raw = *reinterpret_cast<const uint4*>(src);
-                float f[8];
-                unpack8(raw, f);
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float y = f[e] * ca[v][e] + cb[v][e];
-                    f[e] = p.silu ? silu_f(y) : y;
+            for (int v = 0; v < VPT; ++v) {
+                const int q = px + u * p.pl;
+                if (on[v] && q < p_end) {
+                    float f[8];
+                    unpack8(raw[u][v], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float y = f[e] * ca[v][e] + cb[v][e];
+                        f[e] = p.silu ? silu_f(y) : y;
+                    }
+                    *reinterpret_cast<uint4*>(p.out + ((size_t)b * p.hw + q) * p.C + (cvi + v * p.tpp) * 8) = pack8(f);
                 }
-                *reinterpret_cast<uint4*>(p.out + pix * p.C + c) = pack8(f);
             }
-        }
     }
 }
 
