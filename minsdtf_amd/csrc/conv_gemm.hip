@@ -21,147 +21,7 @@
 //     time-embedding / residual and writes the result with 8- or 16-byte vectors;
 //   * small-M layers (8x8 and 16x16 levels at batch 1) are split over K into fp32 partial slabs
 //     reduced by a second tiny kernel, deterministically (no atomics).
-#include "common.h"
-
-struct CGArgs {
-    const bf16_t* a0; const bf16_t* a1; const bf16_t* w;
-    const float* bias; const float* rowvec; const int32_t* step_ptr;
-    const bf16_t* residual; void* out; bf16_t* out1; bf16_t* out2; float* ws;
-    int batch, h_in, w_in, c0, c1, h_out, w_out, ksize, stride, pad, upsample;
-    int M, N, K, hw_out, nkc, nk, nk_per, tiles_n;
-    int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
-    int split_mode, ns0, ns1, out1_ld, out2_ld;
-};
-
-__device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows
-
-// ---- epilogue for one group of 4 consecutive output columns of one row -----------------------
-__device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, int step, float v[4]) {
-    if (p.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-    }
-    if (p.rowvec) {
-        const float4 rv = *reinterpret_cast<const float4*>(
-            p.rowvec + (size_t)step * p.rv_step_stride + (size_t)b * p.rv_batch_stride + n);
-        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-    }
-    if (p.act == MSD_ACT_SILU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-    }
-    if (p.split_mode == 0) {
-        if (p.residual) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.res_ld + n);
-            v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
-        }
-        if (p.out_f32) {
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n) =
-                make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
-        }
-    } else {
-        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-        if (n < p.ns0) {
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
-        } else if (n < p.ns0 + p.ns1) {
-            *reinterpret_cast<uint2*>(p.out1 + (size_t)m * p.out1_ld + (n - p.ns0)) = o;
-        } else {
-            const int nv = p.N - p.ns0 - p.ns1;
-            const int nn = n - p.ns0 - p.ns1;
-            const int s = m - b * p.hw_out;
-            bf16_t* dst = p.out2 + ((size_t)b * nv + nn) * p.out2_ld + s;
-            dst[0] = (bf16_t)(o.x & 0xFFFF);
-            dst[(size_t)p.out2_ld] = (bf16_t)(o.x >> 16);
-            dst[(size_t)2 * p.out2_ld] = (bf16_t)(o.y & 0xFFFF);
-            dst[(size_t)3 * p.out2_ld] = (bf16_t)(o.y >> 16);
-        }
-    }
-}
-
-// Whole-wave epilogue: lane (r = lane&15, g = lane>>4) holds, per (j, i), output channels
-// n..n+3 (n = nbase + 16j + 4g) of pixel m (= mbase + 16i + r).
-template <int MI, int NJ>
-__device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI], int mbase, int nbase, int r, int g) {
-    if (gridDim.y > 1) {
-        float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = mbase + i * 16 + r;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nbase + j * 16 + 4 * g;
-                if (n >= p.N) continue;
-                *reinterpret_cast<float4*>(ws + (size_t)m * p.N + n) =
-                    make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-            }
-        }
-        return;
-    }
-    const int step = p.step_ptr ? *p.step_ptr : 0;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = mbase + i * 16 + r;
-        if (m >= p.M) continue;
-        const int b = m / p.hw_out;
-        if (p.act == MSD_ACT_GEGLU) {
-#pragma unroll
-            for (int j = 0; j < NJ; j += 2) {
-                const int nb = nbase + j * 16;  // multiple of 32: x columns nb+[0,16), gate nb+16+[0,16)
-                const int n = nb + 4 * g;
-                if (n >= p.N) continue;
-                float v[4];
-                float4 bx = make_float4(0, 0, 0, 0), bg = bx;
-                if (p.bias) {
-                    bx = *reinterpret_cast<const float4*>(p.bias + n);
-                    bg = *reinterpret_cast<const float4*>(p.bias + n + 16);
-                }
-                v[0] = geglu_f(acc[j][i][0] + bx.x, acc[j + 1][i][0] + bg.x);
-                v[1] = geglu_f(acc[j][i][1] + bx.y, acc[j + 1][i][1] + bg.y);
-                v[2] = geglu_f(acc[j][i][2] + bx.z, acc[j + 1][i][2] + bg.z);
-                v[3] = geglu_f(acc[j][i][3] + bx.w, acc[j + 1][i][3] + bg.w);
-                const int no = (nb >> 1) + 4 * g;
-                if (p.residual) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.res_ld + no);
-                    v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
-                }
-                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nbase + j * 16 + 4 * g;
-                if (n >= p.N) continue;
-                float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-                cg_store4(p, m, b, n, step, v);
-            }
-        }
-    }
-}
-
-// ---- LDS-DMA helpers (compiler-invisible on purpose: see cdna_hip_programming.md §5.7) ---------
-// One wave instruction copies 64 x 16 B from per-lane global addresses to LDS bytes
-// [lds_dst, lds_dst + 1024) in lane order.  M0 carries the LDS base and is restored.
-__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+#include "conv_common.h"
 
 // Tile configurations (BM x BN output tile, WGM x WGN waves, each wave (BM/WGM) x (BN/WGN)):
 //   128x128 / 2x4 waves (64x32 per wave)   128x64 / 2x2 (64x32)   64x64 / 2x2 (32x32)
@@ -297,7 +157,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         }
         if (++stage == S) stage = 0;
     }
-    cg_epilogue<MI, NJ>(p, acc, m0 + wm * WMT, n0 + wn * WNT, r, g);
+    int mrow[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * WMT + i * 16;
+    cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WNT, r, g);
 }
 
 // ---- first-generation kernel: register-staged, one tile ahead (kept for A/B runs) --------------
@@ -421,7 +284,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const CGArgs p) {
         if (more) store_tile(buf ^ 1);
         __syncthreads();
     }
-    cg_epilogue<MI, NJ>(p, acc, m0 + wm * WM, n0 + wn * WN, r, g);
+    int mrow[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * WM + i * 16;
+    cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WN, r, g);
 }
 
 // split-K: sum the fp32 slabs in slice order, then the same epilogue (plain mode only)
@@ -454,6 +320,8 @@ static const TileCfg g_cfgs[] = {
 #undef X
 };
 constexpr int NUM_TILE_CFGS = 5;
+
+int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int slices, hipStream_t stream);
 
 static bool g_cg_attr_done = false;
 static int g_conv_impl = 1;  // 1 = LDS-DMA ring (default), 0 = register-staged first-generation kernel
@@ -539,9 +407,22 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.split_mode = q->split_mode; a.ns0 = q->ns0; a.ns1 = q->ns1; a.out1_ld = q->out1_ld; a.out2_ld = q->out2_ld;
 
     int splitk = q->splitk < 1 ? 1 : q->splitk;
-    if (splitk > a.nk) splitk = a.nk;
-    a.nk_per = (a.nk + splitk - 1) / splitk;
-    const int slices = (a.nk + a.nk_per - 1) / a.nk_per;
+    // halo variant (tile_m = 1000 + pixels per tile: 1128 = 8x16, 1256 = 16x16): spatially blocked 3x3
+    int halo_th = 0;
+    if (q->tile_m >= 1000) {
+        const int th = (q->tile_m - 1000) / 16;
+        const bool ok = g_conv_impl == 1 && q->ksize == 3 && q->stride == 1 && !q->upsample && (q->w_in % 16) == 0 &&
+                        (th == 8 || th == 16) && (q->h_in % th) == 0;
+        if (ok) halo_th = th;
+    }
+    if (halo_th) {  // split-K is over 64-channel chunks (each = 9 K steps)
+        if (splitk > a.nkc) splitk = a.nkc;
+        a.nk_per = (a.nkc + splitk - 1) / splitk;
+    } else {
+        if (splitk > a.nk) splitk = a.nk;
+        a.nk_per = (a.nk + splitk - 1) / splitk;
+    }
+    const int slices = halo_th ? (a.nkc + a.nk_per - 1) / a.nk_per : (a.nk + a.nk_per - 1) / a.nk_per;
     if (slices > 1) {
         if (q->split_mode || q->act == MSD_ACT_GEGLU) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: split-K needs plain mode");
         if (!q->workspace || q->workspace_floats < (long long)slices * a.M * a.N)
@@ -551,7 +432,20 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     // tile configuration: explicit (tile_m, tile_n) or the size heuristic
     int bm = q->tile_m, bn = q->tile_n;
     if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
-    if (bm == 0) bm = 128;
+    if (bm == 0 || bm >= 1000) bm = 128;   // a halo request that is not eligible falls back to 128-row tiles
+    if (halo_th) {
+        if (halo_th == 16) bn = 128;
+        a.tiles_n = (a.N + bn - 1) / bn;
+        rc = msd_conv_halo_launch(a, halo_th, bn, slices, stream);
+        if (rc) return rc;
+        MSD_CHECK_LAUNCH();
+        if (slices > 1) {
+            const long long quads = (long long)a.M * (a.N / 4);
+            hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices);
+            MSD_CHECK_LAUNCH();
+        }
+        return MSD_OK;
+    }
     int cfg = -1;
     for (int i = 0; i < NUM_TILE_CFGS; ++i)
         if (g_cfgs[i].bm == bm && g_cfgs[i].bn == bn) cfg = i;

@@ -54,6 +54,12 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=3, H=12, W=20, c0=64, N=192, ks=3, tile_m=256, tile_n=128),
     dict(B=1, H=8, W=8, c0=256, N=320, ks=3, tile_m=64, tile_n=64, splitk=3),
     dict(B=2, H=16, W=16, c0=128, c1=64, N=128, ks=3, tile_m=256, tile_n=128, upsample=True),
+    dict(B=2, H=16, W=16, c0=64, N=128, ks=3, tile_m=1128, tile_n=64),               # halo-tile 3x3 kernel, 8x16 tiles
+    dict(B=2, H=16, W=32, c0=128, c1=64, N=192, ks=3, tile_m=1128, tile_n=128),      # halo + concat + ragged N
+    dict(B=1, H=32, W=16, c0=128, N=320, ks=3, tile_m=1256, tile_n=128),             # halo 16x16 tiles
+    dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, splitk=2),    # halo + split over chunks
+    dict(B=3, H=16, W=48, c0=320, N=320, ks=3, tile_m=1256, tile_n=128, splitk=3),
+    dict(B=2, H=12, W=20, c0=64, N=64, ks=3, tile_m=1128, tile_n=64),                # not tileable -> generic fallback
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing

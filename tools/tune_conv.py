@@ -100,15 +100,23 @@ def tune_one(shape, iters=10):
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     best = None
     results = []
-    for (bm, bn) in tuning.TILES:
+    cands = list(tuning.TILES)
+    if ks == 3 and stride == 1 and not ups and w_in % 16 == 0:  # halo-tile kernel (tile_m = 1000 + pixels per tile)
+        if h_in % 8 == 0:
+            cands += [(1128, 64), (1128, 128)]
+        if h_in % 16 == 0:
+            cands += [(1256, 128)]
+    for (bm, bn) in cands:
         if bm == 256 and M < 1024:
             continue
         if bn == 128 and N <= 64:
             continue
         sks = [1]
         if allow_split:
-            tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-            sks += [s for s in (2, 3, 4, 6, 8, 12, 16) if s <= nk // 4 and tiles * s <= 2048 and tiles < 512]
+            bme = bm - 1000 if bm >= 1000 else bm
+            tiles = ((M + bme - 1) // bme) * ((N + bn - 1) // bn)
+            kmax = (cin // 64) if bm >= 1000 else nk // 4   # the halo kernel splits over 64-channel chunks
+            sks += [s for s in (2, 3, 4, 6, 8, 12, 16) if s <= kmax and tiles * s <= 2048 and tiles < 512]
         for sk in sks:
             wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32) if sk > 1 else None
             calls = [ops.conv_gemm(a0=x, w=w, out=out, batch=batch, h_in=h_in, w_in=w_in, c0=cin, N=N, ksize=ks, stride=stride,
