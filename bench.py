@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--controlnet", action="store_true", help="BASELINE config 5: ControlNet residuals every step")
     args = ap.parse_args()
 
     import torch
@@ -72,6 +73,11 @@ def main():
     sd = StableDiffusion(size, size, jit_compile=not args.no_graph, device=dev)
     unet_arrays = sd.diffusion_model.load_synthetic(seed=0)
     vae_arrays = sd.image_decoder.load_synthetic(seed=0)
+    hint_img = None
+    if args.controlnet:  # zero-convs are NOT zero (bias_scale > 0 also draws non-trivial biases), else the path is vacuous
+        sd.control_net.load_synthetic(seed=0, bias_scale=0.05)
+        sd.hint_net.load_synthetic(seed=0, bias_scale=0.05)
+        hint_img = np.random.default_rng(7).integers(0, 256, (b, size, size, 3)).astype(np.float32) / 255.0
     if rank != 0 or args.no_cpu_baseline:
         unet_arrays = vae_arrays = None
     log(f"[rank {rank}] weights generated + packed in {time.time() - t0:.1f}s")
@@ -84,8 +90,8 @@ def main():
     def one_job():
         """contexts/noise broadcast -> local denoise loop + decode -> all-gather of uint8 images"""
         def local(c, u, z):
-            eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, False)
-            eng.prepare({"both": np.concatenate([u, c], axis=0)}, z, sd.scheduler, None, 0, None)
+            eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, args.controlnet)
+            eng.prepare({"both": np.concatenate([u, c], axis=0)}, z, sd.scheduler, None, 0, hint_img)
             eng.run_steps(nsteps, None)
             return sd.image_decoder.decode_to_uint8(eng.latent)
         sd.scheduler.set_timesteps(nsteps)
@@ -113,21 +119,23 @@ def main():
     images = gb * args.steps
     value = images / elapsed
     tflop_per_image = 2 * nsteps * UNET_TFLOP * (size / 512) ** 2 + VAE_TFLOP * (size / 512) ** 2
+    if args.controlnet:
+        tflop_per_image += (2 * nsteps * 0.2686 + 0.015) * (size / 512) ** 2  # ControlNet per UNet call + HintNet once
     out = {
         "metric": "512x512 images/sec (whole node), SD1.5 25-step txt2img",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"SD1.5 {size}x{size} {nsteps}-step txt2img, CFG 7.5 + rescale 0.7, batch {b}/GPU, "
-                               f"UNet+VAE HIP path, random-init weights", "global_batch": gb,
+                               f"UNet+VAE{'+ControlNet' if args.controlnet else ''} HIP path, random-init weights", "global_batch": gb,
                    "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph},
         "tflops_per_gpu": round(tflop_per_image * b * args.steps / elapsed, 2),
     }
 
     if rank == 0 and not args.no_roofline:
-        out["roofline"], extra = kernel_roofline(sd, b, nsteps)
+        out["roofline"], extra = kernel_roofline(sd, b, nsteps, args.controlnet)
         out["eager_ms_per_unet_step_by_entry_point"] = extra  # event-per-launch pass (includes ~1-2 us of event gap per call)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.controlnet:
         out["psnr_db_vs_oracle_golden"] = golden_psnr(sd, size, nsteps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(unet_arrays, vae_arrays, ctx[:1], unc[:1], noise[:1], nsteps)
@@ -138,13 +146,13 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_roofline(sd, b, nsteps):
+def kernel_roofline(sd, b, nsteps, control=False):
     """Eager, event-timed pass over one denoise step: per-call durations on the launch stream."""
     import torch
 
     from minsdtf_amd import _lib
 
-    eng = sd._engine(b, 77, 77, nsteps, 7.5, 0.7, False)
+    eng = sd._engine(b, 77, 77, nsteps, 7.5, 0.7, control)
     calls = eng.step.calls
     st = torch.cuda.current_stream()
     reps = 3

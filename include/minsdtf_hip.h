@@ -96,7 +96,9 @@ typedef struct MsdConvGemm {
     int32_t ns0, ns1, out1_ld, out2_ld;
     int32_t splitk;      /* >=1; K-tiles are divided over this many slices */
     int32_t tile_n;      /* 0 = auto, else 64 or 128 */
-    int32_t tile_m;      /* 0 = 128, else 64 / 128 / 256; valid (tile_m x tile_n): 128x128 128x64 64x64 64x128 256x128 */
+    int32_t tile_m;      /* 0 = 128, else 64 / 128 / 256; valid (tile_m x tile_n): 128x128 128x64 64x64 64x128 256x128;
+                            1128 / 1256 = halo-tile 3x3 kernel with 8x16 / 16x16 pixel tiles (falls back if not eligible) */
+    int32_t stages;      /* 0 = default LDS ring depth of the tile; deeper rings built: 128x128:4 64x64:8 64x128:5 128x64:5 */
 } MsdConvGemm;
 
 int msd_conv_gemm(const MsdConvGemm* p, msd_stream_t stream);

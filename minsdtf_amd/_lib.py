@@ -31,7 +31,7 @@ class MsdConvGemm(C.Structure):
         ("upsample", C.c_int32), ("N", C.c_int32), ("act", C.c_int32), ("out_dtype", C.c_int32),
         ("out_ld", C.c_int32), ("res_ld", C.c_int32), ("rv_step_stride", C.c_int32), ("rv_batch_stride", C.c_int32),
         ("split_mode", C.c_int32), ("ns0", C.c_int32), ("ns1", C.c_int32), ("out1_ld", C.c_int32),
-        ("out2_ld", C.c_int32), ("splitk", C.c_int32), ("tile_n", C.c_int32), ("tile_m", C.c_int32),
+        ("out2_ld", C.c_int32), ("splitk", C.c_int32), ("tile_n", C.c_int32), ("tile_m", C.c_int32), ("stages", C.c_int32),
     ]
 
 

@@ -9,6 +9,7 @@ struct CGArgs {
     const bf16_t* residual; void* out; bf16_t* out1; bf16_t* out2; float* ws;
     int batch, h_in, w_in, c0, c1, h_out, w_out, ksize, stride, pad, upsample;
     int M, N, K, hw_out, nkc, nk, nk_per, tiles_n;
+    int tiles_m, m_fast;   // m_fast: consecutive tiles (= same XCD) share the WEIGHT rows instead of the pixel rows
     int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
     int split_mode, ns0, ns1, out1_ld, out2_ld;
 };
@@ -143,5 +144,15 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most min(later, MAXT) tiles of L DMA instructions each are still in flight
+template <int L, int MAXT>
+__device__ __forceinline__ void wait_vmcnt_tiles(int later) {
+    if constexpr (MAXT <= 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (later >= MAXT) wait_vmcnt<(MAXT * L < 63 ? MAXT * L : 63)>();
+        else wait_vmcnt_tiles<L, MAXT - 1>(later);
+    }
 }
 

@@ -52,7 +52,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     // (9 taps, all n-tiles) and then hit that XCD's private 4 MiB L2 instead of the Infinity Cache.
     // Pure speed: any placement computes the same result.
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    // which operand the XCD-contiguous run shares: the pixel rows (n fastest) when the activation
+    // tensor is the bigger one, the weight rows (m fastest) for the weight-heavy small-M layers —
+    // otherwise every XCD's L2 pulls its own copy of up to 59 MB of weights per layer
+    const int tile_n = p.m_fast ? tile / p.tiles_m : tile % p.tiles_n;
+    const int tile_m = p.m_fast ? tile % p.tiles_m : tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kt_begin = blockIdx.y * p.nk_per;
     const int kt_end = min(p.nk, kt_begin + p.nk_per);
@@ -130,9 +134,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     for (int it = 0; it < nkt; ++it) {
         // retire tile `it`: all but the tiles issued after it may stay in flight
         const int later = min(nkt, it + S - 1) - (it + 1);
-        if (later >= S - 2) wait_vmcnt<(S - 2) * L>();
-        else if (S > 3 && later == 1) wait_vmcnt<L>();
-        else wait_vmcnt<0>();
+        wait_vmcnt_tiles<L, S - 2>(later);
         __builtin_amdgcn_s_barrier();  // tile `it` visible to all waves; stage (it-1)%S free for reuse
         if (it + S - 1 < nkt) {
             int st = stage + S - 1;
@@ -307,19 +309,23 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, in
 }
 
 // ---- tile configurations of the LDS-DMA kernel ------------------------------------------------
-struct TileCfg { int bm, bn, threads, lds; };
+struct TileCfg { int bm, bn, threads, lds, stages; };
 #define MSD_TILE_CFGS(X) \
     X(0, 128, 128, 2, 4, 3) \
     X(1, 128, 64, 2, 2, 3)  \
     X(2, 64, 64, 2, 2, 4)   \
     X(3, 64, 128, 2, 2, 3)  \
-    X(4, 256, 128, 4, 2, 3)
+    X(4, 256, 128, 4, 2, 3) \
+    X(5, 128, 128, 2, 4, 4) \
+    X(6, 64, 64, 2, 2, 8)   \
+    X(7, 64, 128, 2, 2, 5)  \
+    X(8, 128, 64, 2, 2, 5)
 static const TileCfg g_cfgs[] = {
-#define X(id, bm, bn, wgm, wgn, st) {bm, bn, wgm * wgn * 64, st * (bm + bn) * 128},
+#define X(id, bm, bn, wgm, wgn, st) {bm, bn, wgm * wgn * 64, st * (bm + bn) * 128, st},
     MSD_TILE_CFGS(X)
 #undef X
 };
-constexpr int NUM_TILE_CFGS = 5;
+constexpr int NUM_TILE_CFGS = 9;
 
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int slices, hipStream_t stream);
 
@@ -436,6 +442,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     if (halo_th) {
         if (halo_th == 16) bn = 128;
         a.tiles_n = (a.N + bn - 1) / bn;
+        a.tiles_m = a.batch * (a.h_in / halo_th) * (a.w_in / 16);
+        a.m_fast = (a.N > a.M) ? 1 : 0;
         rc = msd_conv_halo_launch(a, halo_th, bn, slices, stream);
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
@@ -448,11 +456,15 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     }
     int cfg = -1;
     for (int i = 0; i < NUM_TILE_CFGS; ++i)
-        if (g_cfgs[i].bm == bm && g_cfgs[i].bn == bn) cfg = i;
+        if (g_cfgs[i].bm == bm && g_cfgs[i].bn == bn && (cfg < 0 || g_cfgs[i].stages == q->stages)) cfg = i;
+    // (the first entry of a tile size is its default ring depth; `stages` selects a deeper ring: more
+    //  bytes in flight per CU for the weight-streaming small-M layers that run one workgroup per CU)
     if (cfg < 0 || (g_conv_impl != 1 && bm != 128))
         MSD_FAIL(MSD_E_ARG, "conv_gemm: unsupported tile %dx%d (have 128x128 128x64 64x64 64x128 256x128)", bm, bn);
     const int tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = (a.N + bn - 1) / bn;
+    a.tiles_m = tiles_m;
+    a.m_fast = (a.N > a.M) ? 1 : 0;   // weights are the bigger operand: keep each weight panel on one XCD
     dim3 grid(tiles_m * a.tiles_n, slices);
     if (g_conv_impl == 1) {
         switch (cfg) {

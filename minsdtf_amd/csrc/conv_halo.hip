@@ -43,7 +43,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     const int tiles_x = p.w_in / TW, tiles_y = p.h_in / TH;
     const int tps = tiles_x * tiles_y;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = tile % p.tiles_n, tmi = tile / p.tiles_n;
+    const int tile_n = p.m_fast ? tile / p.tiles_m : tile % p.tiles_n;
+    const int tmi = p.m_fast ? tile % p.tiles_m : tile / p.tiles_n;
     const int b = tmi / tps;
     const int trem = tmi - b * tps;
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;

@@ -240,7 +240,7 @@ class Emitter:
         M = x0.B * ho * wo
         nk = ksize * ksize * (cin // 64)
         can_split = not (split is not None or act == ops.ACT_GEGLU)
-        tile_m, tile_n, sk = tuning.lookup(x0.B, x0.H, x0.W, cin, N, ksize, stride, upsample, M, nk, can_split)
+        tile_m, tile_n, sk, stages = tuning.lookup(x0.B, x0.H, x0.W, cin, N, ksize, stride, upsample, M, nk, can_split)
         if sk > 1:
             p.ws_floats = max(p.ws_floats, sk * M * N)
         if out is None and split is None:
@@ -252,7 +252,7 @@ class Emitter:
                   bias=self.W[(wkey or name) + ".b"] if bias else None, act=act, out_dtype=out_dtype,
                   residual=None if residual is None else residual.buf, res_ld=None if residual is None else residual.C,
                   workspace=p.ws if sk > 1 else None, workspace_floats=sk * M * N if sk > 1 else 0, splitk=sk,
-                  tile_m=tile_m, tile_n=tile_n,
+                  tile_m=tile_m, tile_n=tile_n, stages=stages,
                   step_ptr=self.step_ptr if rowvec is not None else None, name=name)
         if rowvec is not None:
             kw.update(rowvec=rowvec[0], rv_step_stride=rowvec[1], rv_batch_stride=rowvec[2])

@@ -43,7 +43,7 @@ def _p(x) -> Optional[int]:
 def conv_gemm(*, a0, w, out, batch, h_in, w_in, c0, N, a1=None, c1=0, ksize=1, stride=1, upsample=False, bias=None,
               rowvec=None, rv_step_stride=0, rv_batch_stride=0, step_ptr=None, residual=None, res_ld=None, act=ACT_NONE,
               out_dtype=OUT_BF16, out_ld=None, split=None, workspace=None, workspace_floats=0, splitk=1, tile_n=0,
-              tile_m=0, name="conv_gemm") -> Call:
+              tile_m=0, stages=0, name="conv_gemm") -> Call:
     """split = (ns0, ns1, out1, out1_ld, out2, out2_ld) selects the q|k|v^T epilogue."""
     lib = _lib.load()
     pad = 1 if ksize == 3 else 0
@@ -68,7 +68,7 @@ def conv_gemm(*, a0, w, out, batch, h_in, w_in, c0, N, a1=None, c1=0, ksize=1, s
         s.out1, s.out1_ld, s.out2, s.out2_ld = _p(out1), out1_ld, _p(out2), out2_ld
         if out_ld is None:
             s.out_ld = max(ns0, 4)
-    s.splitk, s.tile_n, s.tile_m = splitk, tile_n, tile_m
+    s.splitk, s.tile_n, s.tile_m, s.stages = splitk, tile_n, tile_m, stages
     return Call(lib.msd_conv_gemm, (C.byref(s),), name, keep=s)
 
 

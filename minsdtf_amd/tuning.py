@@ -1,10 +1,11 @@
-"""Per-layer-shape launch configuration of msd_conv_gemm (tile size, split-K).
+"""Per-layer-shape launch configuration of msd_conv_gemm (tile size, LDS ring depth, split-K).
 
 The kernel is bounded by the per-CU L2->LDS operand rate, so the best tile is a trade between
-bytes per FLOP (bigger tiles) and workgroups in flight (smaller tiles / split-K) that depends on the
-layer shape.  `conv_tuning.json` holds the configuration measured fastest on an MI355X for every
-conv / dense shape of the SD1.5 UNet, ControlNet and VAE decoder at the benchmarked batch sizes
-(produced by tools/tune_conv.py); shapes that are not in the table fall back to a size heuristic.
+bytes per FLOP (bigger tiles, the halo-tile 3x3 variant), bytes in flight per CU (ring depth) and
+workgroups in flight (smaller tiles / split-K) that depends on the layer shape.
+`conv_tuning.json` holds the configuration measured fastest on an MI355X for every conv / dense
+shape of the SD1.5 UNet, ControlNet and VAE decoder at the benchmarked batch sizes (produced by
+tools/tune_conv.py); shapes that are not in the table fall back to a size heuristic.
 """
 from __future__ import annotations
 
@@ -15,7 +16,11 @@ from typing import Dict, Optional, Tuple
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning.json")
 _table: Optional[Dict[str, list]] = None
 
-TILES = ((128, 128), (128, 64), (64, 64), (64, 128), (256, 128))
+# (tile_m, tile_n, stages): stages 0 = the tile's default ring depth.  tile_m 1128 / 1256 = halo-tile
+# 3x3 kernel with 8x16 / 16x16 pixel tiles.
+TILES = ((128, 128, 0), (128, 64, 0), (64, 64, 0), (64, 128, 0), (256, 128, 0),
+         (128, 128, 4), (64, 64, 8), (64, 128, 5), (128, 64, 5))
+HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0))
 
 
 def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=True) -> str:
@@ -33,8 +38,8 @@ def _load() -> Dict[str, list]:
     return _table
 
 
-def heuristic(M: int, N: int, nk: int, allow_split: bool) -> Tuple[int, int, int]:
-    """(tile_m, tile_n, splitk) when the shape has not been measured."""
+def heuristic(M: int, N: int, nk: int, allow_split: bool) -> Tuple[int, int, int, int]:
+    """(tile_m, tile_n, splitk, stages) when the shape has not been measured."""
     bn = 128 if (N % 128 == 0 or N > 1024) else 64
     bm = 128
     if M <= 64:
@@ -43,14 +48,15 @@ def heuristic(M: int, N: int, nk: int, allow_split: bool) -> Tuple[int, int, int
     sk = 1
     if allow_split and tiles < 160 and nk >= 32:
         sk = max(1, min((256 + tiles - 1) // tiles, nk // 8, 16))
-    return bm, bn, sk
+    return bm, bn, sk, 0
 
 
-def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split) -> Tuple[int, int, int]:
+def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split) -> Tuple[int, int, int, int]:
     ent = _load().get(shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split))
     if ent is not None:
         bm, bn, sk = int(ent[0]), int(ent[1]), int(ent[2])
+        stages = int(ent[3]) if len(ent) > 4 else 0   # [bm, bn, splitk, stages, us] (older tables: [bm, bn, splitk, us])
         if not allow_split:
             sk = 1
-        return bm, bn, sk
+        return bm, bn, sk, stages
     return heuristic(M, N, nk, allow_split)

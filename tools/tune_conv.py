@@ -102,11 +102,8 @@ def tune_one(shape, iters=10):
     results = []
     cands = list(tuning.TILES)
     if ks == 3 and stride == 1 and not ups and w_in % 16 == 0:  # halo-tile kernel (tile_m = 1000 + pixels per tile)
-        if h_in % 8 == 0:
-            cands += [(1128, 64), (1128, 128)]
-        if h_in % 16 == 0:
-            cands += [(1256, 128)]
-    for (bm, bn) in cands:
+        cands += [t for t in tuning.HALO_TILES if h_in % ((t[0] - 1000) // 16) == 0]
+    for (bm, bn, stg) in cands:
         if bm == 256 and M < 1024:
             continue
         if bn == 128 and N <= 64:
@@ -121,7 +118,7 @@ def tune_one(shape, iters=10):
             wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32) if sk > 1 else None
             calls = [ops.conv_gemm(a0=x, w=w, out=out, batch=batch, h_in=h_in, w_in=w_in, c0=cin, N=N, ksize=ks, stride=stride,
                                    upsample=ups, bias=bias, workspace=wsf, workspace_floats=0 if wsf is None else wsf.numel(),
-                                   splitk=sk, tile_m=bm, tile_n=bn) for w in ws_]
+                                   splitk=sk, tile_m=bm, tile_n=bn, stages=stg) for w in ws_]
             for c in calls[:2]:
                 c(st.cuda_stream)
             torch.cuda.synchronize()
@@ -132,9 +129,9 @@ def tune_one(shape, iters=10):
             e1.record(st)
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / iters
-            results.append((us, bm, bn, sk))
+            results.append((us, bm, bn, sk, stg))
             if best is None or us < best[0]:
-                best = (us, bm, bn, sk)
+                best = (us, bm, bn, sk, stg)
             del wsf
     return best, sorted(results)[:4], 2.0 * M * N * K
 
@@ -156,9 +153,9 @@ def main():
     for s in shapes:
         best, top, flop = tune_one(s)
         key = tuning.shape_key(*s)
-        table[key] = [best[1], best[2], best[3], round(best[0], 1)]
-        alt = " ".join(f"{bm}x{bn}/k{sk}:{us:.0f}" for us, bm, bn, sk in top)
-        print(f"{key:44s} -> {best[1]}x{best[2]} splitk {best[3]:2d}  {best[0]:7.1f} us {flop / best[0] / 1e6:7.1f} TF/s   [{alt}]", flush=True)
+        table[key] = [best[1], best[2], best[3], best[4], round(best[0], 1)]
+        alt = " ".join(f"{bm}x{bn}s{stg}/k{sk}:{us:.0f}" for us, bm, bn, sk, stg in top)
+        print(f"{key:44s} -> {best[1]}x{best[2]}s{best[4]} splitk {best[3]:2d}  {best[0]:7.1f} us {flop / best[0] / 1e6:7.1f} TF/s   [{alt}]", flush=True)
     with open(args.out, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
     print(f"wrote {args.out} ({len(table)} entries) in {time.time() - t0:.0f}s")
