@@ -361,14 +361,24 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         MSD_FAIL(MSD_E_ARG, "conv_gemm: non-positive dims");
     if (q->c0 <= 0 || (q->c0 % 64) || q->c1 < 0 || (q->c1 % 64) || (q->c1 > 0 && !q->a1))
         MSD_FAIL(MSD_E_ARG, "conv_gemm: channel counts must be positive multiples of 64 (c0=%d c1=%d)", q->c0, q->c1);
-    if (!((q->ksize == 1 && q->pad == 0) || (q->ksize == 3 && q->pad == 1)))
+    // `pad` is the LEADING (top / left) zero padding; the trailing padding is implied by the output
+    // size and must be 0 or 1: symmetric pad 1 (the UNet / decoder convs) and the VAE encoder's
+    // ((0,1),(0,1)) stride-2 padding (image_encoder.py:28) are both expressible.
+    if (!((q->ksize == 1 && q->pad == 0) || (q->ksize == 3 && (q->pad == 0 || q->pad == 1))))
         MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: ksize/pad %d/%d", q->ksize, q->pad);
     if (q->stride != 1 && q->stride != 2) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: stride %d", q->stride);
     {
         const int hl = q->upsample ? 2 * q->h_in : q->h_in, wl = q->upsample ? 2 * q->w_in : q->w_in;
-        const int ho = (hl + 2 * q->pad - q->ksize) / q->stride + 1, wo = (wl + 2 * q->pad - q->ksize) / q->stride + 1;
-        if (ho != q->h_out || wo != q->w_out)
-            MSD_FAIL(MSD_E_ARG, "conv_gemm: output dims %dx%d do not match the geometry (%dx%d)", q->h_out, q->w_out, ho, wo);
+        auto dim_ok = [&](int in, int out) {
+            for (int e = 0; e <= (q->ksize == 3 ? 1 : 0); ++e) {
+                const int span = in + q->pad + e - q->ksize;
+                if (span >= 0 && span / q->stride + 1 == out) return true;
+            }
+            return false;
+        };
+        if (!dim_ok(hl, q->h_out) || !dim_ok(wl, q->w_out))
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: output dims %dx%d do not match the geometry (in %dx%d, k%d s%d pad %d)", q->h_out,
+                     q->w_out, hl, wl, q->ksize, q->stride, q->pad);
     }
     if (q->N <= 0 || (q->N % 4)) MSD_FAIL(MSD_E_ARG, "conv_gemm: N=%d must be a positive multiple of 4", q->N);
     if (!msd_aligned16(q->a0) || !msd_aligned16(q->a1) || !msd_aligned16(q->w) || !msd_aligned16(q->out) ||
@@ -417,7 +427,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     int halo_th = 0;
     if (q->tile_m >= 1000) {
         const int th = (q->tile_m - 1000) / 16;
-        const bool ok = g_conv_impl == 1 && q->ksize == 3 && q->stride == 1 && !q->upsample && (q->w_in % 16) == 0 &&
+        const bool ok = g_conv_impl == 1 && q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
+                        q->w_out == q->w_in && !q->upsample && (q->w_in % 16) == 0 &&
                         (th == 8 || th == 16) && (q->h_in % th) == 0;
         if (ok) halo_th = th;
     }

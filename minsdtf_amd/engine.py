@@ -229,13 +229,15 @@ class Emitter:
 
     # conv / dense on the MFMA path; x may be a single Act or a (Act, Act) channel concat
     def conv(self, x, name, N, ksize=1, stride=1, upsample=False, act=ops.ACT_NONE, residual: Optional[Act] = None,
-             rowvec=None, out_dtype=ops.OUT_BF16, bias=True, wkey=None, split=None, out: Optional[Act] = None) -> Act:
+             rowvec=None, out_dtype=ops.OUT_BF16, bias=True, wkey=None, split=None, out: Optional[Act] = None,
+             asym_pad: bool = False) -> Act:
         p = self.p
         x0, x1 = (x if isinstance(x, tuple) else (x, None))
         cin = x0.C + (x1.C if x1 is not None else 0)
         hl, wl = (2 * x0.H, 2 * x0.W) if upsample else (x0.H, x0.W)
         pad = 1 if ksize == 3 else 0
-        ho, wo = (hl + 2 * pad - ksize) // stride + 1, (wl + 2 * pad - ksize) // stride + 1
+        pad_lead, pad_end = ((0, 1) if asym_pad else (pad, pad))  # asym: padding=((0,1),(0,1)) of image_encoder.py:28
+        ho, wo = (hl + pad_lead + pad_end - ksize) // stride + 1, (wl + pad_lead + pad_end - ksize) // stride + 1
         n_out = N // 2 if act == ops.ACT_GEGLU else N
         M = x0.B * ho * wo
         nk = ksize * ksize * (cin // 64)
@@ -252,7 +254,7 @@ class Emitter:
                   bias=self.W[(wkey or name) + ".b"] if bias else None, act=act, out_dtype=out_dtype,
                   residual=None if residual is None else residual.buf, res_ld=None if residual is None else residual.C,
                   workspace=p.ws if sk > 1 else None, workspace_floats=sk * M * N if sk > 1 else 0, splitk=sk,
-                  tile_m=tile_m, tile_n=tile_n, stages=stages,
+                  tile_m=tile_m, tile_n=tile_n, stages=stages, pad=pad_lead, pad_end=pad_end,
                   step_ptr=self.step_ptr if rowvec is not None else None, name=name)
         if rowvec is not None:
             kw.update(rowvec=rowvec[0], rv_step_stride=rowvec[1], rv_batch_stride=rowvec[2])
@@ -579,3 +581,30 @@ def emit_decoder(e: Emitter, latent_f32, B: int, h: int, w: int, out_buf, out_dt
     p.rec(ops.conv_direct, x=g.buf, w=e.W["decoder.conv_out.w"], bias=e.W["decoder.conv_out.b"], out=out_buf, batch=B,
           h_in=g.H, w_in=g.W, c_in=128, c_out=3, ksize=3, in_dtype=ops.OUT_BF16, out_dtype=out_dtype, name="decoder.conv_out")
     p.free(g)
+
+
+def emit_encoder(e: Emitter, image_f32, B: int, H: int, W: int, latent_out_f32) -> None:
+    """ImageEncoder (image_encoder.py:21-48): image (B,H,W,3) in [-1,1] -> mean latent * 0.18215,
+    fp32 (B,H/8,W/8,4).  The three stride-2 convs use the asymmetric ((0,1),(0,1)) padding; the
+    final 1x1 quant_conv + split(...)[0] * 0.18215 (:46-47) is one 8->4 conv with pre-scaled weights."""
+    p = e.p
+    x = p.act(B, H, W, 128)
+    p.rec(ops.conv_direct, x=image_f32, w=e.W["encoder.conv_in.w"], bias=e.W["encoder.conv_in.b"], out=x.buf, batch=B, h_in=H,
+          w_in=W, c_in=3, c_out=128, ksize=3, in_dtype=ops.OUT_F32, out_dtype=ops.OUT_BF16, name="encoder.conv_in")
+    for bi, (cin, cout, down) in enumerate(wtab.VAE_ENC_BLOCKS):
+        for r in range(2):
+            x = e.res_block(x, f"encoder.down_blocks.{bi}.resnets.{r}", cout, free_input=True)
+        if down:
+            y = e.conv(x, f"encoder.down_blocks.{bi}.downsamplers.0.conv", cout, ksize=3, stride=2, asym_pad=True)
+            p.free(x)
+            x = y
+    x = e.res_block(x, "encoder.mid_block.resnets.0", 512, free_input=True)
+    x = emit_vae_attention(e, x, "encoder.mid_block.attentions.0")
+    x = e.res_block(x, "encoder.mid_block.resnets.1", 512, free_input=True)
+    g = e.group_norm(x, "encoder.conv_norm_out", silu=True)
+    p.free(x)
+    m = e.conv(g, "encoder.conv_out", 8, ksize=3, out_dtype=ops.OUT_F32)   # 512 -> 8 moments (mean | logvar), fp32
+    p.free(g)
+    p.rec(ops.conv_direct, x=m.buf, w=e.W["quant_conv.mean.w"], bias=e.W["quant_conv.mean.b"], out=latent_out_f32, batch=B,
+          h_in=m.H, w_in=m.W, c_in=8, c_out=4, ksize=1, in_dtype=ops.OUT_F32, out_dtype=ops.OUT_F32, name="quant_conv.mean")
+    p.free(m)

@@ -43,13 +43,18 @@ def _p(x) -> Optional[int]:
 def conv_gemm(*, a0, w, out, batch, h_in, w_in, c0, N, a1=None, c1=0, ksize=1, stride=1, upsample=False, bias=None,
               rowvec=None, rv_step_stride=0, rv_batch_stride=0, step_ptr=None, residual=None, res_ld=None, act=ACT_NONE,
               out_dtype=OUT_BF16, out_ld=None, split=None, workspace=None, workspace_floats=0, splitk=1, tile_n=0,
-              tile_m=0, stages=0, name="conv_gemm") -> Call:
-    """split = (ns0, ns1, out1, out1_ld, out2, out2_ld) selects the q|k|v^T epilogue."""
+              tile_m=0, stages=0, pad=None, pad_end=None, name="conv_gemm") -> Call:
+    """split = (ns0, ns1, out1, out1_ld, out2, out2_ld) selects the q|k|v^T epilogue.
+    pad / pad_end: leading / trailing zero padding (default: symmetric 1 for 3x3, 0 for 1x1);
+    (0, 1) is the VAE encoder's stride-2 padding ((0,1),(0,1))."""
     lib = _lib.load()
-    pad = 1 if ksize == 3 else 0
+    if pad is None:
+        pad = 1 if ksize == 3 else 0
+    if pad_end is None:
+        pad_end = pad
     hl, wl = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
-    h_out = (hl + 2 * pad - ksize) // stride + 1
-    w_out = (wl + 2 * pad - ksize) // stride + 1
+    h_out = (hl + pad + pad_end - ksize) // stride + 1
+    w_out = (wl + pad + pad_end - ksize) // stride + 1
     n_out = N // 2 if act == ACT_GEGLU else N
     s = _lib.MsdConvGemm()
     s.a0, s.a1, s.w = _p(a0), _p(a1), _p(w)

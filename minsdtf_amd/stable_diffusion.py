@@ -16,7 +16,7 @@ properties, same return value (``uint8 (B, H, W, 3)``).  What differs is where t
   routes agree.
 
 Out of scope here: the CLIP text front-end (prompts must arrive as embeddings, or
-through a user-supplied ``text_frontend``), the VAE encoder for img2img, inpainting, TCD.
+through a user-supplied ``text_frontend``), inpainting, TCD.
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ import torch
 
 from . import engine, ops
 from . import weights as wtab
-from .models import ControlNet, DiffusionModel, HintNet, ImageDecoder, _BoundPlan, _skip_hw, default_device
+from .models import ControlNet, DiffusionModel, HintNet, ImageDecoder, ImageEncoder, _BoundPlan, _skip_hw, default_device
 from .scheduler import Scheduler
 
 MAX_PROMPT_LENGTH = 77
@@ -313,6 +313,20 @@ class StableDiffusionBase:
         bot = image_array[y1, x0, :] * (1.0 - dx) + image_array[y1, x1, :] * dx
         return top * (1.0 - dy) + bot * dy
 
+    def preprocessed_image(self, x):
+        """Reference :277-286: path or HxWx3 array -> ((1,H,W,3) in [0,1], (1,H,W,3) in [-1,1])."""
+        if type(x) is str:
+            from PIL import Image
+
+            x = np.array(Image.open(x).convert("RGB"))
+        else:
+            x = np.array(x)
+        image_array = self.resize(x, self.img_height, self.img_width)
+        image_array = np.array(image_array, dtype=np.float32) / 255.0
+        input_image_array = image_array[None, ..., :3]
+        input_image_tensor = input_image_array * 2.0 - 1.0
+        return input_image_array, input_image_tensor
+
     # ---- the loop (reference :317-486)
     def generate_image(self, encoded_text, negative_prompt=None, batch_size=1, num_steps=50, unconditional_guidance_scale=7.5,
                        diffusion_noise=None, seed=None, negative_embedding=None, control_net_image=None, inpaint_mask=None,
@@ -323,8 +337,6 @@ class StableDiffusionBase:
                              "used to generate diffusion noise when it's not already user-specified.")
         if inpaint_mask is not None:
             raise NotImplementedError("inpainting is outside the accelerated path (SURVEY.md §8f rank 4)")
-        if reference_image is not None and (0.0 < reference_image_strength < 1.0):
-            raise NotImplementedError("image_to_image needs the VAE encoder (SURVEY.md §8f rank 1), not built yet")
         context = self._expand_tensor(encoded_text, batch_size)
         if negative_prompt is None and negative_embedding is None:
             unconditional_context = np.repeat(self._get_unconditional_context(), batch_size, axis=0)
@@ -341,6 +353,20 @@ class StableDiffusionBase:
         else:
             diffusion_noise = self._get_initial_diffusion_noise(batch_size, seed)
         self.scheduler.set_timesteps(num_steps)
+        # image_to_image (reference :410-418,559-568): encode the reference image, keep only the last
+        # int(n*strength+0.5) steps and start from signal[t_init]*z0 + noise[t_init]*eps.  A strength
+        # outside (0,1) silently falls back to txt2img, like the reference (:410).
+        timesteps_asc = self.scheduler.timesteps[::-1]
+        run_steps = num_steps
+        if reference_image is not None and (0.0 < reference_image_strength < 1.0):
+            _, input_image_tensor = self.preprocessed_image(reference_image)
+            run_steps = int(num_steps * reference_image_strength + 0.5)
+            init_time = timesteps_asc[run_steps]
+            init_latent = self.image_encoder.predict_on_batch(input_image_tensor)
+            timesteps_asc = timesteps_asc[:run_steps]
+            diffusion_noise = (self.scheduler.signal_rates[init_time] * np.repeat(init_latent, batch_size, axis=0)
+                               + self.scheduler.noise_rates[init_time] * diffusion_noise)
+        start_index = num_steps - run_steps  # position of the first executed timestep in the descending schedule
         hint_image = None
         if control_net_image is not None:
             if isinstance(control_net_image, np.ndarray):
@@ -353,7 +379,7 @@ class StableDiffusionBase:
 
         if host_loop:
             latent = self._host_loop(context, unconditional_context, diffusion_noise, unconditional_guidance_scale,
-                                     guidance_rescale, hint_image, callback)
+                                     guidance_rescale, hint_image, callback, timesteps_asc)
             if return_latent:
                 return np.asarray(latent, dtype=np.float32)
             decoded = self.image_decoder.predict_on_batch(latent)
@@ -368,8 +394,8 @@ class StableDiffusionBase:
             ctxs = {"uncond": unconditional_context, "cond": context}
         else:
             ctxs = {"cond": context}
-        eng.prepare(ctxs, diffusion_noise, self.scheduler, self.scheduler.timesteps, 0, hint_image)
-        eng.run_steps(num_steps, callback)
+        eng.prepare(ctxs, diffusion_noise, self.scheduler, self.scheduler.timesteps, start_index, hint_image)
+        eng.run_steps(run_steps, callback)
         if return_latent:
             return eng.latent.cpu().numpy()
         return self.image_decoder.decode_to_uint8(eng.latent).cpu().numpy()
@@ -384,9 +410,10 @@ class StableDiffusionBase:
             self._engines = {key: eng}  # one resident engine: its arenas are the big allocations
         return eng
 
-    def _host_loop(self, context, unconditional_context, latent, g, phi, hint_image, callback):
+    def _host_loop(self, context, unconditional_context, latent, g, phi, hint_image, callback, timesteps=None):
         """The reference's own loop over predict_on_batch (stable_diffusion.py:442-479)."""
-        timesteps = self.scheduler.timesteps[::-1]
+        if timesteps is None:
+            timesteps = self.scheduler.timesteps[::-1]
         batch_size = latent.shape[0]
         hint = self.hint_net.predict_on_batch(hint_image) if hint_image is not None else None
         iteration = 0
@@ -450,6 +477,14 @@ class StableDiffusion(StableDiffusionBase):
             if self.jit_compile:
                 self._image_decoder.compile(jit_compile=True)
         return self._image_decoder
+
+    @property
+    def image_encoder(self):
+        if self._image_encoder is None:
+            self._image_encoder = ImageEncoder(ckpt_path=self.vae_ckpt, device=self.device)
+            if self.jit_compile:
+                self._image_encoder.compile(jit_compile=True)
+        return self._image_encoder
 
     @property
     def control_net(self):

@@ -220,8 +220,30 @@ def decoder_table() -> List[WeightSpec]:
     return t.rows
 
 
+VAE_ENC_BLOCKS = ((128, 128, True), (128, 256, True), (256, 512, True), (512, 512, False))
+
+
+def encoder_table() -> List[WeightSpec]:
+    """VAE encoder (reference image_encoder.py:21-48; table ckpt_loader.py 'encoder', 108 tensors)."""
+    t = _Table("", use_alt=False)
+    t.conv("encoder.conv_in", "encoder.conv_in", 3, 128, 3)
+    for bi, (cin, cout, down) in enumerate(VAE_ENC_BLOCKS):
+        for r in range(2):
+            _vae_resnet(t, f"encoder.down_blocks.{bi}.resnets.{r}", cin if r == 0 else cout, cout)
+        if down:
+            t.conv(f"encoder.down_blocks.{bi}.downsamplers.0.conv", f"encoder.down_blocks.{bi}.downsamplers.0.conv", cout, cout, 3)
+    _vae_resnet(t, "encoder.mid_block.resnets.0", 512, 512)
+    _vae_attention(t, "encoder.mid_block.attentions.0", 512)
+    _vae_resnet(t, "encoder.mid_block.resnets.1", 512, 512)
+    t.norm("encoder.conv_norm_out", "encoder.conv_norm_out", 512)
+    t.conv("encoder.conv_out", "encoder.conv_out", 512, 8, 3)
+    t.conv("quant_conv", "quant_conv", 8, 8, 1)
+    return t.rows
+
+
 TABLES = {
     "civitai_model": unet_table,
+    "encoder": encoder_table,
     "decoder": decoder_table,
     "controlnet": controlnet_table,
     "hintnet": hintnet_table,
@@ -265,7 +287,7 @@ def synth_tensors(kind: str, seed: int = 0, bias_scale: float = 0.0) -> Iterator
     caller batches the work.  ``bias_scale`` > 0 draws biases / norm offsets from U(-s, s) (used by
     parity tests so that bias / beta paths are not vacuous); 0 gives the Keras default init.
     """
-    salt = {"civitai_model": 0, "decoder": 1, "controlnet": 2, "hintnet": 3}[kind]
+    salt = {"civitai_model": 0, "decoder": 1, "controlnet": 2, "hintnet": 3, "encoder": 4}[kind]
     rng = np.random.Generator(np.random.PCG64([seed, salt]))
     for spec in table(kind):
         if spec.kind in ("conv_w", "dense_w"):

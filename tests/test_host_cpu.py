@@ -109,7 +109,14 @@ def _fake_decoder(latent):
     return np.tanh(up * 0.7).astype(np.float32)
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def _fake_encoder(img):
+    img = np.asarray(img, dtype=np.float32)
+    b, h, w, _ = img.shape
+    m = img.reshape(b, h // 8, 8, w // 8, 8, 3).mean(axis=(2, 4))
+    return np.concatenate([m, m.mean(axis=-1, keepdims=True)], axis=-1).astype(np.float32) * 0.7
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_host_loop_matches_reference(tag):
     """generate_image(host_loop=True) with the same numpy fake models the reference's loop was run
     with: same call order and arguments (uncond before cond, one call when guidance <= 0), same
@@ -128,16 +135,18 @@ def test_host_loop_matches_reference(tag):
             if self.kind == "unet":
                 trace.append(["unet", float(np.asarray(x[1])[0, 0]), float(np.asarray(x[2]).mean())])
                 return self.fn(*x[:3])
-            trace.append(["decoder"])
+            trace.append([self.kind])
             return self.fn(x)
 
     class Pipe(StableDiffusionBase):
         diffusion_model = property(lambda self: Fake(_fake_unet, "unet"))
         image_decoder = property(lambda self: Fake(_fake_decoder, "decoder"))
+        image_encoder = property(lambda self: Fake(_fake_encoder, "encoder"))
 
     p = Pipe(64, 64)
     p.unconditional_context = g["uncond"]
-    img = p.generate_image(g["context"], diffusion_noise=g[f"{tag}_noise"], host_loop=True, **tr["kwargs"])
+    extra = {"reference_image": g["d_reference_image"]} if tag == "d" else {}   # image_to_image run
+    img = p.generate_image(g["context"], diffusion_noise=g[f"{tag}_noise"], host_loop=True, **tr["kwargs"], **extra)
     assert img.dtype == np.uint8 and img.shape == g[f"{tag}_image"].shape
     assert len(trace) == len(tr["calls"])
     for mine, ref in zip(trace, tr["calls"]):
@@ -179,11 +188,12 @@ def test_weight_tables_match_reference_digests():
     from minsdtf_amd import weights as W
 
     g = gold("g6_ckpt_tables.json")
-    for kind in ("civitai_model", "decoder", "controlnet", "hintnet"):
+    for kind in ("civitai_model", "decoder", "controlnet", "hintnet", "encoder"):
         assert len(W.table(kind)) == g[kind]["count"]
         assert W.table_digest(kind) == g[kind]["sha256"]
     assert (W.param_count("civitai_model"), W.param_count("decoder"), W.param_count("controlnet"), W.param_count("hintnet")) == \
         (859520964, 49490199, 360192640, 1086480)
+    assert W.param_count("encoder") == 34163664
     import hashlib
 
     h = hashlib.sha256()

@@ -60,6 +60,8 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, splitk=2),    # halo + split over chunks
     dict(B=3, H=16, W=48, c0=320, N=320, ks=3, tile_m=1256, tile_n=128, splitk=3),
     dict(B=2, H=12, W=20, c0=64, N=64, ks=3, tile_m=1128, tile_n=64),                # not tileable -> generic fallback
+    dict(B=2, H=16, W=16, c0=128, N=128, ks=3, stride=2, asym=True),                 # VAE encoder downsampler: pad bottom/right only
+    dict(B=1, H=10, W=18, c0=64, N=192, ks=3, stride=2, asym=True, splitk=3, tile_m=64, tile_n=64),
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing
@@ -76,7 +78,11 @@ def test_conv_gemm(gpu, case):
     bias = torch.randn(N)
     pad = 1 if ks == 3 else 0
     xin = torch.cat([x0, x1], dim=-1) if c1 else x0
-    ref = conv_ref(xin, w, bias, stride=stride, pad=pad, upsample=ups)
+    asym = case.get("asym", False)
+    if asym:   # image_encoder.py PaddedConv2D(padding=((0,1),(0,1)), strides=2)
+        ref = conv_ref(F.pad(xin, (0, 0, 0, 1, 0, 1)), w, bias, stride=stride, pad=0)
+    else:
+        ref = conv_ref(xin, w, bias, stride=stride, pad=pad, upsample=ups)
     Ho, Wo = ref.shape[1], ref.shape[2]
     M = B * Ho * Wo
     steps = 3
@@ -98,7 +104,8 @@ def test_conv_gemm(gpu, case):
                          upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N, rv_batch_stride=N,
                          step_ptr=step, residual=resid.to(torch.bfloat16).to(d), act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
                          out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, workspace=ws, workspace_floats=ws.numel(),
-                         splitk=splitk, tile_n=case.get("tile_n", 0), tile_m=case.get("tile_m", 0))
+                         splitk=splitk, tile_n=case.get("tile_n", 0), tile_m=case.get("tile_m", 0),
+                         **(dict(pad=0, pad_end=1) if asym else {}))
     run_calls(call)
     close(out.reshape(B, Ho, Wo, N), ref, what=str(case))
 

@@ -94,6 +94,14 @@ def fake_decoder(latent):
     return np.tanh(up * 0.7).astype(np.float32)
 
 
+def fake_encoder(img):
+    """numpy stand-in for ImageEncoder: (1,H,W,3) in [-1,1] -> (1,H/8,W/8,4)."""
+    img = np.asarray(img, dtype=np.float32)
+    b, h, w, _ = img.shape
+    m = img.reshape(b, h // 8, 8, w // 8, 8, 3).mean(axis=(2, 4))
+    return np.concatenate([m, m.mean(axis=-1, keepdims=True)], axis=-1).astype(np.float32) * 0.7
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # ---------------------------------------------------------------- G1 scheduler
@@ -157,7 +165,7 @@ def main():
             if self.tag == "unet":
                 trace.append(("unet", float(np.asarray(x[1])[0, 0]), float(np.asarray(x[2]).mean())))
                 return self.fn(*x[:3])
-            trace.append(("decoder",))
+            trace.append((self.tag,))
             return self.fn(x)
 
     class RefPipe(ref_sd.StableDiffusionBase):
@@ -169,6 +177,10 @@ def main():
         def image_decoder(self):
             return FakeModel(fake_decoder, "decoder")
 
+        @property
+        def image_encoder(self):
+            return FakeModel(fake_encoder, "encoder")
+
     g2 = {}
     rng = np.random.default_rng(7)
     ctx = rng.standard_normal((77, 768)).astype(np.float32)
@@ -177,13 +189,19 @@ def main():
     g2["context"], g2["uncond"] = ctx, unc
     runs = {"a": dict(batch_size=1, num_steps=25, unconditional_guidance_scale=7.5, guidance_rescale=0.7),
             "b": dict(batch_size=2, num_steps=4, unconditional_guidance_scale=5.0, guidance_rescale=0.0),
-            "c": dict(batch_size=1, num_steps=3, unconditional_guidance_scale=0.0, guidance_rescale=0.0)}
+            "c": dict(batch_size=1, num_steps=3, unconditional_guidance_scale=0.0, guidance_rescale=0.0),
+            # image_to_image: strength 0.8 of 25 steps -> 20 steps from t=760, init latent noised at t=800
+            "d": dict(batch_size=2, num_steps=25, unconditional_guidance_scale=7.5, guidance_rescale=0.7,
+                      reference_image_strength=0.8)}
+    ref_img = rng.integers(0, 256, (40, 56, 3)).astype(np.uint8)   # not the model size: exercises the bilinear resize
+    g2["d_reference_image"] = ref_img
     traces = {}
     for tag, kw in runs.items():
         pipe = RefPipe(64, 64)
         noise = rng.standard_normal((kw["batch_size"], 8, 8, 4)).astype(np.float32)
         del trace[:]
-        img = pipe.generate_image(ctx, diffusion_noise=noise, **kw)
+        extra = {"reference_image": ref_img} if "reference_image_strength" in kw else {}
+        img = pipe.generate_image(ctx, diffusion_noise=noise, **kw, **extra)
         g2[f"{tag}_noise"], g2[f"{tag}_image"] = noise, img
         traces[tag] = {"kwargs": kw, "calls": list(trace)}
         # the final latent is not returned by the reference; recover it by re-running its own loop pieces
