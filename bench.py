@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--controlnet", action="store_true", help="BASELINE config 5: ControlNet residuals every step")
+    ap.add_argument("--streams", type=int, default=0, help="1: cond+uncond as one batch-2B forward; 2: two HIP streams; 0: automatic")
     args = ap.parse_args()
 
     import torch
@@ -71,6 +72,7 @@ def main():
     gb = b * world
     t0 = time.time()
     sd = StableDiffusion(size, size, jit_compile=not args.no_graph, device=dev)
+    sd.denoise_streams = args.streams or None
     unet_arrays = sd.diffusion_model.load_synthetic(seed=0)
     vae_arrays = sd.image_decoder.load_synthetic(seed=0)
     hint_img = None
@@ -91,7 +93,7 @@ def main():
         """contexts/noise broadcast -> local denoise loop + decode -> all-gather of uint8 images"""
         def local(c, u, z):
             eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, args.controlnet)
-            eng.prepare({"both": np.concatenate([u, c], axis=0)}, z, sd.scheduler, None, 0, hint_img)
+            eng.prepare(eng.contexts(u, c), z, sd.scheduler, None, 0, hint_img)
             eng.run_steps(nsteps, None)
             return sd.image_decoder.decode_to_uint8(eng.latent)
         sd.scheduler.set_timesteps(nsteps)
@@ -128,7 +130,8 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"SD1.5 {size}x{size} {nsteps}-step txt2img, CFG 7.5 + rescale 0.7, batch {b}/GPU, "
                                f"UNet+VAE{'+ControlNet' if args.controlnet else ''} HIP path, random-init weights", "global_batch": gb,
-                   "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph},
+                   "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph,
+                   "cond_uncond": "two HIP streams" if sd._engine(b, 77, 77, nsteps, 7.5, 0.7, args.controlnet).dual else "one fused batch"},
         "tflops_per_gpu": round(tflop_per_image * b * args.steps / elapsed, 2),
     }
 
@@ -153,7 +156,7 @@ def kernel_roofline(sd, b, nsteps, control=False):
     from minsdtf_amd import _lib
 
     eng = sd._engine(b, 77, 77, nsteps, 7.5, 0.7, control)
-    calls = eng.step.calls
+    calls = eng.calls
     st = torch.cuda.current_stream()
     reps = 3
     per_name = {}

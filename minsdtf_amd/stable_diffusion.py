@@ -57,7 +57,7 @@ class DenoiseEngine:
 
     def __init__(self, unet: DiffusionModel, B: int, t_cond: int, t_uncond: int, num_steps: int, guidance: float,
                  guidance_rescale: float, control_net: Optional[ControlNet] = None, hint_net: Optional[HintNet] = None,
-                 use_graph: bool = True):
+                 use_graph: bool = True, streams: Optional[int] = None):
         unet._require_weights()
         self.unet, self.B, self.num_steps = unet, B, num_steps
         self.h, self.w = unet.h, unet.w
@@ -66,7 +66,20 @@ class DenoiseEngine:
         cfg = guidance > 0.0
         self.cfg = cfg
         h, w = self.h, self.w
-        fuse = cfg and (t_cond == t_uncond)
+        # Two ways to run the cond and uncond halves of a step (no op couples samples, so both are the
+        # reference's two predict_on_batch calls, :442-460):
+        #  * fused: ONE batch-2B forward;
+        #  * dual (streams=2): two batch-B forwards on two HIP streams that fork after the previous
+        #    sampler step and join before the next one.
+        # Measured on MI355X at 512x512 (profiles/ r1 notes): one batch-1 pass alone takes 5.1 ms of
+        # kernel time, two of them overlapped on two streams 6.6 ms per step, the fused batch-2 pass
+        # 6.7 ms — the same within noise (5.98 vs 6.03 images/s at batch 1, 8.46 vs 8.55 at batch 2),
+        # because the small-batch kernels are bounded by per-workgroup latency with idle CUs either
+        # way.  Fused is the default (one arena, one kernel chain); dual stays selectable.
+        if streams is None:
+            streams = 1
+        self.dual = bool(cfg and streams == 2)
+        fuse = cfg and (t_cond == t_uncond) and not self.dual
         # passes: list of (rows in eps, NB, context length); fused = uncond rows then cond rows
         if not cfg:
             passes = [(0, B, t_cond, "cond")]
@@ -118,15 +131,19 @@ class DenoiseEngine:
         prep.finalize()
         self.prep = prep
 
-        # ---- per-step plan --------------------------------------------------------------------
-        step = engine.Plan(dev)
+        # ---- per-step plans: one per stream (`branches`) + the sampler step (`tail`) ------------
         n = h * w * 4
         self.eps = torch.zeros((2 * B if cfg else B), n, dtype=torch.float32, device=dev)
         cols_u = engine.temb_columns(False)
         cols_c = engine.temb_columns(True)
-        s_u = engine.Emitter(step, unet._W, step_ptr=self.step_ptr)
-        s_c = engine.Emitter(step, control_net._W, step_ptr=self.step_ptr) if self.has_control else None
+        self.branches = []
+        step = None
         for (row0, nb, t, tag) in passes:
+            if step is None or self.dual:
+                step = engine.Plan(dev)   # dual: each half owns its arena, the halves are live at the same time
+                self.branches.append(step)
+                s_u = engine.Emitter(step, unet._W, step_ptr=self.step_ptr)
+                s_c = engine.Emitter(step, control_net._W, step_ptr=self.step_ptr) if self.has_control else None
             controls = None
             if self.has_control:
                 controls = [step.act(nb, *_skip_hw(i, h, w), ch) for i, ch in enumerate(wtab.UNET_SKIP_CH + (1280,))]
@@ -137,14 +154,46 @@ class DenoiseEngine:
             engine.emit_unet(s_u, self.latent, B, nb, h, w, (table_u, total_u, 0, cols_u), ctx_kv_u[tag], t, eps_view, controls)
             if controls is not None:
                 step.free(*controls)
-        step.rec(ops.cfg_step, eps=self.eps, latent=self.latent, coef=self.coef, step_ptr=self.step_ptr, batch=B, n=n,
+        tail = engine.Plan(dev) if self.dual else step
+        tail.rec(ops.cfg_step, eps=self.eps, latent=self.latent, coef=self.coef, step_ptr=self.step_ptr, batch=B, n=n,
                  num_steps=num_steps, guidance=guidance, guidance_rescale=guidance_rescale, advance=True)
-        step.finalize()
-        self.step = step
+        for pl in self.branches:
+            pl.finalize()
+        self.tail = tail if self.dual else None
+        if self.dual:
+            tail.finalize()
+            self._side = torch.cuda.Stream(device=dev)
         self._step_graph: Optional[torch.cuda.CUDAGraph] = None
         self._loop_graph: Optional[torch.cuda.CUDAGraph] = None
         self._loop_graph_steps = 0
         self._warmed = False
+
+    @property
+    def calls(self):
+        """Every launch of one sampler step, in issue order (profiling / bench helpers)."""
+        out = [c for pl in self.branches for c in pl.calls]
+        return out + (self.tail.calls if self.tail is not None else [])
+
+    def contexts(self, unconditional_context, context) -> Dict[str, np.ndarray]:
+        """The `prepare` input for this engine's pass layout."""
+        if not self.cfg:
+            return {"cond": context}
+        if len(self.passes) == 1:
+            return {"both": np.concatenate([unconditional_context, context], axis=0)}
+        return {"uncond": unconditional_context, "cond": context}
+
+    def _one_step(self, main: "torch.cuda.Stream") -> None:
+        """Issue one sampler step on `main` (dual: the cond half forks to the side stream and joins
+        before the CFG / sampler kernel).  Works eagerly and under stream capture."""
+        if not self.dual:
+            self.branches[0].run(main.cuda_stream)
+            return
+        side = self._side
+        side.wait_stream(main)
+        self.branches[0].run(main.cuda_stream)
+        self.branches[1].run(side.cuda_stream)
+        main.wait_stream(side)
+        self.tail.run(main.cuda_stream)
 
     # ---- graphs
     def _capture(self, fn) -> torch.cuda.CUDAGraph:
@@ -153,7 +202,7 @@ class DenoiseEngine:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             with torch.cuda.graph(g, stream=s):
-                fn(torch.cuda.current_stream().cuda_stream)
+                fn(torch.cuda.current_stream())
         torch.cuda.current_stream().wait_stream(s)
         return g
 
@@ -163,7 +212,7 @@ class DenoiseEngine:
         if self._warmed:
             return
         saved = (self.latent.clone(), self.step_ptr.clone())
-        self.step.run(torch.cuda.current_stream().cuda_stream)
+        self._one_step(torch.cuda.current_stream())
         torch.cuda.synchronize()
         self.latent.copy_(saved[0])
         self.step_ptr.copy_(saved[1])
@@ -172,9 +221,9 @@ class DenoiseEngine:
     def run_steps(self, count: int, callback: Optional[Callable[[int], None]] = None) -> None:
         """Advance the latent by `count` sampler steps from the current device step counter."""
         if not self.use_graph:
-            st = torch.cuda.current_stream().cuda_stream
+            st = torch.cuda.current_stream()
             for i in range(count):
-                self.step.run(st)
+                self._one_step(st)
                 if callback is not None:
                     callback(i + 1)
             return
@@ -182,7 +231,7 @@ class DenoiseEngine:
             if self._loop_graph is None or self._loop_graph_steps != count:
                 def whole(stream):
                     for _ in range(count):
-                        self.step.run(stream)
+                        self._one_step(stream)
                 self._warm()
                 self._loop_graph = self._capture(whole)  # capture records, it does not execute
                 self._loop_graph_steps = count
@@ -190,7 +239,7 @@ class DenoiseEngine:
             return
         if self._step_graph is None:
             self._warm()
-            self._step_graph = self._capture(self.step.run)
+            self._step_graph = self._capture(self._one_step)
         for i in range(count):
             self._step_graph.replay()
             callback(i + 1)
@@ -235,6 +284,7 @@ class StableDiffusionBase:
         self.active_tcd = active_tcd
         self.scheduler = Scheduler(active_tcd=active_tcd)
         self._engines: Dict[tuple, DenoiseEngine] = {}
+        self.denoise_streams = None  # None / 1: cond+uncond as one fused batch; 2: two concurrent HIP streams
         self.text_frontend = None
         self.unconditional_context = None  # (77, 768) embedding of the empty prompt, supplied by the caller
 
@@ -388,25 +438,20 @@ class StableDiffusionBase:
 
         eng = self._engine(batch_size, context.shape[1], unconditional_context.shape[1], num_steps,
                            float(unconditional_guidance_scale), float(guidance_rescale), hint_image is not None)
-        if eng.cfg and len(eng.passes) == 1:
-            ctxs = {"both": np.concatenate([unconditional_context, context], axis=0)}
-        elif eng.cfg:
-            ctxs = {"uncond": unconditional_context, "cond": context}
-        else:
-            ctxs = {"cond": context}
-        eng.prepare(ctxs, diffusion_noise, self.scheduler, self.scheduler.timesteps, start_index, hint_image)
+        eng.prepare(eng.contexts(unconditional_context, context), diffusion_noise, self.scheduler, self.scheduler.timesteps, start_index, hint_image)
         eng.run_steps(run_steps, callback)
         if return_latent:
             return eng.latent.cpu().numpy()
         return self.image_decoder.decode_to_uint8(eng.latent).cpu().numpy()
 
     def _engine(self, B, tc, tu, steps, g, phi, control) -> DenoiseEngine:
-        key = (B, tc, tu, steps, g, phi, control)
+        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams)
         eng = self._engines.get(key)
         if eng is None:
             eng = DenoiseEngine(self.diffusion_model, B, tc, tu, steps, g, phi,
                                 control_net=self.control_net if control else None,
-                                hint_net=self.hint_net if control else None, use_graph=self.jit_compile)
+                                hint_net=self.hint_net if control else None, use_graph=self.jit_compile,
+                                streams=self.denoise_streams)
             self._engines = {key: eng}  # one resident engine: its arenas are the big allocations
         return eng
 

@@ -72,6 +72,30 @@ def test_batch_equals_independent_samples(gpu, nets):
         assert O.psnr(both[i:i + 1], one) >= 50.0  # same arithmetic up to split-K / tile choices that depend on M
 
 
+@pytest.mark.parametrize("jit", [True, False])
+def test_two_stream_step_equals_fused_batch(gpu, nets, jit):
+    """denoise_streams=2: the cond and uncond halves of a step as two batch-B forwards on two HIP
+    streams (fork after the sampler step, join before the next) == the fused batch-2B forward."""
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+    from oracle import sd_oracle as O
+
+    rng = np.random.default_rng(24)
+    ctx = rng.standard_normal((2, 77, 768)).astype(np.float32)
+    unc = rng.standard_normal((77, 768)).astype(np.float32)
+    noise = rng.standard_normal((2, 8, 8, 4)).astype(np.float32)
+    kw = dict(batch_size=2, num_steps=4, unconditional_guidance_scale=7.5, guidance_rescale=0.7, diffusion_noise=noise,
+              return_latent=True)
+    out = {}
+    for streams in (1, 2):
+        sd = StableDiffusion(64, 64, jit_compile=jit, device=gpu)
+        sd._diffusion_model, sd.unconditional_context, sd.denoise_streams = nets["unet"], unc, streams
+        out[streams] = sd.generate_image(ctx, **kw)
+        assert sd._engine(2, 77, 77, 4, 7.5, 0.7, False).dual == (streams == 2)
+        again = sd.generate_image(ctx, **kw)                      # replay (graph or eager): same bits
+        np.testing.assert_array_equal(out[streams], again)
+    assert O.psnr(out[2], out[1]) >= 50.0   # batch-1 vs batch-2 launches pick different tiles / split-K
+
+
 def test_non_power_of_two_latent(gpu):
     """C4-like geometry: 192x192 image -> 24x24 latent (S = 576, 144, 36, 9 tokens per level)."""
     from minsdtf_amd import weights as Wt

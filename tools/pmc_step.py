@@ -26,7 +26,7 @@ def main():
     noise = np.random.default_rng(0).standard_normal((1, size // 8, size // 8, 4)).astype(np.float32)
     sd.scheduler.set_timesteps(steps)
     eng = sd._engine(1, 77, 77, steps, 7.5, 0.7, False)
-    eng.prepare({"both": np.concatenate([unc, ctx], axis=0)}, noise, sd.scheduler, None, 0, None)
+    eng.prepare(eng.contexts(unc, ctx), noise, sd.scheduler, None, 0, None)
     eng.run_steps(2, None)
     torch.cuda.synchronize()
     print("done", float(eng.latent.abs().mean()))

@@ -62,6 +62,11 @@ def collect_shapes(quick=False):
         e = engine.Emitter(p, W)
         engine.emit_decoder(e, _T(), b, h, h, _T(), 0)
 
+    def vae_enc(b, h):
+        p = engine.Plan("cpu")
+        e = engine.Emitter(p, W)
+        engine.emit_encoder(e, _T(), b, 8 * h, 8 * h, _T())
+
     unet(2, 64)
     vae(1, 64)
     if not quick:
@@ -72,6 +77,7 @@ def collect_shapes(quick=False):
         vae(4, 64)
         vae(1, 96)
         controlnet(2, 64)
+        vae_enc(1, 64)
     tuning.lookup = orig
     engine.tuning.lookup = orig
     uniq = []
