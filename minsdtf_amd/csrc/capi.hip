@@ -24,11 +24,17 @@ extern "C" int msd_init(void) {
 }
 
 void msd_set_conv_impl(int v);
+void msd_set_gn_impl(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "conv_impl" (1 = LDS-DMA ring
- * [default], 0 = first-generation register-staged kernel). */
+ * [default], 0 = first-generation register-staged kernel); "gn_impl" (1 = single-launch per-group
+ * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
 extern "C" int msd_set_option(const char* key, int value) {
     if (key && strcmp(key, "conv_impl") == 0) {
         msd_set_conv_impl(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "gn_impl") == 0) {
+        msd_set_gn_impl(value);
         return MSD_OK;
     }
     MSD_FAIL(MSD_E_ARG, "set_option: unknown key");

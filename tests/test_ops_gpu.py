@@ -215,9 +215,19 @@ def test_conv_direct(gpu, case):
     dict(B=1, hw=4096, c0=128, silu=False),            # VAE-like: few channels, many pixels
     dict(B=3, hw=100, c0=512, silu=True),
     dict(B=2, hw=65536, c0=128, silu=True),            # > 64 chunks: separate ordered finalize launch
+    dict(B=2, hw=3264, c0=320, silu=True),             # single-launch kernel: 4-byte units, 16 per thread
+    dict(B=1, hw=3000, c0=320, c1=320, silu=True),     # 8-byte units, 15 per thread, ragged last pass
+    dict(B=2, hw=1024, c0=640, c1=320, silu=True),     # C=960: group 21 straddles x0|x1, 4-byte units
+    dict(B=1, hw=1024, c0=1280, c1=640, silu=False),   # C=1920: 8-byte units, 16 per thread
+    dict(B=2, hw=1000, c0=1280, silu=True),            # 16-byte units, ragged last pass
+    dict(B=1, hw=4096, c0=640, c1=320, silu=True),     # slab too big for registers -> three-launch path
+    dict(B=2, hw=256, c0=1280, c1=640, silu=True, impl=0),   # three-launch path forced on a small tensor
+    dict(B=2, hw=64, c0=320, silu=True, impl=0),
 ])
 def test_group_norm(gpu, case):
-    from minsdtf_amd import ops
+    from minsdtf_amd import _lib, ops
+
+    _lib.load().msd_set_option(b"gn_impl", case.get("impl", 1))
 
     torch.manual_seed(5)
     B, hw, c0, c1 = case["B"], case["hw"], case["c0"], case.get("c1", 0)
@@ -235,8 +245,23 @@ def test_group_norm(gpu, case):
     call = ops.group_norm(partials=partials, x0=x0.to(torch.bfloat16).to(gpu), x1=None if x1 is None else x1.to(torch.bfloat16).to(gpu),
                           gamma=gamma.to(gpu), beta=beta.to(gpu), stats=stats, out=out, batch=B, hw=hw, c0=c0, c1=c1,
                           silu=case["silu"])
-    run_calls(call)
+    try:
+        run_calls(call)
+    finally:
+        _lib.load().msd_set_option(b"gn_impl", 1)
     close(out, ref, atol=2e-2, what=str(case))
+    # {mean, rstd} per (sample, group) are part of the contract on both paths
+    xs = x.reshape(B, hw, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1)
+    st = stats.cpu().reshape(B, 32, 2)
+    np.testing.assert_allclose(st[..., 0].numpy(), xs.mean(-1).numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(st[..., 1].numpy(), (xs.var(-1, unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-3)
+    out2 = torch.full_like(out, float("nan"))
+    call2 = ops.group_norm(partials=partials, x0=x0.to(torch.bfloat16).to(gpu), x1=None if x1 is None else x1.to(torch.bfloat16).to(gpu),
+                           gamma=gamma.to(gpu), beta=beta.to(gpu), stats=stats, out=out2, batch=B, hw=hw, c0=c0, c1=c1,
+                           silu=case["silu"])
+    run_calls(call2)
+    if case.get("impl", 1) == 1:
+        assert torch.equal(out.view(torch.int16), out2.view(torch.int16))   # bit-reproducible run to run
 
 
 @pytest.mark.parametrize("rows,c", [(256, 320), (100, 640), (64, 1280), (7, 2048)])
