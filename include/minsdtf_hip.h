@@ -95,10 +95,13 @@ typedef struct MsdConvGemm {
     int32_t split_mode;  /* 0: plain; 1: columns [0,ns0)->out, [ns0,ns0+ns1)->out1, rest->out2 transposed */
     int32_t ns0, ns1, out1_ld, out2_ld;
     int32_t splitk;      /* >=1; K-tiles are divided over this many slices */
-    int32_t tile_n;      /* 0 = auto, else 64 or 128 */
-    int32_t tile_m;      /* 0 = 128, else 64 / 128 / 256; valid (tile_m x tile_n): 128x128 128x64 64x64 64x128 256x128;
-                            1128 / 1256 = halo-tile 3x3 kernel with 8x16 / 16x16 pixel tiles (falls back if not eligible) */
-    int32_t stages;      /* 0 = default LDS ring depth of the tile; deeper rings built: 128x128:4 64x64:8 64x128:5 128x64:5 */
+    int32_t tile_n;      /* 0 = auto, else 64, 80 or 128 */
+    int32_t tile_m;      /* 0 = 128, else 64 / 128 / 256; valid (tile_m x tile_n): 128x128 128x64 64x64 64x128 256x128 128x80;
+                            1128 / 1256 = halo-tile 3x3 kernel with 8x16 / 16x16 pixel tiles (x 64 / 80 / 128 channels;
+                            falls back if not eligible).  The 80-wide tiles serve N = 320 / 640 at small batch, where
+                            they make the workgroup count a multiple of the 256 CUs */
+    int32_t stages;      /* 0 = default LDS ring depth of the tile; deeper rings built: 128x128:4 64x64:8 64x128:5 128x64:5
+                            128x80:4; halo tiles 1128x64:8 1128x128:6 1128x80:8 1256x80:5 (an unknown depth = the default) */
 } MsdConvGemm;
 
 int msd_conv_gemm(const MsdConvGemm* p, msd_stream_t stream);

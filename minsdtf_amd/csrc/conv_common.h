@@ -91,6 +91,7 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
         if (m >= p.M) continue;
         const int b = m / p.hw_out;
         if (p.act == MSD_ACT_GEGLU) {
+            if constexpr (NJ % 2 == 0) {   // (x|gate pairs: the host never sends GEGLU to an odd-NJ tile)
 #pragma unroll
             for (int j = 0; j < NJ; j += 2) {
                 const int nb = nbase + j * 16;  // multiple of 32: x columns nb+[0,16), gate nb+16+[0,16)
@@ -113,6 +114,7 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
                 }
                 uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
+            }
             }
         } else {
 #pragma unroll

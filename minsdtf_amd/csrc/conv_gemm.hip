@@ -35,11 +35,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     constexpr int NT = NW * 64;                 // threads
     constexpr int WMT = BM / WGM, WNT = BN / WGN;   // wave tile
     constexpr int MI = WMT / 16, NJ = WNT / 16;
-    constexpr int AR = BM * 8 / NT, BR = BN * 8 / NT;   // 16-byte pieces per thread per tile
-    static_assert(AR >= 1 && BR >= 1 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0 && (NJ % 2) == 0, "tile config");
-    constexpr int L = AR + BR;                  // DMA instructions per thread per tile
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, ST_BYTES = A_BYTES + B_BYTES;
     constexpr int RPP = NT / 8;                 // rows covered by one pass of the workgroup
+    constexpr int BNP = (BN + RPP - 1) / RPP * RPP;     // weight rows as staged (BN = 80: padded to the DMA round)
+    constexpr int AR = BM * 8 / NT, BR = BNP * 8 / NT;  // 16-byte pieces per thread per tile
+    static_assert(AR >= 1 && BR >= 1 && (BM * 8) % NT == 0 && WMT % 16 == 0 && WNT % 16 == 0, "tile config");
+    constexpr int L = AR + BR;                  // DMA instructions per thread per tile
+    constexpr int A_BYTES = BM * 128, B_BYTES = BNP * 128, ST_BYTES = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     for (int i = 0; i < BR; ++i) {
         const int row = lrow + RPP * i;
         const int n = n0 + row;
-        wsrc[i] = (n < p.N) ? (p.w + (size_t)n * p.K + (cpos ^ ((row >> 1) & 7)) * 8) : nullptr;
+        wsrc[i] = (row < BN && n < p.N) ? (p.w + (size_t)n * p.K + (cpos ^ ((row >> 1) & 7)) * 8) : nullptr;
     }
     // LDS destination of this wave's pass i: 8 rows x 128 B, lane-linear
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
@@ -319,15 +320,20 @@ struct TileCfg { int bm, bn, threads, lds, stages; };
     X(5, 128, 128, 2, 4, 4) \
     X(6, 64, 64, 2, 2, 8)   \
     X(7, 64, 128, 2, 2, 5)  \
-    X(8, 128, 64, 2, 2, 5)
+    X(8, 128, 64, 2, 2, 5)  \
+    X(9, 128, 80, 4, 1, 3)  \
+    X(10, 128, 80, 4, 1, 4)
+// (128x80: for N = 320 / 640 at small batch — 64 x 4 = 256 workgroups at M = 8192, one per CU, where
+//  64-wide tiles make 320 and 128-wide ones 192; the 80 weight rows are staged as 96)
+constexpr int cfg_lds(int bm, int bn, int threads, int st) { return st * (bm + (bn + threads / 8 - 1) / (threads / 8) * (threads / 8)) * 128; }
 static const TileCfg g_cfgs[] = {
-#define X(id, bm, bn, wgm, wgn, st) {bm, bn, wgm * wgn * 64, st * (bm + bn) * 128, st},
+#define X(id, bm, bn, wgm, wgn, st) {bm, bn, wgm * wgn * 64, cfg_lds(bm, bn, wgm * wgn * 64, st), st},
     MSD_TILE_CFGS(X)
 #undef X
 };
-constexpr int NUM_TILE_CFGS = 9;
+constexpr int NUM_TILE_CFGS = 11;
 
-int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int slices, hipStream_t stream);
+int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream);
 
 static bool g_cg_attr_done = false;
 static int g_conv_impl = 1;  // 1 = LDS-DMA ring (default), 0 = register-staged first-generation kernel
@@ -344,7 +350,7 @@ int msd_conv_gemm_init() {
 #define X(id, bm, bn, wgm, wgn, st)                                                                          \
     if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<bm, bn, wgm, wgn, st>),  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, st * (bm + bn) * 128);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, cfg_lds(bm, bn, wgm * wgn * 64, st));
     MSD_TILE_CFGS(X)
 #undef X
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_gemm): %s", hipGetErrorString(e));
@@ -426,7 +432,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     // halo variant (tile_m = 1000 + pixels per tile: 1128 = 8x16, 1256 = 16x16): spatially blocked 3x3
     int halo_th = 0;
     if (q->tile_m >= 1000) {
-        const int th = (q->tile_m - 1000) / 16;
+        const int th = (q->tile_m % 1000) / 16;   // 1128 / 1256: 8x16 / 16x16 pixels; 2128: 8x16 on 8 waves
         const bool ok = g_conv_impl == 1 && q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
                         q->w_out == q->w_in && !q->upsample && (q->w_in % 16) == 0 &&
                         (th == 8 || th == 16) && (q->h_in % th) == 0;
@@ -449,13 +455,14 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     // tile configuration: explicit (tile_m, tile_n) or the size heuristic
     int bm = q->tile_m, bn = q->tile_n;
     if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
+    if (bn == 80 && (q->act == MSD_ACT_GEGLU || g_conv_impl != 1)) bn = 64;   // (80 = 5 fragments: no x|gate pairing)
     if (bm == 0 || bm >= 1000) bm = 128;   // a halo request that is not eligible falls back to 128-row tiles
     if (halo_th) {
-        if (halo_th == 16) bn = 128;
+        if (halo_th == 16 && bn != 80) bn = 128;
         a.tiles_n = (a.N + bn - 1) / bn;
         a.tiles_m = a.batch * (a.h_in / halo_th) * (a.w_in / 16);
         a.m_fast = (a.N > a.M) ? 1 : 0;
-        rc = msd_conv_halo_launch(a, halo_th, bn, slices, stream);
+        rc = msd_conv_halo_launch(a, halo_th, bn, q->stages, q->tile_m >= 2000 ? 1 : 0, slices, stream);
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
         if (slices > 1) {
@@ -481,8 +488,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         switch (cfg) {
 #define X(id, bm_, bn_, wgm, wgn, st)                                                                                   \
     case id:                                                                                                            \
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st>), grid, dim3(wgm * wgn * 64), st * (bm_ + bn_) * 128, \
-                           stream, a);                                                                                  \
+        hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st>), grid, dim3(wgm * wgn * 64),                  \
+                           cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, a);                                           \
         break;
             MSD_TILE_CFGS(X)
 #undef X

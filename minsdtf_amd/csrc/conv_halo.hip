@@ -17,6 +17,21 @@
 // w % 16 == 0, h % TH == 0.
 #include "conv_common.h"
 
+// wait until at most min(later, MAXL) weight tiles (BR instructions each) + optionally one halo (HR) are in flight
+template <int BR, int HR, int MAXL>
+__device__ __forceinline__ void halo_wait(int later, bool halo) {
+    if constexpr (MAXL <= 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (later >= MAXL) {
+            if (halo) wait_vmcnt<(MAXL * BR + HR < 63 ? MAXL * BR + HR : 63)>();
+            else wait_vmcnt<(MAXL * BR < 63 ? MAXL * BR : 63)>();
+        } else {
+            halo_wait<BR, HR, MAXL - 1>(later, halo);
+        }
+    }
+}
+
 template <int TH, int BN, int WGM, int WGN, int S>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGArgs p) {
     constexpr int TW = 16, BM = TH * TW;
@@ -28,9 +43,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     constexpr int RPP = NT / 8;                            // LDS rows written per DMA round
     constexpr int HR = (HROWS + RPP - 1) / RPP;            // DMA rounds (= instructions per thread) per halo
     constexpr int H_BYTES = HR * RPP * 128;
-    constexpr int BR = BN * 8 / NT;                        // weight DMA instructions per thread per K step
-    constexpr int W_BYTES = BN * 128;
-    static_assert((BN * 8) % NT == 0 && (NJ % 2) == 0 && S == 3, "config");
+    constexpr int BNP = (BN + RPP - 1) / RPP * RPP;        // weight rows as staged (BN = 80: padded to the DMA round)
+    constexpr int BR = BNP * 8 / NT;                       // weight DMA instructions per thread per K step
+    constexpr int W_BYTES = BNP * 128;
+    static_assert(WNT % 16 == 0 && WMT % 16 == 0, "config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -74,7 +90,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     for (int i = 0; i < BR; ++i) {
         const int row = lrow + RPP * i;
         const int n = n0 + row;
-        wsrc[i] = (n < p.N) ? (p.w + (size_t)n * p.K + (cpos ^ ((row >> 1) & 7)) * 8) : nullptr;
+        wsrc[i] = (row < BN && n < p.N) ? (p.w + (size_t)n * p.K + (cpos ^ ((row >> 1) & 7)) * 8) : nullptr;
     }
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;   // this wave's 8 rows inside a DMA round
     const int cin = p.c0 + p.c1;
@@ -107,30 +123,33 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // program order of the DMA queue: H(c_begin), W(0), W(1) | it: [H(next chunk) at tap 0], W(it+2)
+    // Program order of the DMA queue: H(c_begin), W(0) .. W(S-2) | iteration it: [H(next chunk) at tap 0],
+    // W(it+S-1).  With one workgroup per CU (batch 1-2) a K step costs (L2 latency) / (tiles in flight):
+    // S = 3 measured ~0.7 us per step against ~0.13 us of MFMA work, hence the deeper rings.
+    static_assert(S >= 3 && S - 1 <= 9, "ring depth");
     if (nkt > 0) {
         issue_halo(c_begin, 0);
-        issue_w(c_begin, 0, 0);
-        issue_w(c_begin, 1, 1);
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s)
+            if (s < nkt) issue_w(c_begin, s, s);
     }
     int c = c_begin, tap = 0, stage = 0, hbuf = 0;
-    bool halo_prev = false;  // a halo was issued during the previous iteration (after W(it)'s issue point)
+    int cw = c_begin, tw = S - 1, sw = S - 1;   // (chunk, tap, stage) of the next weight tile to issue
+    if (tw >= 9) { tw -= 9; ++cw; }
+    int since_halo = 1 << 20;                   // iterations since a halo was issued
     for (int it = 0; it < nkt; ++it) {
         // Retire W(it) (and, being older in the queue, the halo of this chunk).  Younger than W(it):
-        // W(it+1) if it exists, preceded by the halo issued at iteration it-1 if there was one.
-        const bool later_w = (it + 1 < nkt);
-        if (!later_w) wait_vmcnt<0>();
-        else if (halo_prev) wait_vmcnt<BR + HR>();
-        else wait_vmcnt<BR>();
+        // W(it+1) .. W(it+S-2) as far as they exist, plus the halo if one was issued in iterations
+        // it-S+2 .. it-1 (loads complete in order, so "at most N outstanding" retires everything older).
+        halo_wait<BR, HR, S - 2>(min(S - 2, nkt - 1 - it), since_halo <= S - 2);
         __builtin_amdgcn_s_barrier();
-        halo_prev = false;
-        if (tap == 0 && c + 1 < c_end) { issue_halo(c + 1, hbuf ^ 1); halo_prev = true; }
-        if (it + 2 < nkt) {
-            int c2 = c, t2 = tap + 2;
-            if (t2 >= 9) { t2 -= 9; c2 += 1; }
-            int st = stage + 2; if (st >= S) st -= S;
-            issue_w(c2, t2, st);
+        if (tap == 0 && c + 1 < c_end) { issue_halo(c + 1, hbuf ^ 1); since_halo = 0; }
+        if (it + S - 1 < nkt) {
+            issue_w(cw, tw, sw);
+            if (++tw == 9) { tw = 0; ++cw; }
+            if (++sw == S) sw = 0;
         }
+        ++since_halo;
         const int ky = tap / 3, kx = tap - ky * 3;
         const char* bW = smem + 2 * H_BYTES + stage * W_BYTES + (wn * WNT + r) * 128;
         const char* bH = smem + hbuf * H_BYTES;
@@ -161,26 +180,43 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WNT, r, g);
 }
 
-// (tile height, BN, waves m x n)
-#define MSD_HALO_CFGS(X) \
-    X(8, 64, 2, 2)       \
-    X(8, 128, 2, 4)      \
-    X(16, 128, 4, 2)
+// (tile height, BN, waves m x n).  BN = 80 exists for the N = 320 / 640 layers at batch 1-2: 8x16-pixel
+// tiles x 80 channels give exactly 256 workgroups at 64x64 (one per CU) where 64-wide tiles give 320
+// (a second, quarter-full round) and 128-wide ones 192.
+// Last column: weight-ring depth.  3 is the default of every tile; the deeper rings (selected with
+// MsdConvGemm.stages) are for launches that put a single workgroup on a CU.
+// Variant 1 (tile_m 2128): the same tile on 8 waves — two waves per SIMD even when the launch puts a
+// single workgroup on a CU, so one wave's LDS-DMA issue stalls and LDS latency hide under the other's MFMAs.
+#define MSD_HALO_CFGS(X)   \
+    X(8, 64, 2, 2, 3, 0)   \
+    X(8, 128, 2, 4, 3, 0)  \
+    X(16, 128, 4, 2, 3, 0) \
+    X(8, 80, 4, 1, 3, 0)   \
+    X(16, 80, 4, 1, 3, 0)  \
+    X(8, 64, 2, 2, 8, 0)   \
+    X(8, 128, 2, 4, 6, 0)  \
+    X(8, 80, 4, 1, 8, 0)   \
+    X(16, 80, 4, 1, 5, 0)  \
+    X(8, 64, 4, 2, 3, 1)   \
+    X(8, 80, 8, 1, 3, 1)
 
-template <int TH, int BN, int WGM, int WGN>
+template <int TH, int BN, int WGM, int WGN, int S>
 static constexpr int halo_lds() {
     constexpr int NT = WGM * WGN * 64, RPP = NT / 8, HROWS = (TH + 2) * 18, HR = (HROWS + RPP - 1) / RPP;
-    return 2 * HR * RPP * 128 + 3 * BN * 128;
+    constexpr int BNP = (BN + RPP - 1) / RPP * RPP;
+    constexpr int bytes = 2 * HR * RPP * 128 + S * BNP * 128;
+    static_assert(bytes <= 160 * 1024, "LDS budget");
+    return bytes;
 }
 
 static bool g_halo_attr_done = false;
 int msd_conv_halo_init() {
     if (g_halo_attr_done) return MSD_OK;
     hipError_t e = hipSuccess;
-#define X(th, bn, wgm, wgn)                                                                                   \
+#define X(th, bn, wgm, wgn, st, var)                                                                            \
     if (e == hipSuccess)                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, 3>),    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn>());
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st>),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st>());
     MSD_HALO_CFGS(X)
 #undef X
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_halo): %s", hipGetErrorString(e));
@@ -189,18 +225,31 @@ int msd_conv_halo_init() {
 }
 
 // Launch for an already validated argument block; returns MSD_E_UNSUPPORTED if (th, bn) is not built.
-int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int slices, hipStream_t stream) {
+int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream) {
     int rc = msd_conv_halo_init();
     if (rc) return rc;
     const int tiles = a.batch * (a.h_in / th) * (a.w_in / 16) * a.tiles_n;
     dim3 grid(tiles, slices);
-#define X(th_, bn_, wgm, wgn)                                                                                             \
-    if (th == th_ && bn == bn_) {                                                                                         \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, 3>), grid, dim3(wgm * wgn * 64),                       \
-                           (halo_lds<th_, bn_, wgm, wgn>()), stream, a);                                                  \
+    // `stages` picks the ring depth if that variant is built, otherwise the tile's default (3)
+    bool have = false;
+#define X(th_, bn_, wgm, wgn, st, var) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
+    MSD_HALO_CFGS(X)
+#undef X
+    if (!have) {   // unknown ring depth -> the tile's default; unknown 8-wave variant -> the 4-wave tile
+        stages = 3;
+        have = false;
+#define X(th_, bn_, wgm, wgn, st, var) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
+        MSD_HALO_CFGS(X)
+#undef X
+        if (!have) variant = 0;
+    }
+#define X(th_, bn_, wgm, wgn, st, var)                                                                                    \
+    if (th == th_ && bn == bn_ && stages == st && variant == var) {                                                                      \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st>), grid, dim3(wgm * wgn * 64),                      \
+                           (halo_lds<th_, bn_, wgm, wgn, st>()), stream, a);                                              \
         return MSD_OK;                                                                                                    \
     }
     MSD_HALO_CFGS(X)
 #undef X
-    MSD_FAIL(MSD_E_UNSUPPORTED, "conv_halo: no %dx16 x %d configuration", th, bn);
+    MSD_FAIL(MSD_E_UNSUPPORTED, "conv_halo: no %dx16 x %d configuration (variant %d)", th, bn, variant);
 }

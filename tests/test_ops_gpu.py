@@ -60,6 +60,16 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, splitk=2),    # halo + split over chunks
     dict(B=3, H=16, W=48, c0=320, N=320, ks=3, tile_m=1256, tile_n=128, splitk=3),
     dict(B=2, H=12, W=20, c0=64, N=64, ks=3, tile_m=1128, tile_n=64),                # not tileable -> generic fallback
+    dict(B=2, H=16, W=16, c0=128, N=320, ks=3, tile_m=1128, tile_n=80),              # 80-wide tiles (5 fragments per wave): halo 8x16
+    dict(B=1, H=32, W=16, c0=64, c1=64, N=200, ks=3, tile_m=1256, tile_n=80, splitk=2),   # halo 16x16 x 80, ragged N, split
+    dict(B=2, H=16, W=16, c0=192, N=128, ks=3, tile_m=1128, tile_n=64, stages=8),    # deep weight rings of the halo kernel
+    dict(B=2, H=16, W=32, c0=128, c1=64, N=192, ks=3, tile_m=1128, tile_n=128, stages=6, splitk=2),
+    dict(B=1, H=16, W=16, c0=64, N=320, ks=3, tile_m=1128, tile_n=80, stages=8),     # ring deeper than the K loop of a chunk
+    dict(B=1, H=32, W=32, c0=256, N=160, ks=3, tile_m=1256, tile_n=80, stages=5),
+    dict(B=2, H=16, W=16, c0=128, N=192, ks=3, tile_m=2128, tile_n=64),              # 8x16 tiles on 8 waves
+    dict(B=1, H=16, W=32, c0=64, c1=64, N=320, ks=3, tile_m=2128, tile_n=80, splitk=2),
+    dict(B=2, H=12, W=20, c0=128, N=320, ks=1, tile_m=128, tile_n=80),               # generic 128x80, ragged M
+    dict(B=2, H=12, W=20, c0=192, N=168, ks=3, tile_m=128, tile_n=80, stages=4, splitk=3),
     dict(B=2, H=16, W=16, c0=128, N=128, ks=3, stride=2, asym=True),                 # VAE encoder downsampler: pad bottom/right only
     dict(B=1, H=10, W=18, c0=64, N=192, ks=3, stride=2, asym=True, splitk=3, tile_m=64, tile_n=64),
 ])
@@ -104,7 +114,7 @@ def test_conv_gemm(gpu, case):
                          upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N, rv_batch_stride=N,
                          step_ptr=step, residual=resid.to(torch.bfloat16).to(d), act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
                          out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, workspace=ws, workspace_floats=ws.numel(),
-                         splitk=splitk, tile_n=case.get("tile_n", 0), tile_m=case.get("tile_m", 0),
+                         splitk=splitk, tile_n=case.get("tile_n", 0), tile_m=case.get("tile_m", 0), stages=case.get("stages", 0),
                          **(dict(pad=0, pad_end=1) if asym else {}))
     run_calls(call)
     close(out.reshape(B, Ho, Wo, N), ref, what=str(case))

@@ -108,15 +108,17 @@ def tune_one(shape, iters=10):
     results = []
     cands = list(tuning.TILES)
     if ks == 3 and stride == 1 and not ups and w_in % 16 == 0:  # halo-tile kernel (tile_m = 1000 + pixels per tile)
-        cands += [t for t in tuning.HALO_TILES if h_in % ((t[0] - 1000) // 16) == 0]
+        cands += [t for t in tuning.HALO_TILES if h_in % ((t[0] % 1000) // 16) == 0]
     for (bm, bn, stg) in cands:
         if bm == 256 and M < 1024:
             continue
         if bn == 128 and N <= 64:
             continue
+        if bn == 80 and (N % 80 or not allow_split):   # (the 'n' shapes include GEGLU, which pairs fragments)
+            continue
         sks = [1]
         if allow_split:
-            bme = bm - 1000 if bm >= 1000 else bm
+            bme = bm % 1000 if bm >= 1000 else bm
             tiles = ((M + bme - 1) // bme) * ((N + bn - 1) // bn)
             kmax = (cin // 64) if bm >= 1000 else nk // 4   # the halo kernel splits over 64-channel chunks
             sks += [s for s in (2, 3, 4, 6, 8, 12, 16) if s <= kmax and tiles * s <= 2048 and tiles < 512]
