@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 UNET_TFLOP = 0.8033   # per UNet forward, 512x512, ctx 77, per sample
 VAE_TFLOP = 2.5145    # per decode
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # HBM3E, MI355X_MICROARCH.md
 
 
 def log(*a):
@@ -135,8 +136,23 @@ def main():
         "tflops_per_gpu": round(tflop_per_image * b * args.steps / elapsed, 2),
     }
 
+    if rank == 0:
+        # the two halves of the job, timed separately (SURVEY.md §8d timing protocol): hipGraph replays on resident inputs
+        eng = sd._engine(b, 77, 77, nsteps, 7.5, 0.7, args.controlnet)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        sd.scheduler.set_timesteps(nsteps)
+        eng.prepare(eng.contexts(unc[:b], ctx[:b]), noise[:b], sd.scheduler, None, 0, hint_img)
+        torch.cuda.synchronize()
+        ev[0].record()
+        eng.run_steps(nsteps, None)
+        ev[1].record()
+        sd.image_decoder.decode_to_uint8(eng.latent)
+        ev[2].record()
+        torch.cuda.synchronize()
+        out["ms_denoise_loop"] = round(ev[0].elapsed_time(ev[1]), 3)
+        out["ms_vae_decode"] = round(ev[1].elapsed_time(ev[2]), 3)
     if rank == 0 and not args.no_roofline:
-        out["roofline"], extra = kernel_roofline(sd, b, nsteps, args.controlnet)
+        out["roofline"], out["roofline_by_kernel"], extra = kernel_roofline(sd, b, nsteps, args.controlnet)
         out["eager_ms_per_unet_step_by_entry_point"] = extra  # event-per-launch pass (includes ~1-2 us of event gap per call)
     if rank == 0 and world == 1 and not args.controlnet:
         out["psnr_db_vs_oracle_golden"] = golden_psnr(sd, size, nsteps)
@@ -160,6 +176,31 @@ def kernel_roofline(sd, b, nsteps, control=False):
     st = torch.cuda.current_stream()
     reps = 3
     per_name = {}
+    klass = {}   # kernel class -> time, algorithmic FLOP and algorithmic bytes of one denoise step
+
+    def work(c):
+        """(class, algorithmic FLOP, algorithmic HBM bytes) of one launch: every operand read once, the
+        result written once; attention scores never touch HBM."""
+        s = c.keep
+        if isinstance(s, _lib.MsdConvGemm):
+            M, cin = s.batch * s.h_out * s.w_out, s.c0 + s.c1
+            K = s.ksize * s.ksize * cin
+            n_out = s.N // 2 if s.act == _lib.ACT_GEGLU else s.N
+            byt = 2 * (s.batch * s.h_in * s.w_in * cin + s.N * K) + (4 if s.out_dtype == _lib.OUT_F32 else 2) * M * n_out
+            if s.residual:
+                byt += 2 * M * n_out
+            return ("conv3x3" if s.ksize == 3 else "dense / conv1x1"), 2.0 * M * s.N * K, byt
+        if isinstance(s, _lib.MsdAttention):
+            fl = 4.0 * s.batch * s.heads * s.s * s.t * s.head_dim
+            byt = 2 * s.batch * s.heads * s.head_dim * (2 * s.s + 2 * s.t)
+            return ("self-attention" if s.s == s.t else "cross-attention"), fl, byt
+        if isinstance(s, _lib.MsdGroupNorm):
+            return "group_norm(+swish)", 0.0, 4 * s.batch * s.hw * (s.c0 + s.c1)
+        fn = c.fn.__name__ if hasattr(c.fn, "__name__") else str(c.fn)
+        if fn == "msd_layer_norm":
+            return "layer_norm", 0.0, 4 * c.args[4] * c.args[5]
+        return None, 0.0, 0
+
     for rep in range(reps + 1):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(calls) + 1)]
         evs[0].record(st)
@@ -180,6 +221,13 @@ def kernel_roofline(sd, b, nsteps, control=False):
                 M = s.batch * s.h_out * s.w_out
                 K = s.ksize * s.ksize * (s.c0 + s.c1)
                 d["flop"] += 2.0 * M * s.N * K / reps
+            k, fl, byt = work(c)
+            if k is not None:
+                e = klass.setdefault(k, {"ms": 0.0, "n": 0.0, "flop": 0.0, "bytes": 0.0})
+                e["ms"] += ms / reps
+                e["n"] += 1.0 / reps
+                e["flop"] += fl / reps
+                e["bytes"] += byt / reps
     eng.step_ptr.zero_()
     dump = os.environ.get("MSD_DUMP_CALLS")
     if dump:  # per-call table of the last repetition (shape, duration, achieved TFLOP/s)
@@ -212,11 +260,30 @@ def kernel_roofline(sd, b, nsteps, control=False):
     avg_ms = g["ms"] / n
     flop_per_launch = g["flop"] / n
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
+    # HBM-side bytes per launch come from the PMC pass committed under profiles/ (rocprofv3 --pmc cannot run
+    # inside this process); null when the file is missing
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            traffic = json.load(f).get("conv_gemm", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
+            "traffic": traffic, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
             "gflop_per_launch": round(flop_per_launch / 1e9, 3)}
-    return roof, extra
+    # per kernel class of one denoise step (event-per-launch pass: each duration includes ~1-2 us of event gap):
+    # MFMA utilisation of the contractions, achieved algorithmic HBM rate of everything
+    by_kernel = {}
+    for k, e in sorted(klass.items(), key=lambda kv: -kv[1]["ms"]):
+        sec = e["ms"] * 1e-3
+        row = {"launches": int(round(e["n"])), "ms": round(e["ms"], 3), "algorithmic_GBps": round(e["bytes"] / sec / 1e9, 1),
+               "hbm_frac": round(e["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)}
+        if e["flop"]:
+            row["TFLOPps"] = round(e["flop"] / sec / 1e12, 1)
+            row["mfma_frac"] = round(e["flop"] / sec / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        by_kernel[k] = row
+    return roof, by_kernel, extra
 
 
 def golden_psnr(sd, size, nsteps):
