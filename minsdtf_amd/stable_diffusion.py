@@ -20,6 +20,7 @@ through a user-supplied ``text_frontend``), inpainting, TCD.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, Optional
 
 import numpy as np
@@ -501,8 +502,12 @@ class StableDiffusion(StableDiffusionBase):
         self.text_encoder_ckpt = text_encoder_ckpt
         self.vae_ckpt = vae_ckpt
         self.controlnet_path = controlnet_path
-        self.lora_path = lora_path
+        self.lora_path = None
+        self.text_encoder_lora_dict = None
         self.unet_lora_dict = None
+        if lora_path is not None and os.path.exists(str(lora_path)):   # reference :641-643
+            self.text_encoder_lora_dict, self.unet_lora_dict = wtab.load_weights_from_lora(lora_path)
+            self.lora_path = lora_path
         self.device = device if device is not None else default_device()
 
     @property

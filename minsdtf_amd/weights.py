@@ -352,17 +352,20 @@ def read_state_dict(ckpt_path: str) -> Dict[str, np.ndarray]:
     return sd
 
 
-def load_weights_from_file(model, ckpt_path: str, kind: str, lora_dict: Optional[dict] = None) -> None:
+def load_weights_from_file(model, ckpt_path: str, kind: str, lora_dict: Optional[dict] = None,
+                           specs: Optional[List[WeightSpec]] = None) -> None:
     """Positional load with the reference's semantics (ckpt_loader.py:2136-2193).
 
     ``model`` exposes ``name``, ``weights`` (ordered objects with ``.shape``/``.name`` in Keras
-    layout) and ``set_weights(list)`` — the same surface the reference loader uses.
+    layout) and ``set_weights(list)`` — the same surface the reference loader uses.  ``specs``
+    overrides the table of ``kind`` (the reference passes the table as an argument too).
     """
     import os
 
     print("{} loading:[{}]".format(model.name, os.path.basename(ckpt_path)))
     sd = read_state_dict(ckpt_path)
-    specs = table(kind)
+    if specs is None:
+        specs = table(kind)
     out = []
     lora_keys = list(lora_dict.keys()) if lora_dict is not None else []
     lora_count, lora_idx = len(lora_keys), 0
@@ -388,3 +391,89 @@ def load_weights_from_file(model, ckpt_path: str, kind: str, lora_dict: Optional
         print("Apply {}/{} lora weights".format(lora_idx, lora_count))
     model.set_weights(out)
     print("Loaded %d weights for %s" % (len(out), model.name))
+
+
+# --------------------------------------------------------------------------------------
+# LoRA files (kohya naming) -> additive weight deltas (mirrors ckpt_loader.load_weights_from_lora)
+# --------------------------------------------------------------------------------------
+# The reference restores module names from the flattened kohya keys with a fixed list of string
+# substitutions (ckpt_loader.py:2236-2273); only these layer types come out with a usable name, the
+# others (conv_in, conv_out, time_embedding, norms) are never matched by the loader.  Here the
+# inverse map is built from the weight table instead: kohya name = "lora_unet_" + module path with
+# "." -> "_", restricted to the same layer types so that exactly the same deltas get applied.
+_LORA_UNET_SUFFIXES = ("proj_in", "proj_out", "attn1.to_q", "attn1.to_k", "attn1.to_v", "attn1.to_out.0", "attn2.to_q",
+                       "attn2.to_k", "attn2.to_v", "attn2.to_out.0", "ff.net.0.proj", "ff.net.2", "time_emb_proj",
+                       "conv_shortcut", "downsamplers.0.conv", "upsamplers.0.conv", "conv1", "conv2")
+_LORA_TE_SUFFIXES = ("mlp.fc1", "mlp.fc2", "self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj")
+_lora_unet_names: Optional[Dict[str, str]] = None
+
+
+def _lora_unet_name_map() -> Dict[str, str]:
+    global _lora_unet_names
+    if _lora_unet_names is None:
+        m = {}
+        for spec in table("civitai_model"):
+            if spec.alt_key is None or not spec.alt_key.endswith(".weight"):
+                continue
+            path = spec.alt_key[:-len(".weight")]
+            if path.endswith(_LORA_UNET_SUFFIXES):
+                m["lora_unet_" + path.replace(".", "_")] = spec.alt_key
+        _lora_unet_names = m
+    return _lora_unet_names
+
+
+def _lora_te_name(name: str) -> Optional[str]:
+    """lora_te_text_model_encoder_layers_<i>_<module> -> text_model.encoder.layers.<i>.<module>.weight"""
+    head = "lora_te_text_model_encoder_layers_"
+    if not name.startswith(head):
+        return None
+    idx, _, rest = name[len(head):].partition("_")
+    for suf in _LORA_TE_SUFFIXES:
+        if rest == suf.replace(".", "_"):
+            return f"text_model.encoder.layers.{idx}.{suf}.weight"
+    return None
+
+
+def lora_delta(lora_up, lora_down, alpha) -> np.ndarray:
+    """(alpha / rank) * up . down in the checkpoint (PyTorch) layout: Linear (out,in), 1x1 conv
+    (out,in,1,1) and 3x3 conv (out,in,3,3, `down` carries the taps) — ckpt_loader.py:2216-2230."""
+    import torch
+
+    up = torch.as_tensor(np.asarray(lora_up.detach().float().cpu() if hasattr(lora_up, "detach") else lora_up, dtype=np.float32))
+    down = torch.as_tensor(np.asarray(lora_down.detach().float().cpu() if hasattr(lora_down, "detach") else lora_down, dtype=np.float32))
+    a = np.asarray(alpha.detach().float().cpu() if hasattr(alpha, "detach") else alpha, dtype=np.float32)
+    scale = a / float(up.shape[1])
+    if down.dim() == 2:
+        w = up @ down
+    elif tuple(down.shape[2:4]) == (1, 1):
+        w = (up[:, :, 0, 0] @ down[:, :, 0, 0])[:, :, None, None]
+    else:
+        # out[o, i] = sum_r up[o, r] (*) down[r, i]: a conv of the per-input-channel taps with `up` as the filter
+        w = torch.nn.functional.conv2d(down.permute(1, 0, 2, 3), up).permute(1, 0, 2, 3)
+    return w.numpy() * scale
+
+
+def load_weights_from_lora(ckpt_path: str) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+    """LoRA file -> (text_encoder_deltas, unet_deltas), keyed by the diffusers weight names that
+    ``load_weights_from_file(..., lora_dict=)`` looks up (reference ckpt_loader.py:2196-2276).
+    The text-encoder half is returned for API parity; the CLIP front-end is outside this path."""
+    print("loading:[{}]".format(ckpt_path))
+    sd = read_state_dict(ckpt_path)
+    text_encoder, unet = {}, {}
+    names = _lora_unet_name_map()
+    for key in list(sd.keys()):
+        key = str(key)
+        if not key.endswith(".alpha"):
+            continue
+        name = key[:-len(".alpha")]
+        w = lora_delta(sd[name + ".lora_up.weight"], sd[name + ".lora_down.weight"], sd[key])
+        if name.startswith("lora_te_text_model"):
+            restored = _lora_te_name(name)
+            if restored is not None:
+                text_encoder[restored] = w
+        elif name.startswith("lora_unet_"):
+            restored = names.get(name)
+            if restored is not None:
+                unet[restored] = w
+    print("lora dict:[{}] done.".format(ckpt_path))
+    return text_encoder, unet

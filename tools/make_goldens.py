@@ -102,6 +102,113 @@ def fake_encoder(img):
     return np.concatenate([m, m.mean(axis=-1, keepdims=True)], axis=-1).astype(np.float32) * 0.7
 
 
+def lora_fixture(seed=11):
+    """A small kohya-style LoRA state dict: every UNet layer type the reference can restore (names made
+    from its own UNET_KEY_MAPPING), a few text-encoder entries and a few names it cannot restore."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    from minsdtf_amd import weights as W
+
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def add(name, shape_up, shape_down):
+        sd[name + ".lora_up.weight"] = torch.from_numpy(rng.standard_normal(shape_up).astype(np.float32))
+        sd[name + ".lora_down.weight"] = torch.from_numpy(rng.standard_normal(shape_down).astype(np.float32))
+        sd[name + ".alpha"] = torch.tensor(float(rng.integers(1, 9)))
+
+    for spec in W.table("civitai_model"):
+        if spec.alt_key is None or not spec.alt_key.endswith(".weight") or spec.kind not in ("conv_w", "dense_w"):
+            continue
+        name = "lora_unet_" + spec.alt_key[:-7].replace(".", "_")
+        ts = spec.torch_shape
+        if len(ts) == 2:
+            add(name, (4, 2), (2, 3))
+        elif ts[2] == 1:
+            add(name, (4, 2, 1, 1), (2, 3, 1, 1))
+        else:
+            add(name, (4, 2, 1, 1), (2, 3, 3, 3))
+    for i in (0, 11):
+        for mod in ("mlp_fc1", "mlp_fc2", "self_attn_q_proj", "self_attn_k_proj", "self_attn_v_proj", "self_attn_out_proj"):
+            add(f"lora_te_text_model_encoder_layers_{i}_{mod}", (4, 2), (2, 3))
+    return sd
+
+
+class FakeKerasModel:
+    """The loader surface of a Keras model: name, weights[i].shape/.name, set_weights."""
+
+    class _W:
+        def __init__(self, shape, name):
+            self.shape, self.name = tuple(shape), name
+
+    def __init__(self, name, specs):
+        self.name = name
+        self.weights = [self._W(s.shape, s.name) for s in specs]
+        self.loaded = None
+
+    def set_weights(self, ws):
+        self.loaded = [np.asarray(w) for w in ws]
+
+
+def digest_arrays(arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def make_loader_goldens(ck):
+    import tempfile
+
+    import torch
+    from safetensors.torch import save_file
+
+    sys.path.insert(0, ROOT)
+    from minsdtf_amd import weights as W
+
+    g8 = {}
+    with tempfile.TemporaryDirectory() as d:
+        # (a) LoRA file -> delta dicts through the reference's load_weights_from_lora
+        lpath = os.path.join(d, "lora.safetensors")
+        save_file(lora_fixture(), lpath)
+        te, un = ck.load_weights_from_lora(lpath)
+        # the reference also files the layers its substitutions cannot restore (conv_in, conv_out, time_embedding)
+        # under names no weight has; the loader never matches them — keep them apart
+        real = {s.alt_key for s in W.table("civitai_model") if s.alt_key}
+        g8["lora_unet_keys"] = sorted(k for k in un if k in real)
+        g8["lora_unet_unmatched"] = sorted(k for k in un if k not in real)
+        g8["lora_te_keys"] = sorted(te.keys())
+        g8["lora_unet_digest"] = digest_arrays([un[k] for k in g8["lora_unet_keys"]])
+        g8["lora_te_digest"] = digest_arrays([te[k] for k in sorted(te.keys())])
+        # (b) positional load through the reference's load_weights_from_file
+        #     hintnet: whole table, LDM keys only;  UNet: first 120 rows, half the tensors stored under the
+        #     diffusers (fallback) keys, with the LoRA deltas resized to the real shapes of those rows
+        for kind, nrows, use_alt, with_lora in (("hintnet", None, False, False), ("civitai_model", 120, True, True),
+                                                ("encoder", 30, False, False)):
+            specs = W.table(kind)[:nrows]
+            rng = np.random.default_rng(5)
+            sd, lora = {}, {}
+            for i, s in enumerate(specs):
+                w = rng.standard_normal(s.torch_shape).astype(np.float32)
+                key = s.alt_key if (use_alt and s.alt_key is not None and i % 2) else s.key
+                sd[key] = torch.from_numpy(w)
+                if with_lora and s.alt_key is not None and s.alt_key in un and i % 3 == 0:
+                    lora[s.alt_key] = rng.standard_normal(s.torch_shape).astype(np.float32) * 0.1
+            path = os.path.join(d, kind + ".safetensors")
+            save_file(sd, path)
+            fake = FakeKerasModel(kind, specs)
+            mapping = ck.CKPT_MAPPING[kind][:nrows] if nrows else ck.CKPT_MAPPING[kind]
+            ck.load_weights_from_file(fake, path, mapping, key_mapping=ck.UNET_KEY_MAPPING if use_alt else None,
+                                      lora_dict=dict(lora) if with_lora else None)
+            g8[f"load_{kind}_digest"] = digest_arrays(fake.loaded)
+            g8[f"load_{kind}_count"] = len(fake.loaded)
+            g8[f"load_{kind}_lora_applied"] = len(lora)
+    json.dump(g8, open(os.path.join(OUT, "g8_loaders.json"), "w"), indent=0, sort_keys=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # ---------------------------------------------------------------- G1 scheduler
@@ -229,6 +336,8 @@ def main():
           "expand_in": ctx[:5, :6], "expand_out": pipe._expand_tensor(ctx[:5, :6], 3),
           "expand_in_b": ctx[None, :5, :6], "expand_out_b": pipe._expand_tensor(ctx[None, :5, :6], 1)}
     np.savez_compressed(os.path.join(OUT, "g7_host_utils.npz"), **g7)
+    # ---------------------------------------------------------------- G8 checkpoint / LoRA loaders (§8f rank 2)
+    make_loader_goldens(ck)
     print("goldens written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:36s} {os.path.getsize(os.path.join(OUT, f)):8d} B")
