@@ -101,7 +101,8 @@ typedef struct MsdConvGemm {
                             falls back if not eligible).  The 80-wide tiles serve N = 320 / 640 at small batch, where
                             they make the workgroup count a multiple of the 256 CUs */
     int32_t stages;      /* 0 = default LDS ring depth of the tile; deeper rings built: 128x128:4 64x64:8 64x128:5 128x64:5
-                            128x80:4; halo tiles 1128x64:8 1128x128:6 1128x80:8 1256x80:5 (an unknown depth = the default) */
+                            128x80:4; halo tiles 1128x64:8 1128x128:6 1128x80:8 1256x80:5 (an unknown depth = the default);
+                            10 + depth = the tile on 8 waves (two per SIMD): 64x64:14 128x64:13 64x128:13 */
 } MsdConvGemm;
 
 int msd_conv_gemm(const MsdConvGemm* p, msd_stream_t stream);

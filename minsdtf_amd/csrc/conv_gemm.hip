@@ -312,26 +312,33 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, in
 // ---- tile configurations of the LDS-DMA kernel ------------------------------------------------
 struct TileCfg { int bm, bn, threads, lds, stages; };
 #define MSD_TILE_CFGS(X) \
-    X(0, 128, 128, 2, 4, 3) \
-    X(1, 128, 64, 2, 2, 3)  \
-    X(2, 64, 64, 2, 2, 4)   \
-    X(3, 64, 128, 2, 2, 3)  \
-    X(4, 256, 128, 4, 2, 3) \
-    X(5, 128, 128, 2, 4, 4) \
-    X(6, 64, 64, 2, 2, 8)   \
-    X(7, 64, 128, 2, 2, 5)  \
-    X(8, 128, 64, 2, 2, 5)  \
-    X(9, 128, 80, 4, 1, 3)  \
-    X(10, 128, 80, 4, 1, 4)
+    X(0, 128, 128, 2, 4, 3, 3) \
+    X(1, 128, 64, 2, 2, 3, 3)  \
+    X(2, 64, 64, 2, 2, 4, 4)   \
+    X(3, 64, 128, 2, 2, 3, 3)  \
+    X(4, 256, 128, 4, 2, 3, 3) \
+    X(5, 128, 128, 2, 4, 4, 4) \
+    X(6, 64, 64, 2, 2, 8, 8)   \
+    X(7, 64, 128, 2, 2, 5, 5)  \
+    X(8, 128, 64, 2, 2, 5, 5)  \
+    X(9, 128, 80, 4, 1, 3, 3)  \
+    X(10, 128, 80, 4, 1, 4, 4) \
+    X(11, 64, 64, 2, 4, 4, 14) \
+    X(12, 128, 64, 4, 2, 3, 13) \
+    X(13, 64, 128, 2, 4, 3, 13)
+// Last column = the `stages` request that selects the entry (the first entry of a tile size is its
+// default).  Codes 10 + depth are the same tile on 8 waves (32x16 / 32x32 per wave): two waves per SIMD
+// even when a launch puts one workgroup on a CU, so one wave's LDS-DMA issue and LDS latency overlap the
+// other's MFMAs.
 // (128x80: for N = 320 / 640 at small batch — 64 x 4 = 256 workgroups at M = 8192, one per CU, where
 //  64-wide tiles make 320 and 128-wide ones 192; the 80 weight rows are staged as 96)
 constexpr int cfg_lds(int bm, int bn, int threads, int st) { return st * (bm + (bn + threads / 8 - 1) / (threads / 8) * (threads / 8)) * 128; }
 static const TileCfg g_cfgs[] = {
-#define X(id, bm, bn, wgm, wgn, st) {bm, bn, wgm * wgn * 64, cfg_lds(bm, bn, wgm * wgn * 64, st), st},
+#define X(id, bm, bn, wgm, wgn, st, code) {bm, bn, wgm * wgn * 64, cfg_lds(bm, bn, wgm * wgn * 64, st), code},
     MSD_TILE_CFGS(X)
 #undef X
 };
-constexpr int NUM_TILE_CFGS = 11;
+constexpr int NUM_TILE_CFGS = 14;
 
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream);
 
@@ -347,7 +354,7 @@ int msd_conv_gemm_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128);
-#define X(id, bm, bn, wgm, wgn, st)                                                                          \
+#define X(id, bm, bn, wgm, wgn, st, code)                                                                    \
     if (e == hipSuccess)                                                                                     \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<bm, bn, wgm, wgn, st>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg_lds(bm, bn, wgm * wgn * 64, st));
@@ -473,8 +480,10 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         return MSD_OK;
     }
     int cfg = -1;
+    // (GEGLU pairs the fragments of a wave: the 8-wave 64x64 tile has a single one per wave)
+    const int stages_req = (q->act == MSD_ACT_GEGLU && q->stages >= 10) ? 0 : q->stages;
     for (int i = 0; i < NUM_TILE_CFGS; ++i)
-        if (g_cfgs[i].bm == bm && g_cfgs[i].bn == bn && (cfg < 0 || g_cfgs[i].stages == q->stages)) cfg = i;
+        if (g_cfgs[i].bm == bm && g_cfgs[i].bn == bn && (cfg < 0 || g_cfgs[i].stages == stages_req)) cfg = i;
     // (the first entry of a tile size is its default ring depth; `stages` selects a deeper ring: more
     //  bytes in flight per CU for the weight-streaming small-M layers that run one workgroup per CU)
     if (cfg < 0 || (g_conv_impl != 1 && bm != 128))
@@ -486,7 +495,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     dim3 grid(tiles_m * a.tiles_n, slices);
     if (g_conv_impl == 1) {
         switch (cfg) {
-#define X(id, bm_, bn_, wgm, wgn, st)                                                                                   \
+#define X(id, bm_, bn_, wgm, wgn, st, code)                                                                             \
     case id:                                                                                                            \
         hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st>), grid, dim3(wgm * wgn * 64),                  \
                            cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, a);                                           \

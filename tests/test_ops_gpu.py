@@ -68,6 +68,9 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=1, H=32, W=32, c0=256, N=160, ks=3, tile_m=1256, tile_n=80, stages=5),
     dict(B=2, H=16, W=16, c0=128, N=192, ks=3, tile_m=2128, tile_n=64),              # 8x16 tiles on 8 waves
     dict(B=1, H=16, W=32, c0=64, c1=64, N=320, ks=3, tile_m=2128, tile_n=80, splitk=2),
+    dict(B=2, H=12, W=20, c0=128, N=192, ks=3, tile_m=64, tile_n=64, stages=14),     # 8-wave variants of the small tiles
+    dict(B=2, H=12, W=20, c0=64, c1=64, N=192, ks=1, tile_m=128, tile_n=64, stages=13, splitk=2),
+    dict(B=1, H=8, W=8, c0=256, N=320, ks=3, tile_m=64, tile_n=128, stages=13, stride=2),
     dict(B=2, H=12, W=20, c0=128, N=320, ks=1, tile_m=128, tile_n=80),               # generic 128x80, ragged M
     dict(B=2, H=12, W=20, c0=192, N=168, ks=3, tile_m=128, tile_n=80, stages=4, splitk=3),
     dict(B=2, H=16, W=16, c0=128, N=128, ks=3, stride=2, asym=True),                 # VAE encoder downsampler: pad bottom/right only
