@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 1
+#define MSD_ABI_VERSION 2
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -64,6 +64,7 @@ int msd_set_option(const char* key, int value);
 #define MSD_ACT_NONE 0
 #define MSD_ACT_SILU 1
 #define MSD_ACT_GEGLU 2 /* W rows interleaved in 16-column x|gate groups; writes N/2 columns */
+#define MSD_ACT_QUICK_GELU 3 /* x * sigmoid(1.702 x)  (CLIP MLP, text_encoder.py:100-101) */
 
 #define MSD_OUT_BF16 0
 #define MSD_OUT_F32 1
@@ -180,7 +181,8 @@ int msd_layer_norm(const void* x, const float* gamma, const float* beta, void* o
  *       vt_ld >= t; columns >= t are padding and are ignored)
  *   out: bf16 [batch][s][o_ld]
  *   softmax(scale * q k^T) v, scale applied to the scores (diffusion_model.py:105,123).
- * head_dim in {40, 80, 160}.
+ * head_dim in {40, 80, 160} (UNet) and 64 (CLIP text encoder).  causal != 0 (needs s == t) masks
+ * key index > query index, the additive -inf upper triangle of text_encoder.py:75-78.
  */
 typedef struct MsdAttention {
     const void* q;
@@ -191,6 +193,7 @@ typedef struct MsdAttention {
     int32_t s, t;
     int32_t q_ld, k_ld, vt_ld, o_ld;
     float scale;
+    int32_t causal;
 } MsdAttention;
 
 int msd_attention(const MsdAttention* p, msd_stream_t stream);
@@ -199,6 +202,14 @@ int msd_attention(const MsdAttention* p, msd_stream_t stream);
  * [rows][ld_out] (VAE single-head attention, layers.py:48-50). cols % 8 == 0. */
 int msd_softmax_rows(const float* x, void* out, int64_t rows, int32_t cols, int32_t ld_in, int32_t ld_out, float scale,
                      msd_stream_t stream);
+
+/* msd_embedding_sum — out[r, :] = bf16(tok_table[tokens[r], :] + pos_table[positions[r], :]).
+ * Replaces CLIPEmbedding.call (text_encoder.py:22-33): two Embedding lookups and their sum.
+ * tables fp32 [vocab][dim] / [max_len][dim], tokens / positions int32 [rows], dim % 4 == 0; ids outside
+ * their table are an argument error reported through `status` (device int32, set to 1; may be NULL). */
+int msd_embedding_sum(const int32_t* tokens, const int32_t* positions, const float* tok_table, const float* pos_table,
+                      void* out, int32_t rows, int32_t dim, int32_t vocab, int32_t max_len, int32_t* status,
+                      msd_stream_t stream);
 
 /* msd_memset_zero — stream-ordered hipMemsetAsync(ptr, 0, bytes) (GroupNorm statistic slots). */
 int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream);

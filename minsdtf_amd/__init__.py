@@ -11,7 +11,7 @@ def __getattr__(name):
     if name in ("StableDiffusion", "StableDiffusionBase"):
         from . import stable_diffusion as m
         return getattr(m, name)
-    if name in ("DiffusionModel", "ImageDecoder", "ControlNet", "HintNet"):
+    if name in ("DiffusionModel", "ImageDecoder", "ImageEncoder", "ControlNet", "HintNet", "TextEncoder", "TextClipEmbedding"):
         from . import models as m
         return getattr(m, name)
     raise AttributeError(name)

@@ -11,9 +11,9 @@ import os
 
 LIB_NAME = "libminsdtf_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
 
 
@@ -59,6 +59,7 @@ class MsdAttention(C.Structure):
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
         ("batch", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("s", C.c_int32), ("t", C.c_int32),
         ("q_ld", C.c_int32), ("k_ld", C.c_int32), ("vt_ld", C.c_int32), ("o_ld", C.c_int32), ("scale", C.c_float),
+        ("causal", C.c_int32),
     ]
 
 
@@ -85,6 +86,8 @@ SYMBOLS = {
     "msd_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                    C.c_void_p]),
     "msd_memset_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "msd_embedding_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.c_void_p]),
     "msd_cfg_step": (C.c_int, [C.POINTER(MsdCfgStep), C.c_void_p]),
     "msd_add_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "msd_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -25,6 +25,7 @@ struct AArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* out;
     int batch, heads, s, t, q_ld, k_ld, vt_ld, o_ld;
     float sl2;  // scale * log2(e)
+    int causal; // key index > query index is masked (CLIP text encoder, text_encoder.py:75-78)
 };
 
 template <int D, bool PIPE>
@@ -214,6 +215,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                 for (int e = 0; e < 4; ++e)
                     if (t0 + kf * 16 + 4 * g + e >= p.t) { sacc[kf][0][e] = -1e30f; sacc[kf][1][e] = -1e30f; }
         }
+        if (p.causal) {       // every query keeps key 0, so no row is ever fully masked
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int qi = q0 + f * 16 + r;
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (t0 + kf * 16 + 4 * g + e > qi) sacc[kf][f][e] = -1e30f;
+            }
+        }
         bf16x8 pb[2][2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -320,6 +332,9 @@ int msd_attention_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<160, attn_pipe<160>()>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<160>());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<64, attn_pipe<64>()>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<64>());
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
     g_attn_attr_done = true;
     return MSD_OK;
@@ -343,12 +358,15 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     a.batch = q->batch; a.heads = q->heads; a.s = q->s; a.t = q->t;
     a.q_ld = q->q_ld; a.k_ld = q->k_ld; a.vt_ld = q->vt_ld; a.o_ld = q->o_ld;
     a.sl2 = q->scale * 1.4426950408889634f;
+    a.causal = q->causal ? 1 : 0;
+    if (a.causal && q->s != q->t) MSD_FAIL(MSD_E_ARG, "attention: causal masking needs s == t");
     dim3 grid(((q->s + 127) / 128) * q->heads * q->batch);
     switch (q->head_dim) {
         case 40: hipLaunchKernelGGL((attention_kernel<40, attn_pipe<40>()>), grid, dim3(256), attn_lds_bytes<40>(), stream, a); break;
         case 80: hipLaunchKernelGGL((attention_kernel<80, attn_pipe<80>()>), grid, dim3(256), attn_lds_bytes<80>(), stream, a); break;
         case 160: hipLaunchKernelGGL((attention_kernel<160, attn_pipe<160>()>), grid, dim3(256), attn_lds_bytes<160>(), stream, a); break;
-        default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 80, 160)", q->head_dim);
+        case 64: hipLaunchKernelGGL((attention_kernel<64, attn_pipe<64>()>), grid, dim3(256), attn_lds_bytes<64>(), stream, a); break;
+        default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 64, 80, 160)", q->head_dim);
     }
     MSD_CHECK_LAUNCH();
     return MSD_OK;

@@ -30,6 +30,9 @@ __device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, 
     if (p.act == MSD_ACT_SILU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    } else if (p.act == MSD_ACT_QUICK_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_rcp(1.0f + __expf(-1.702f * v[e]));
     }
     if (p.split_mode == 0) {
         if (p.residual) {

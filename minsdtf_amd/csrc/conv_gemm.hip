@@ -400,7 +400,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         MSD_FAIL(MSD_E_ALIGN, "conv_gemm: pointers must be 16-byte aligned");
     if ((q->out_ld % 4) || (q->residual && (q->res_ld % 4)) || (q->rv_step_stride % 4) || (q->rv_batch_stride % 4))
         MSD_FAIL(MSD_E_ALIGN, "conv_gemm: leading dimensions must be multiples of 4");
-    if (q->act < 0 || q->act > 2) MSD_FAIL(MSD_E_ARG, "conv_gemm: act");
+    if (q->act < 0 || q->act > 3) MSD_FAIL(MSD_E_ARG, "conv_gemm: act");
     if (q->act == MSD_ACT_GEGLU && ((q->N % 32) || q->out_dtype != MSD_OUT_BF16 || q->split_mode || q->rowvec))
         MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: GEGLU needs N%%32==0, bf16 out, plain mode");
     if (q->split_mode) {

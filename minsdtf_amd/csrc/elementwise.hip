@@ -129,3 +129,40 @@ extern "C" int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream_) {
     if (e != hipSuccess) MSD_FAIL((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
     return MSD_OK;
 }
+
+
+// ---- CLIP token + position embedding (text_encoder.py:22-33) ------------------------------------
+__global__ __launch_bounds__(256) void embedding_sum_kernel(const int32_t* tokens, const int32_t* positions, const float* tok,
+                                                            const float* pos, bf16_t* out, int rows, int dim, int vocab,
+                                                            int max_len, int32_t* status) {
+    const int nq = dim >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)rows * nq) return;
+    const int r = (int)(idx / nq), c = (int)(idx - (long long)r * nq) * 4;
+    int ti = tokens[r], pi = positions[r];
+    if ((unsigned)ti >= (unsigned)vocab || (unsigned)pi >= (unsigned)max_len) {
+        if (status) *status = 1;
+        ti = 0; pi = 0;
+    }
+    const float4 a = *reinterpret_cast<const float4*>(tok + (size_t)ti * dim + c);
+    const float4 b = *reinterpret_cast<const float4*>(pos + (size_t)pi * dim + c);
+    uint2 o;
+    o.x = pack_bf2(a.x + b.x, a.y + b.y);
+    o.y = pack_bf2(a.z + b.z, a.w + b.w);
+    *reinterpret_cast<uint2*>(out + (size_t)r * dim + c) = o;
+}
+
+extern "C" int msd_embedding_sum(const int32_t* tokens, const int32_t* positions, const float* tok_table, const float* pos_table,
+                                 void* out, int32_t rows, int32_t dim, int32_t vocab, int32_t max_len, int32_t* status,
+                                 msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!tokens || !positions || !tok_table || !pos_table || !out) MSD_FAIL(MSD_E_ARG, "embedding_sum: null pointer");
+    if (rows <= 0 || dim <= 0 || (dim % 4) || vocab <= 0 || max_len <= 0) MSD_FAIL(MSD_E_ARG, "embedding_sum: bad dims");
+    if (!msd_aligned16(tok_table) || !msd_aligned16(pos_table) || (((uintptr_t)out) & 7u))
+        MSD_FAIL(MSD_E_ALIGN, "embedding_sum: tables must be 16-byte aligned, out 8-byte aligned");
+    const long long n = (long long)rows * (dim / 4);
+    hipLaunchKernelGGL(embedding_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tokens, positions,
+                       tok_table, pos_table, (bf16_t*)out, rows, dim, vocab, max_len, status);
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}

@@ -608,3 +608,34 @@ def emit_encoder(e: Emitter, image_f32, B: int, H: int, W: int, latent_out_f32) 
     p.rec(ops.conv_direct, x=m.buf, w=e.W["quant_conv.mean.w"], bias=e.W["quant_conv.mean.b"], out=latent_out_f32, batch=B,
           h_in=m.H, w_in=m.W, c_in=8, c_out=4, ksize=1, in_dtype=ops.OUT_F32, out_dtype=ops.OUT_F32, name="quant_conv.mean")
     p.free(m)
+
+
+def emit_text_encoder(e: Emitter, x: Act, n_layers: int, heads: int = 12) -> Act:
+    """CLIP text transformer (text_encoder.py:36-58,104-113): n_layers x [LN -> causal self-attention
+    (q/k/v/out Dense with bias, scale on the scores) -> +x -> LN -> fc1 -> quick_gelu -> fc2 -> +x],
+    then the final LayerNorm.  x: bf16 tokens [B][T][768]; the layers after out[clip_skip] are not built."""
+    p = e.p
+    B, T, C = x.B, x.H, x.C
+    d = C // heads
+    Tp = (T + 7) // 8 * 8
+    for i in range(n_layers):
+        ln = f"text_model.encoder.layers.{i}"
+        h = e.layer_norm(x, ln + ".layer_norm1")
+        q, k = p.act(B, T, 1, C), p.act(B, T, 1, C)
+        vt = p.alloc(B * C * Tp * 2)
+        e.conv(h, ln + ".self_attn.qkv", 3 * C, split=(C, C, q.buf, k.buf, vt, Tp))
+        p.free(h)
+        o = p.act(B, T, 1, C)
+        p.rec(ops.attention, q=q.buf, k=k.buf, vt=vt, out=o.buf, batch=B, heads=heads, head_dim=d, s=T, t=T, q_ld=C, k_ld=C,
+              vt_ld=Tp, o_ld=C, scale=float(d) ** -0.5, causal=True, name=ln + ".self_attn")
+        p.free(q, k, vt)
+        x2 = e.conv(o, ln + ".self_attn.out_proj", C, residual=x)
+        p.free(o, x)
+        h = e.layer_norm(x2, ln + ".layer_norm2")
+        f = e.conv(h, ln + ".mlp.fc1", 4 * C, act=ops.ACT_QUICK_GELU)
+        p.free(h)
+        x = e.conv(f, ln + ".mlp.fc2", C, residual=x2)
+        p.free(f, x2)
+    out = e.layer_norm(x, "text_model.final_layer_norm")
+    p.free(x)
+    return out

@@ -63,12 +63,15 @@ class HipModel:
         self.device = device if device is not None else default_device()
         lib = _lib.load()
         _lib.check(lib.msd_init(), "msd_init")
-        self._specs = wtab.table(self.kind)
+        self._specs = wtab.table(self.kind, **self._table_kw())
         self.weights: List[WeightVar] = [
             WeightVar(s.name + (".kernel" if s.kind.endswith("_w") else "." + s.kind), s.shape) for s in self._specs]
         self._W: Optional[Dict[str, torch.Tensor]] = None
         self._plans: Dict[tuple, "_BoundPlan"] = {}
         self._use_graph = False
+
+    def _table_kw(self) -> dict:
+        return {}
 
     # ---- Keras-like surface
     def compile(self, jit_compile=True, **_):
@@ -94,14 +97,14 @@ class HipModel:
 
     def load_synthetic(self, seed=0, bias_scale=0.0) -> List[np.ndarray]:
         """Fill with the seeded synthetic checkpoint; returns the Keras-layout list."""
-        arrays = wtab.synth_keras_weights(self.kind, seed=seed, bias_scale=bias_scale)
+        arrays = wtab.synth_keras_weights(self.kind, seed=seed, bias_scale=bias_scale, **self._table_kw())
         self.set_weights(arrays)
         return arrays
 
     def _maybe_load(self, ckpt_path, lora_dict=None):
         """Reference constructors load a local checkpoint if given one; no network download here."""
         if ckpt_path is not None and os.path.exists(ckpt_path):
-            wtab.load_weights_from_file(self, ckpt_path, self.kind, lora_dict=lora_dict)
+            wtab.load_weights_from_file(self, ckpt_path, self.kind, lora_dict=lora_dict, specs=self._specs)
 
     # ---- packing
     def _pack(self, named) -> Dict[str, torch.Tensor]:
@@ -132,7 +135,7 @@ class HipModel:
                 W[n + ".w"], W[n + ".b"] = packing.pack_geglu(dw, b, d)
                 continue
             if n.endswith((".attn1.to_q", ".attn1.to_k", ".attn1.to_v", ".attn2.to_k", ".attn2.to_v",
-                           ".query", ".key", ".value")):
+                           ".query", ".key", ".value", ".self_attn.q_proj", ".self_attn.k_proj", ".self_attn.v_proj")):
                 continue  # stacked below
             if cw is not None:
                 W[n + ".w"] = packing.pack_conv(cw, d)
@@ -148,10 +151,11 @@ class HipModel:
             elif n.endswith(".attn2.to_k"):
                 base = n[: -len(".to_k")]
                 W[base + ".kv.w"] = packing.pack_dense_stack([get(base + ".to_k", "dense_w"), get(base + ".to_v", "dense_w")], d)
-            elif n.endswith(".query"):
-                base = n[: -len(".query")]
-                W[base + ".qkv.w"] = packing.pack_dense_stack([get(base + "." + k, "dense_w") for k in ("query", "key", "value")], d)
-                W[base + ".qkv.b"] = packing.dev_f32(np.concatenate([get(base + "." + k, "bias") for k in ("query", "key", "value")]), d)
+            elif n.endswith(".query") or n.endswith(".self_attn.q_proj"):
+                trio = ("query", "key", "value") if n.endswith(".query") else ("q_proj", "k_proj", "v_proj")
+                base = n[: -len("." + trio[0])]
+                W[base + ".qkv.w"] = packing.pack_dense_stack([get(base + "." + k, "dense_w") for k in trio], d)
+                W[base + ".qkv.b"] = packing.dev_f32(np.concatenate([get(base + "." + k, "bias") for k in trio]), d)
         if tproj_w:
             W["time_emb_proj_cat.w"] = packing.dev_f32(np.concatenate(tproj_w, axis=1).reshape(1, 1, 1280, -1), d)
             W["time_emb_proj_cat.b"] = packing.dev_f32(np.concatenate(tproj_b), d)
@@ -449,5 +453,106 @@ class ImageEncoder(HipModel):
         bp.io["image"].copy_(torch.from_numpy(img))
         bp.run()
         return bp.io["latent"].cpu().numpy()
+
+    __call__ = predict_on_batch
+
+
+class TextClipEmbedding(HipModel):
+    """CLIP token + position embedding (reference text_encoder.py:104-121): [tokens, positions] int32
+    (B, 77) -> (B, 77, 768)."""
+    kind = "text_clip_embedding"
+
+    def __init__(self, max_length=77, embed_dim=768, vocab_size=49408, name=None, ckpt_path=None, device=None):
+        if (max_length, embed_dim, vocab_size) != (wtab.CLIP_MAX_LEN, wtab.CLIP_DIM, wtab.CLIP_VOCAB):
+            raise ValueError("only the SD1.5 CLIP ViT-L/14 text model geometry is built (77, 768, 49408)")
+        super().__init__(name or "text_clip_embedding", device)
+        self._maybe_load(ckpt_path)
+
+    def _pack(self, named):
+        return {s.name: packing.dev_f32(named[(s.name, s.kind)], self.device) for s in self._specs}
+
+    def emit(self, plan: engine.Plan, tokens, positions, out: engine.Act, status) -> None:
+        plan.rec(ops.embedding_sum, tokens=tokens, positions=positions,
+                 tok_table=self._W["text_model.embeddings.token_embedding"],
+                 pos_table=self._W["text_model.embeddings.position_embedding"], out=out.buf, rows=out.M, dim=wtab.CLIP_DIM,
+                 vocab=wtab.CLIP_VOCAB, max_len=wtab.CLIP_MAX_LEN, status=status, name="text_model.embeddings")
+
+    def _build(self, B, T) -> _BoundPlan:
+        plan = engine.Plan(self.device)
+        tok, pos = plan.alloc(B * T * 4), plan.alloc(B * T * 4)
+        x = plan.act(B, T, 1, wtab.CLIP_DIM)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.emit(plan, tok, pos, x, status)
+        o32 = plan.alloc(x.M * wtab.CLIP_DIM * 4)
+        plan.rec(ops.cast_bf16_to_f32, x=x.buf, out=o32, n=x.M * wtab.CLIP_DIM, name="clip_emb.f32")
+        plan.finalize()
+        bp = _BoundPlan(plan, self._use_graph)
+        bp.io["tokens"], bp.io["positions"] = tok.tensor(torch.int32, (B, T)), pos.tensor(torch.int32, (B, T))
+        bp.io["emb"], bp.io["status"] = o32.tensor(torch.float32, (B, T, wtab.CLIP_DIM)), status
+        return bp
+
+    def predict_on_batch(self, x):
+        tokens, positions = (np.ascontiguousarray(np.asarray(a), dtype=np.int32) for a in x)
+        positions = np.array(np.broadcast_to(positions, tokens.shape), dtype=np.int32)
+        B, T = tokens.shape
+        bp = self._bound((B, T), lambda: self._build(B, T))
+        bp.io["tokens"].copy_(torch.from_numpy(tokens))
+        bp.io["positions"].copy_(torch.from_numpy(positions))
+        bp.run()
+        if int(bp.io["status"].item()):
+            bp.io["status"].zero_()
+            raise ValueError("token / position id outside the embedding table")
+        return bp.io["emb"].cpu().numpy()
+
+    __call__ = predict_on_batch
+
+
+class TextEncoder(HipModel):
+    """CLIP text transformer (reference text_encoder.py:123-169): clip_emb (B, 77, 768) -> final
+    LayerNorm of the output of layer `clip_skip` (B, 77, 768)."""
+    kind = "text_encoder"
+
+    def __init__(self, max_length=77, embed_dim=768, num_heads=12, num_layers=12, clip_skip=-2, name=None, ckpt_path=None,
+                 lora_dict=None, device=None):
+        if (embed_dim, num_heads, num_layers) != (wtab.CLIP_DIM, wtab.CLIP_HEADS, wtab.CLIP_LAYERS):
+            raise ValueError("only the SD1.5 CLIP ViT-L/14 text model geometry is built (768, 12 heads, 12 layers)")
+        if not -num_layers <= clip_skip <= -1:
+            raise ValueError("clip_skip must be in [-num_layers, -1]")
+        self.clip_skip, self.max_length = clip_skip, max_length
+        super().__init__(name or "text_encoder", device)
+        self._maybe_load(ckpt_path, lora_dict)
+
+    def _table_kw(self):
+        return {"clip_skip": self.clip_skip}
+
+    def count_params(self) -> int:
+        return int(sum(int(np.prod(s.shape)) for s in self._specs))
+
+    @property
+    def n_layers(self) -> int:
+        return wtab.CLIP_LAYERS + self.clip_skip + 1
+
+    def _build(self, B, T) -> _BoundPlan:
+        plan = engine.Plan(self.device)
+        e = engine.Emitter(plan, self._W)
+        C = wtab.CLIP_DIM
+        x32 = plan.alloc(B * T * C * 4)
+        x = plan.act(B, T, 1, C)
+        plan.rec(ops.cast_f32_to_bf16, x=x32, out=x.buf, n=B * T * C, name="clip_emb.bf16")
+        y = engine.emit_text_encoder(e, x, self.n_layers)
+        o32 = plan.alloc(B * T * C * 4)
+        plan.rec(ops.cast_bf16_to_f32, x=y.buf, out=o32, n=B * T * C, name="context.f32")
+        plan.finalize()
+        bp = _BoundPlan(plan, self._use_graph)
+        bp.io["emb"], bp.io["context"] = x32.tensor(torch.float32, (B, T, C)), o32.tensor(torch.float32, (B, T, C))
+        return bp
+
+    def predict_on_batch(self, x):
+        emb = _np32(x)
+        B, T, _ = emb.shape
+        bp = self._bound((B, T), lambda: self._build(B, T))
+        bp.io["emb"].copy_(torch.from_numpy(emb))
+        bp.run()
+        return bp.io["context"].cpu().numpy()
 
     __call__ = predict_on_batch

@@ -12,7 +12,7 @@ import ctypes as C
 from typing import Optional
 
 from . import _lib
-from ._lib import ACT_GEGLU, ACT_NONE, ACT_SILU, OUT_BF16, OUT_F32, OUT_U8  # noqa: F401
+from ._lib import ACT_GEGLU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, OUT_BF16, OUT_F32, OUT_U8  # noqa: F401
 
 
 class Call:
@@ -112,12 +112,14 @@ def layer_norm(*, x, gamma, beta, out, rows, c, eps=1e-5, name="layer_norm") -> 
     return Call(lib.msd_layer_norm, (_p(x), _p(gamma), _p(beta), _p(out), rows, c, C.c_float(eps)), name)
 
 
-def attention(*, q, k, vt, out, batch, heads, head_dim, s, t, q_ld, k_ld, vt_ld, o_ld, scale, name="attention") -> Call:
+def attention(*, q, k, vt, out, batch, heads, head_dim, s, t, q_ld, k_ld, vt_ld, o_ld, scale, causal=False,
+              name="attention") -> Call:
     lib = _lib.load()
     a = _lib.MsdAttention()
     a.q, a.k, a.vt, a.out = _p(q), _p(k), _p(vt), _p(out)
     a.batch, a.heads, a.head_dim, a.s, a.t = batch, heads, head_dim, s, t
     a.q_ld, a.k_ld, a.vt_ld, a.o_ld, a.scale = q_ld, k_ld, vt_ld, o_ld, float(scale)
+    a.causal = int(bool(causal))
     return Call(lib.msd_attention, (C.byref(a),), name, keep=a)
 
 
@@ -149,6 +151,13 @@ def cast_f32_to_bf16(*, x, out, n, name="cast_f2b") -> Call:
 def cast_bf16_to_f32(*, x, out, n, name="cast_b2f") -> Call:
     lib = _lib.load()
     return Call(lib.msd_cast_bf16_to_f32, (_p(x), _p(out), n), name)
+
+
+def embedding_sum(*, tokens, positions, tok_table, pos_table, out, rows, dim, vocab, max_len, status=None,
+                  name="embedding_sum") -> Call:
+    lib = _lib.load()
+    return Call(lib.msd_embedding_sum, (_p(tokens), _p(positions), _p(tok_table), _p(pos_table), _p(out), rows, dim, vocab, max_len,
+                                        _p(status)), name)
 
 
 def memset_zero(*, ptr, nbytes, name="memset") -> Call:

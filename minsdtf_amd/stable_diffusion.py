@@ -28,7 +28,8 @@ import torch
 
 from . import engine, ops
 from . import weights as wtab
-from .models import ControlNet, DiffusionModel, HintNet, ImageDecoder, ImageEncoder, _BoundPlan, _skip_hw, default_device
+from .models import (ControlNet, DiffusionModel, HintNet, ImageDecoder, ImageEncoder, TextClipEmbedding, TextEncoder, _BoundPlan,
+                     _skip_hw, default_device)
 from .scheduler import Scheduler
 
 MAX_PROMPT_LENGTH = 77
@@ -310,25 +311,54 @@ class StableDiffusionBase:
                                    guidance_rescale=guidance_rescale, callback=callback, **kw)
 
     def encode_text(self, prompt, embedding_data=None):
-        """Prompt -> context (77k, 768).  The CLIP front-end is outside the accelerated path
-        (SURVEY.md §8f rank 3): pass an embedding array, or install ``text_frontend`` (any object
-        with ``encode(prompt, embedding_data) -> ndarray``)."""
-        if isinstance(prompt, (np.ndarray, torch.Tensor)):
+        """Prompt -> context (77k, 768).  Accepted forms:
+        * a float array: an already encoded context, returned as is;
+        * an integer array of CLIP token ids, (77,) or (k, 77) (start / end / padding tokens included):
+          run through the CLIP embedding + text transformer on the device (SURVEY.md §8f rank 3);
+          k chunks are concatenated along the token axis like the reference's long prompts;
+        * a string: needs the BPE tokenizer and prompt weighting, which are not rebuilt here (the vocabulary
+          file is a download) — install ``text_frontend`` (any object with
+          ``encode(prompt, embedding_data) -> ndarray``)."""
+        if isinstance(prompt, torch.Tensor):
+            prompt = prompt.detach().cpu().numpy()
+        if isinstance(prompt, np.ndarray):
+            if np.issubdtype(prompt.dtype, np.integer):
+                return self.encode_tokens(prompt)
             return np.asarray(prompt, dtype=np.float32)
         if self.text_frontend is not None:
             return np.asarray(self.text_frontend.encode(prompt, embedding_data), dtype=np.float32)
         raise NotImplementedError(
-            "string prompts need the CLIP text front-end, which this path does not accelerate; pass the "
-            "(77k,768) text embedding instead of a string, or set StableDiffusion.text_frontend")
+            "string prompts need the CLIP tokenizer, which this path does not rebuild; pass CLIP token ids "
+            "(int array (77,)), the (77k,768) text embedding, or set StableDiffusion.text_frontend")
+
+    def encode_tokens(self, tokens) -> np.ndarray:
+        """CLIP token ids (k, 77) -> context (77k, 768): embedding lookup + text transformer on the device
+        (reference stable_diffusion.py:488-493 for the unconditional tokens; long_prompt_weighting.py feeds
+        the same two models chunk by chunk)."""
+        tokens = np.asarray(tokens, dtype=np.int32).reshape(-1, MAX_PROMPT_LENGTH)
+        emb = self.text_clip_embedding.predict_on_batch([tokens, self._get_pos_ids()])
+        ctx = self.text_encoder.predict_on_batch(emb)
+        return np.asarray(ctx, dtype=np.float32).reshape(-1, ctx.shape[-1])
+
+    @staticmethod
+    def _get_pos_ids():
+        return np.asarray([list(range(MAX_PROMPT_LENGTH))], dtype=np.int32)
+
+    def _text_models_ready(self) -> bool:
+        return False
 
     def _get_unconditional_context(self):
         if self.unconditional_context is None:
             if self.text_frontend is not None:
                 self.unconditional_context = np.asarray(self.text_frontend.encode("", None), dtype=np.float32)
+            elif self._text_models_ready():
+                # reference :488-493: start token + 76 end tokens through the embedding and the text encoder
+                ids = np.asarray([[49406] + [49407] * (MAX_PROMPT_LENGTH - 1)], dtype=np.int32)
+                self.unconditional_context = self.encode_tokens(ids)
             else:
                 raise NotImplementedError(
-                    "the unconditional context is CLIP's embedding of the empty prompt; set "
-                    "StableDiffusion.unconditional_context to a (77,768) array or install text_frontend")
+                    "the unconditional context is CLIP's embedding of the empty prompt; pass text_encoder_ckpt=, or set "
+                    "StableDiffusion.unconditional_context to a (77,768) array, or install text_frontend")
         u = np.asarray(self.unconditional_context, dtype=np.float32)
         return u[None] if u.ndim == 2 else u
 
@@ -527,6 +557,30 @@ class StableDiffusion(StableDiffusionBase):
             if self.jit_compile:
                 self._image_decoder.compile(jit_compile=True)
         return self._image_decoder
+
+    @property
+    def text_clip_embedding(self):
+        """Reference :686-691."""
+        if self._text_clip_embedding is None:
+            self._text_clip_embedding = TextClipEmbedding(MAX_PROMPT_LENGTH, ckpt_path=self.text_encoder_ckpt, device=self.device)
+            if self.jit_compile:
+                self._text_clip_embedding.compile(jit_compile=True)
+        return self._text_clip_embedding
+
+    @property
+    def text_encoder(self):
+        """Reference :672-683."""
+        if self._text_encoder is None:
+            self._text_encoder = TextEncoder(MAX_PROMPT_LENGTH, clip_skip=self.clip_skip, ckpt_path=self.text_encoder_ckpt,
+                                             lora_dict=self.text_encoder_lora_dict, device=self.device)
+            if self.jit_compile:
+                self._text_encoder.compile(jit_compile=True)
+        return self._text_encoder
+
+    def _text_models_ready(self) -> bool:
+        if self._text_encoder is not None and self._text_clip_embedding is not None:
+            return self._text_encoder._W is not None and self._text_clip_embedding._W is not None
+        return self.text_encoder_ckpt is not None and os.path.exists(str(self.text_encoder_ckpt))
 
     @property
     def image_encoder(self):

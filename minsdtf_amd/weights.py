@@ -250,8 +250,42 @@ TABLES = {
 }
 
 
-def table(kind: str) -> List[WeightSpec]:
-    return TABLES[kind]()
+# --------------------------------------------------------------------------------------
+# CLIP text encoder (reference text_encoder.py:104-169).  The reference builds
+# these mappings in the constructors, not in CKPT_MAPPING: 16 tensors per encoder layer for layers
+# 0 .. num_layers + clip_skip (the layers after out[clip_skip] are never loaded), then the final
+# LayerNorm; the embedding model holds the two lookup tables.
+# --------------------------------------------------------------------------------------
+CLIP_DIM, CLIP_HEADS, CLIP_LAYERS, CLIP_VOCAB, CLIP_MAX_LEN = 768, 12, 12, 49408, 77
+
+
+def text_encoder_table(clip_skip: int = -1) -> List[WeightSpec]:
+    t = _Table("", use_alt=False)
+    for idx in range(0, CLIP_LAYERS + clip_skip + 1):
+        ln = f"text_model.encoder.layers.{idx}"
+        t.norm(ln + ".layer_norm1", ln + ".layer_norm1", CLIP_DIM)
+        for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            t.dense(f"{ln}.self_attn.{proj}", f"{ln}.self_attn.{proj}", CLIP_DIM, CLIP_DIM)
+        t.norm(ln + ".layer_norm2", ln + ".layer_norm2", CLIP_DIM)
+        t.dense(ln + ".mlp.fc1", ln + ".mlp.fc1", CLIP_DIM, 4 * CLIP_DIM)
+        t.dense(ln + ".mlp.fc2", ln + ".mlp.fc2", 4 * CLIP_DIM, CLIP_DIM)
+    t.norm("text_model.final_layer_norm", "text_model.final_layer_norm", CLIP_DIM)
+    return t.rows
+
+
+def text_clip_embedding_table() -> List[WeightSpec]:
+    return [WeightSpec("text_model.embeddings.token_embedding.weight", None, "text_model.embeddings.token_embedding", "embedding",
+                       None, (CLIP_VOCAB, CLIP_DIM)),
+            WeightSpec("text_model.embeddings.position_embedding.weight", None, "text_model.embeddings.position_embedding",
+                       "embedding", None, (CLIP_MAX_LEN, CLIP_DIM))]
+
+
+TABLES["text_encoder"] = text_encoder_table
+TABLES["text_clip_embedding"] = text_clip_embedding_table
+
+
+def table(kind: str, **kw) -> List[WeightSpec]:
+    return TABLES[kind](**kw)
 
 
 def table_digest(kind: str) -> str:
@@ -280,16 +314,20 @@ def _glorot_limit(spec: WeightSpec) -> float:
     return float(np.sqrt(6.0 / (fan_in + fan_out)))
 
 
-def synth_tensors(kind: str, seed: int = 0, bias_scale: float = 0.0) -> Iterator[Tuple[WeightSpec, np.ndarray]]:
+def synth_tensors(kind: str, seed: int = 0, bias_scale: float = 0.0, **table_kw) -> Iterator[Tuple[WeightSpec, np.ndarray]]:
     """Yield (spec, tensor in checkpoint/PyTorch layout) in table order.
 
     One PCG64 stream per table, consumed in table order, so the values do not depend on how the
     caller batches the work.  ``bias_scale`` > 0 draws biases / norm offsets from U(-s, s) (used by
     parity tests so that bias / beta paths are not vacuous); 0 gives the Keras default init.
     """
-    salt = {"civitai_model": 0, "decoder": 1, "controlnet": 2, "hintnet": 3, "encoder": 4}[kind]
+    salt = {"civitai_model": 0, "decoder": 1, "controlnet": 2, "hintnet": 3, "encoder": 4, "text_encoder": 5,
+            "text_clip_embedding": 6}[kind]
     rng = np.random.Generator(np.random.PCG64([seed, salt]))
-    for spec in table(kind):
+    for spec in table(kind, **table_kw):
+        if spec.kind == "embedding":   # Keras Embedding default: uniform(-0.05, 0.05)
+            yield spec, rng.uniform(-0.05, 0.05, size=spec.shape).astype(np.float32)
+            continue
         if spec.kind in ("conv_w", "dense_w"):
             lim = np.float32(_glorot_limit(spec))
             w = rng.random(size=spec.torch_shape, dtype=np.float32)
@@ -315,9 +353,9 @@ def to_keras_layout(spec: WeightSpec, w: np.ndarray) -> np.ndarray:
     return torch.from_numpy(np.ascontiguousarray(w)).permute(*spec.perm).contiguous().numpy()
 
 
-def synth_keras_weights(kind: str, seed: int = 0, bias_scale: float = 0.0) -> List[np.ndarray]:
+def synth_keras_weights(kind: str, seed: int = 0, bias_scale: float = 0.0, **table_kw) -> List[np.ndarray]:
     """Ordered list in Keras layout — what ``set_weights`` receives in the reference."""
-    return [to_keras_layout(s, w) for s, w in synth_tensors(kind, seed, bias_scale)]
+    return [to_keras_layout(s, w) for s, w in synth_tensors(kind, seed, bias_scale, **table_kw)]
 
 
 def write_synthetic_checkpoint(path: str, kinds=("civitai_model",), seed: int = 0, bias_scale: float = 0.0) -> None:

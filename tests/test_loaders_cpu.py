@@ -131,3 +131,34 @@ def test_pipeline_reads_lora_path(lora_file):
     assert sd.lora_path == lora_file and len(sd.unet_lora_dict) == 278 and len(sd.text_encoder_lora_dict) == 12
     sd2 = StableDiffusion(64, 64, lora_path="/nonexistent/lora.safetensors", device="cpu")
     assert sd2.lora_path is None and sd2.unet_lora_dict is None
+
+
+@pytest.mark.parametrize("clip_skip", [-1, -2, -12])
+def test_text_encoder_tables_match_reference(clip_skip):
+    """The (key, perm) lists text_encoder.py:133-157 builds in its constructor (captured by
+    tools/make_goldens.py under the keras stub) == the generated table, for several clip_skip values."""
+    import hashlib
+
+    from minsdtf_amd import weights as W
+
+    g9 = json.load(open(os.path.join(ROOT, "tests", "golden", "g9_text_tables.json")))
+    specs = W.table("text_encoder", clip_skip=clip_skip)
+    h = hashlib.sha256()
+    for s in specs:
+        h.update(repr((s.key, s.perm)).encode())
+    want = g9[f"text_encoder_clip_skip_{clip_skip}"]
+    assert len(specs) == want["count"] and h.hexdigest() == want["sha256"]
+    assert [[s.key, s.perm] for s in W.table("text_clip_embedding")] == g9["text_clip_embedding"]
+    # 12 layers: 85,056,000 + embeddings 38,004,480 = the 123 M parameters of CLIP ViT-L/14's text model
+    if clip_skip == -1:
+        assert sum(int(np.prod(s.shape)) for s in specs) == 85056000
+        assert sum(int(np.prod(s.shape)) for s in W.table("text_clip_embedding")) == 49408 * 768 + 77 * 768
+
+
+def test_text_encoder_lora_keys_are_table_keys(g8):
+    """The text-encoder half of a LoRA file is keyed by names of the text-encoder table, so
+    TextEncoder(lora_dict=...) merges it through the same positional loader."""
+    from minsdtf_amd import weights as W
+
+    keys = {s.key for s in W.table("text_encoder", clip_skip=-1)}
+    assert set(g8["lora_te_keys"]) <= keys

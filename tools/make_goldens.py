@@ -338,6 +338,30 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g7_host_utils.npz"), **g7)
     # ---------------------------------------------------------------- G8 checkpoint / LoRA loaders (§8f rank 2)
     make_loader_goldens(ck)
+    # ---------------------------------------------------------------- G9 CLIP text model checkpoint mappings (§8f rank 3)
+    # text_encoder.py builds its (key, perm) lists inside the constructors; capture them by constructing the
+    # classes under the keras stub with the loader call intercepted
+    import tempfile
+
+    import stable_diffusion.text_encoder as ref_te
+
+    captured = {}
+
+    def capture(model, ckpt_path, ckpt_mapping, key_mapping=None, lora_dict=None):
+        captured["mapping"] = list(ckpt_mapping)
+
+    ref_te.load_weights_from_file = capture
+    g9 = {}
+    with tempfile.NamedTemporaryFile(suffix=".safetensors") as tmp:
+        for skip in (-1, -2, -12):
+            ref_te.TextEncoder(77, clip_skip=skip, ckpt_path=tmp.name)
+            h = hashlib.sha256()
+            for key, perm in captured["mapping"]:
+                h.update(repr((key, tuple(perm) if perm is not None else None)).encode())
+            g9[f"text_encoder_clip_skip_{skip}"] = {"count": len(captured["mapping"]), "sha256": h.hexdigest()}
+        ref_te.TextClipEmbedding(77, ckpt_path=tmp.name)
+        g9["text_clip_embedding"] = [[k, p] for k, p in captured["mapping"]]
+    json.dump(g9, open(os.path.join(OUT, "g9_text_tables.json"), "w"), indent=0, sort_keys=True)
     print("goldens written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:36s} {os.path.getsize(os.path.join(OUT, f)):8d} B")
