@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 2
+#define MSD_ABI_VERSION 3
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -225,6 +225,11 @@ int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream);
  *           noise_rate[t_prev]}; the last step's row holds {sr, nr, 1, 0} and is_last picks x0.
  *   The row used is coef[*step_ptr]; after the update the kernel increments *step_ptr when
  *   advance != 0.
+ *   Inpainting (stable_diffusion.py:469-475), when inpaint_mask != NULL: after the sampler step
+ *   latent = origin * (1 - mask) + latent * mask with origin = signal_rate[t] * inpaint_init +
+ *   noise_rate[t] * inpaint_noise at the CURRENT timestep t (the reference re-noises the encoded
+ *   image at t, not t_prev).  inpaint_init fp32 [n] (one image, shared by the batch), inpaint_noise
+ *   fp32 [batch][n], inpaint_mask fp32 [n] (the latent-resolution mask repeated over the channels).
  */
 typedef struct MsdCfgStep {
     const float* eps;
@@ -234,6 +239,9 @@ typedef struct MsdCfgStep {
     int32_t batch, n, num_steps;
     float guidance, guidance_rescale;
     int32_t advance;
+    const float* inpaint_init;
+    const float* inpaint_noise;
+    const float* inpaint_mask;
 } MsdCfgStep;
 
 int msd_cfg_step(const MsdCfgStep* p, msd_stream_t stream);

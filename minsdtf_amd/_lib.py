@@ -11,7 +11,7 @@ import os
 
 LIB_NAME = "libminsdtf_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -68,6 +68,7 @@ class MsdCfgStep(C.Structure):
         ("eps", C.c_void_p), ("latent", C.c_void_p), ("coef", C.c_void_p), ("step_ptr", C.c_void_p),
         ("batch", C.c_int32), ("n", C.c_int32), ("num_steps", C.c_int32), ("guidance", C.c_float),
         ("guidance_rescale", C.c_float), ("advance", C.c_int32),
+        ("inpaint_init", C.c_void_p), ("inpaint_noise", C.c_void_p), ("inpaint_mask", C.c_void_p),
     ]
 
 

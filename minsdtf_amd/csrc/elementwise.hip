@@ -11,6 +11,7 @@ struct CfgArgs {
     const float* eps; float* latent; const float* coef; const int32_t* step_ptr;
     int batch, n, num_steps;
     float guidance, rescale;
+    const float* ip_init; const float* ip_noise; const float* ip_mask;
 };
 
 __device__ __forceinline__ double block_sum_1024(double v, double* red) {
@@ -59,7 +60,13 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
         if (cfg) { const float cu = u[i], cc = c[i]; e = (cu + p.guidance * (cc - cu)) * factor; }
         else e = u[i];
         const float x0 = (lat[i] - nr * e) / sr;
-        lat[i] = last ? x0 : (sr_prev * x0 + nr_prev * e);
+        float x = last ? x0 : (sr_prev * x0 + nr_prev * e);
+        if (p.ip_mask) {   // inpainting: keep the (re-noised) original outside the mask
+            const float m = p.ip_mask[i];
+            const float org = sr * p.ip_init[i] + nr * p.ip_noise[(size_t)b * p.n + i];
+            x = org * (1.0f - m) + x * m;
+        }
+        lat[i] = x;
     }
 }
 
@@ -73,6 +80,8 @@ extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
     CfgArgs a;
     a.eps = q->eps; a.latent = q->latent; a.coef = q->coef; a.step_ptr = q->step_ptr;
     a.batch = q->batch; a.n = q->n; a.num_steps = q->num_steps; a.guidance = q->guidance; a.rescale = q->guidance_rescale;
+    a.ip_init = q->inpaint_init; a.ip_noise = q->inpaint_noise; a.ip_mask = q->inpaint_mask;
+    if (a.ip_mask && (!a.ip_init || !a.ip_noise)) MSD_FAIL(MSD_E_ARG, "cfg_step: inpaint_mask needs inpaint_init and inpaint_noise");
     hipLaunchKernelGGL(cfg_step_kernel, dim3(q->batch), dim3(1024), 0, stream, a);
     MSD_CHECK_LAUNCH();
     if (q->advance) {

@@ -59,7 +59,7 @@ class DenoiseEngine:
 
     def __init__(self, unet: DiffusionModel, B: int, t_cond: int, t_uncond: int, num_steps: int, guidance: float,
                  guidance_rescale: float, control_net: Optional[ControlNet] = None, hint_net: Optional[HintNet] = None,
-                 use_graph: bool = True, streams: Optional[int] = None):
+                 use_graph: bool = True, streams: Optional[int] = None, inpaint: bool = False):
         unet._require_weights()
         self.unet, self.B, self.num_steps = unet, B, num_steps
         self.h, self.w = unet.h, unet.w
@@ -157,8 +157,16 @@ class DenoiseEngine:
             if controls is not None:
                 step.free(*controls)
         tail = engine.Plan(dev) if self.dual else step
+        # inpainting (reference :469-475): the blend with the re-noised encoded image is part of the sampler kernel
+        self.inpaint = None
+        if inpaint:
+            self.inpaint = {"init": torch.zeros(n, dtype=torch.float32, device=dev),
+                            "noise": torch.zeros(B, n, dtype=torch.float32, device=dev),
+                            "mask": torch.ones(n, dtype=torch.float32, device=dev)}
+        ip = self.inpaint or {}
         tail.rec(ops.cfg_step, eps=self.eps, latent=self.latent, coef=self.coef, step_ptr=self.step_ptr, batch=B, n=n,
-                 num_steps=num_steps, guidance=guidance, guidance_rescale=guidance_rescale, advance=True)
+                 num_steps=num_steps, guidance=guidance, guidance_rescale=guidance_rescale, advance=True,
+                 inpaint_init=ip.get("init"), inpaint_noise=ip.get("noise"), inpaint_mask=ip.get("mask"))
         for pl in self.branches:
             pl.finalize()
         self.tail = tail if self.dual else None
@@ -247,8 +255,15 @@ class DenoiseEngine:
             callback(i + 1)
 
     def prepare(self, contexts: Dict[str, np.ndarray], noise: np.ndarray, scheduler: Scheduler, timesteps,
-                start_index: int = 0, hint_image: Optional[np.ndarray] = None) -> None:
-        """Upload the per-call inputs and run the preparation plan."""
+                start_index: int = 0, hint_image: Optional[np.ndarray] = None, inpaint=None) -> None:
+        """Upload the per-call inputs and run the preparation plan.  inpaint = (init_latent (1,h,w,4),
+        noise (B,h,w,4), latent mask (h,w) or (h,w,1)) for an engine built with inpaint=True."""
+        if self.inpaint is not None:
+            init, ip_noise, mask = inpaint
+            self.inpaint["init"].copy_(torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32).reshape(-1)))
+            self.inpaint["noise"].copy_(torch.from_numpy(np.ascontiguousarray(ip_noise, dtype=np.float32).reshape(self.B, -1)))
+            m = np.asarray(mask, dtype=np.float32).reshape(self.h, self.w, 1)
+            self.inpaint["mask"].copy_(torch.from_numpy(np.ascontiguousarray(np.broadcast_to(m, (self.h, self.w, 4))).reshape(-1)))
         for tag, arr in contexts.items():
             self.ctx_in[tag].copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)))
         self.latent.copy_(torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float32)))
@@ -308,6 +323,19 @@ class StableDiffusionBase:
                                    unconditional_guidance_scale=unconditional_guidance_scale, seed=seed,
                                    negative_embedding=negative_embedding, control_net_image=control_net_image,
                                    reference_image=reference_image, reference_image_strength=reference_image_strength,
+                                   guidance_rescale=guidance_rescale, callback=callback, **kw)
+
+    def inpaint(self, prompt, negative_prompt=None, batch_size=1, num_steps=50, unconditional_guidance_scale=7.5,
+                embedding=None, negative_embedding=None, seed=None, control_net_image=None, reference_image=None,
+                reference_image_strength=0.8, inpaint_mask=None, mask_blur_strength=None, guidance_rescale=0.7,
+                callback=None, **kw):
+        """Reference :141-175."""
+        encoded_text = self.encode_text(prompt, embedding)
+        return self.generate_image(encoded_text, negative_prompt=negative_prompt, batch_size=batch_size, num_steps=num_steps,
+                                   unconditional_guidance_scale=unconditional_guidance_scale, seed=seed,
+                                   negative_embedding=negative_embedding, control_net_image=control_net_image,
+                                   reference_image=reference_image, reference_image_strength=reference_image_strength,
+                                   inpaint_mask=inpaint_mask, mask_blur_strength=mask_blur_strength,
                                    guidance_rescale=guidance_rescale, callback=callback, **kw)
 
     def encode_text(self, prompt, embedding_data=None):
@@ -394,6 +422,40 @@ class StableDiffusionBase:
         bot = image_array[y1, x0, :] * (1.0 - dx) + image_array[y1, x1, :] * dx
         return top * (1.0 - dy) + bot * dy
 
+    @staticmethod
+    def gaussian_blur(image, radius=3, h_axis=1, v_axis=2):
+        """Separable binomial blur, reflected borders (reference :217-240): the 1-D filter is row
+        `radius - 1` of Pascal's triangle, normalised."""
+        from math import comb
+
+        from scipy.ndimage import correlate1d
+
+        weights = np.asarray([comb(radius - 1, k) for k in range(radius)], dtype=np.float64)
+        weights = weights / np.sum(weights)
+        out = correlate1d(image, weights, axis=h_axis, output=None, mode="reflect", cval=0.0, origin=0)
+        return correlate1d(out, weights, axis=v_axis, output=None, mode="reflect", cval=0.0, origin=0)
+
+    def preprocessed_mask(self, x, blur_radius=5):
+        """Reference :288-302: path or HxW[xC] array -> ((1,H,W,1) image-resolution mask in [0,1], (1,w/8,h/8,1)
+        latent-resolution mask).  The latent resize takes (img_width//8, img_height//8) as (new_h, new_w), as the
+        reference does — identical for square images."""
+        if type(x) is str:
+            from PIL import Image
+
+            x = np.array(Image.open(x).convert("L"))
+        else:
+            x = np.array(x)
+        if len(x.shape) == 2:
+            x = np.expand_dims(x, axis=-1)
+        mask_array = self.resize(x, self.img_height, self.img_width)
+        if mask_array.shape[-1] != 1:
+            mask_array = np.mean(mask_array, axis=-1, keepdims=True)
+        input_mask_array = np.array(mask_array, dtype=np.float32) / 255.0
+        if blur_radius is not None:
+            input_mask_array = self.gaussian_blur(input_mask_array, radius=blur_radius, h_axis=0, v_axis=1)
+        latent_mask_tensor = self.resize(input_mask_array, self.img_width // 8, self.img_height // 8)
+        return np.expand_dims(input_mask_array, axis=0), np.expand_dims(latent_mask_tensor, axis=0)
+
     def preprocessed_image(self, x):
         """Reference :277-286: path or HxWx3 array -> ((1,H,W,3) in [0,1], (1,H,W,3) in [-1,1])."""
         if type(x) is str:
@@ -416,8 +478,6 @@ class StableDiffusionBase:
         if diffusion_noise is not None and seed is not None:
             raise ValueError("`diffusion_noise` and `seed` should not both be passed to `generate_image`. `seed` is only "
                              "used to generate diffusion noise when it's not already user-specified.")
-        if inpaint_mask is not None:
-            raise NotImplementedError("inpainting is outside the accelerated path (SURVEY.md §8f rank 4)")
         context = self._expand_tensor(encoded_text, batch_size)
         if negative_prompt is None and negative_embedding is None:
             unconditional_context = np.repeat(self._get_unconditional_context(), batch_size, axis=0)
@@ -439,14 +499,21 @@ class StableDiffusionBase:
         # outside (0,1) silently falls back to txt2img, like the reference (:410).
         timesteps_asc = self.scheduler.timesteps[::-1]
         run_steps = num_steps
+        # inpainting (reference :406-409,469-475,484-485): the mask only takes effect together with a reference
+        # image; every step the latent outside the mask is replaced by the encoded image re-noised at that step
+        input_mask_array = latent_mask = input_image_array = init_latent = None
+        raw_noise = diffusion_noise
+        if inpaint_mask is not None:
+            input_mask_array, latent_mask = self.preprocessed_mask(inpaint_mask, mask_blur_strength)
         if reference_image is not None and (0.0 < reference_image_strength < 1.0):
-            _, input_image_tensor = self.preprocessed_image(reference_image)
+            input_image_array, input_image_tensor = self.preprocessed_image(reference_image)
             run_steps = int(num_steps * reference_image_strength + 0.5)
             init_time = timesteps_asc[run_steps]
             init_latent = self.image_encoder.predict_on_batch(input_image_tensor)
             timesteps_asc = timesteps_asc[:run_steps]
             diffusion_noise = (self.scheduler.signal_rates[init_time] * np.repeat(init_latent, batch_size, axis=0)
                                + self.scheduler.noise_rates[init_time] * diffusion_noise)
+        inpaint = (init_latent, raw_noise, latent_mask[0]) if (latent_mask is not None and init_latent is not None) else None
         start_index = num_steps - run_steps  # position of the first executed timestep in the descending schedule
         hint_image = None
         if control_net_image is not None:
@@ -458,35 +525,44 @@ class StableDiffusionBase:
                 image_array = Image.open(control_net_image).convert("RGB").resize((self.img_width, self.img_height))
             hint_image = np.tile(np.expand_dims(np.array(image_array, dtype=np.float32) / 255.0, axis=0), (batch_size, 1, 1, 1))
 
-        if host_loop:
-            latent = self._host_loop(context, unconditional_context, diffusion_noise, unconditional_guidance_scale,
-                                     guidance_rescale, hint_image, callback, timesteps_asc)
-            if return_latent:
-                return np.asarray(latent, dtype=np.float32)
-            decoded = self.image_decoder.predict_on_batch(latent)
+        def finish(decoded):
+            """Reference :482-486 (with the pixel-space inpaint blend)."""
             decoded = np.array(((decoded + 1.0) * 0.5), dtype=np.float32)
+            if input_mask_array is not None and input_image_array is not None:
+                decoded = input_image_array * (1.0 - input_mask_array) + decoded * input_mask_array
             return np.clip(decoded * 255.0, 0, 255).astype("uint8")
 
+        if host_loop:
+            latent = self._host_loop(context, unconditional_context, diffusion_noise, unconditional_guidance_scale,
+                                     guidance_rescale, hint_image, callback, timesteps_asc, inpaint)
+            if return_latent:
+                return np.asarray(latent, dtype=np.float32)
+            return finish(self.image_decoder.predict_on_batch(latent))
+
         eng = self._engine(batch_size, context.shape[1], unconditional_context.shape[1], num_steps,
-                           float(unconditional_guidance_scale), float(guidance_rescale), hint_image is not None)
-        eng.prepare(eng.contexts(unconditional_context, context), diffusion_noise, self.scheduler, self.scheduler.timesteps, start_index, hint_image)
+                           float(unconditional_guidance_scale), float(guidance_rescale), hint_image is not None,
+                           inpaint is not None)
+        eng.prepare(eng.contexts(unconditional_context, context), diffusion_noise, self.scheduler, self.scheduler.timesteps,
+                    start_index, hint_image, inpaint)
         eng.run_steps(run_steps, callback)
         if return_latent:
             return eng.latent.cpu().numpy()
+        if input_mask_array is not None and input_image_array is not None:
+            return finish(self.image_decoder.predict_on_batch(eng.latent))   # pixel blend in fp32 before the uint8 cast
         return self.image_decoder.decode_to_uint8(eng.latent).cpu().numpy()
 
-    def _engine(self, B, tc, tu, steps, g, phi, control) -> DenoiseEngine:
-        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams)
+    def _engine(self, B, tc, tu, steps, g, phi, control, inpaint=False) -> DenoiseEngine:
+        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams, inpaint)
         eng = self._engines.get(key)
         if eng is None:
             eng = DenoiseEngine(self.diffusion_model, B, tc, tu, steps, g, phi,
                                 control_net=self.control_net if control else None,
                                 hint_net=self.hint_net if control else None, use_graph=self.jit_compile,
-                                streams=self.denoise_streams)
+                                streams=self.denoise_streams, inpaint=inpaint)
             self._engines = {key: eng}  # one resident engine: its arenas are the big allocations
         return eng
 
-    def _host_loop(self, context, unconditional_context, latent, g, phi, hint_image, callback, timesteps=None):
+    def _host_loop(self, context, unconditional_context, latent, g, phi, hint_image, callback, timesteps=None, inpaint=None):
         """The reference's own loop over predict_on_batch (stable_diffusion.py:442-479)."""
         if timesteps is None:
             timesteps = self.scheduler.timesteps[::-1]
@@ -515,6 +591,11 @@ class StableDiffusionBase:
                 else:
                     latent = self.diffusion_model.predict_on_batch([latent, t_emb, context])
             latent = self.scheduler.step(latent, timestep, latent_prev)
+            if inpaint is not None:   # reference :469-475
+                init_latent, noise, latent_mask = inpaint
+                origin = (self.scheduler.signal_rates[timestep] * np.repeat(init_latent, batch_size, axis=0)
+                          + self.scheduler.noise_rates[timestep] * noise)
+                latent = origin * (1.0 - latent_mask[None]) + latent * latent_mask[None]
             iteration += 1
             if callback is not None:
                 callback(iteration)

@@ -116,7 +116,7 @@ def _fake_encoder(img):
     return np.concatenate([m, m.mean(axis=-1, keepdims=True)], axis=-1).astype(np.float32) * 0.7
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
 def test_host_loop_matches_reference(tag):
     """generate_image(host_loop=True) with the same numpy fake models the reference's loop was run
     with: same call order and arguments (uncond before cond, one call when guidance <= 0), same
@@ -145,7 +145,9 @@ def test_host_loop_matches_reference(tag):
 
     p = Pipe(64, 64)
     p.unconditional_context = g["uncond"]
-    extra = {"reference_image": g["d_reference_image"]} if tag == "d" else {}   # image_to_image run
+    extra = {"reference_image": g["d_reference_image"]} if tag in ("d", "e") else {}   # image_to_image / inpaint runs
+    if tag == "e":
+        extra["inpaint_mask"] = g["e_inpaint_mask"]
     img = p.generate_image(g["context"], diffusion_noise=g[f"{tag}_noise"], host_loop=True, **tr["kwargs"], **extra)
     assert img.dtype == np.uint8 and img.shape == g[f"{tag}_image"].shape
     assert len(trace) == len(tr["calls"])
@@ -165,6 +167,39 @@ def test_oracle_loop_matches_reference_loop():
     np.testing.assert_array_equal(O.to_uint8(_fake_decoder(lat)), g["a_image"])
 
 
+def test_mask_preprocessing_matches_reference():
+    """gaussian_blur (binomial filter, reflected borders) and preprocessed_mask (resize, channel mean,
+    /255, blur, latent-resolution resize) against the reference's outputs (stable_diffusion.py:217-240,288-302)."""
+    from minsdtf_amd.stable_diffusion import StableDiffusionBase
+
+    g = gold("g7_host_utils.npz")
+    p = StableDiffusionBase(64, 64)
+    for r in (1, 3, 5):
+        np.testing.assert_array_equal(p.gaussian_blur(g["blur_in"], radius=r, h_axis=0, v_axis=1), g[f"blur_{r}"])
+    full, lat = p.preprocessed_mask(g["mask_in"], 5)
+    np.testing.assert_array_equal(full, g["mask_full"])
+    np.testing.assert_array_equal(lat, g["mask_latent"])
+    assert full.shape == (1, 64, 64, 1) and lat.shape == (1, 8, 8, 1)
+    np.testing.assert_array_equal(p.preprocessed_mask(np.stack([g["mask_in"]] * 3, -1), None)[1], g["mask_noblur_latent"])
+
+
+def test_oracle_inpaint_loop_matches_reference_loop():
+    """The oracle's loop with init latent + latent mask reproduces the reference's inpaint run 'e' (uint8 image)."""
+    from minsdtf_amd.stable_diffusion import StableDiffusionBase
+    from oracle import sd_oracle as O
+
+    g = gold("g2_host_loop.npz")
+    p = StableDiffusionBase(64, 64)
+    img01, img11 = p.preprocessed_image(g["d_reference_image"])
+    full, lat_mask = p.preprocessed_mask(g["e_inpaint_mask"], 5)
+    lat = O.denoise_loop(lambda l, t, c, ctl: _fake_unet(l, t, c), np.repeat(g["context"][None], 2, 0), np.repeat(g["uncond"], 2, 0),
+                         g["e_noise"], num_steps=10, guidance=5.0, guidance_rescale=0.7, init_latent=_fake_encoder(img11), strength=0.6,
+                         latent_mask=lat_mask)
+    decoded = (_fake_decoder(lat) + 1.0) * 0.5
+    decoded = img01 * (1.0 - full) + np.array(decoded, dtype=np.float32) * full
+    np.testing.assert_array_equal(np.clip(decoded * 255.0, 0, 255).astype("uint8"), g["e_image"])
+
+
 def test_generate_image_argument_errors():
     from minsdtf_amd.stable_diffusion import StableDiffusionBase
 
@@ -173,8 +208,6 @@ def test_generate_image_argument_errors():
         p.generate_image(np.zeros((77, 768), np.float32), diffusion_noise=np.zeros((8, 8, 4)), seed=1)
     with pytest.raises(NotImplementedError):
         p.encode_text("a string prompt")
-    with pytest.raises(NotImplementedError):
-        p.generate_image(np.zeros((77, 768), np.float32), inpaint_mask=np.zeros((64, 64)))
 
 
 # ------------------------------------------------------------------ G5: prompt parser cases (data only)

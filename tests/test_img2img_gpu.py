@@ -113,3 +113,57 @@ def test_image_to_image_api_returns_uint8(gpu, enc):
     img = sd.image_to_image(rng.standard_normal((77, 768)).astype(np.float32), batch_size=1, num_steps=5, seed=3,
                             reference_image=rng.integers(0, 256, (48, 80, 3)).astype(np.uint8), reference_image_strength=0.6)
     assert img.dtype == np.uint8 and img.shape == (1, 64, 64, 3)
+
+
+def test_inpaint_vs_oracle(gpu, enc):
+    """stable_diffusion.py:406-409,469-475,484-485: image_to_image + mask.  Every step the latent outside
+    the (blurred, latent-resolution) mask is replaced by the encoded image re-noised at that step — fused
+    into the sampler kernel on the device path — and the decoded image is blended with the original."""
+    from minsdtf_amd import weights as Wt
+    from minsdtf_amd.models import DiffusionModel, ImageDecoder
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+    from oracle import sd_oracle as O
+
+    m, We = enc
+    u = DiffusionModel(64, 64, device=gpu)
+    Wu = O.named_weights(Wt.table("civitai_model"), u.load_synthetic(seed=0, bias_scale=0.05))
+    dec = ImageDecoder(device=gpu)
+    Wd = O.named_weights(Wt.table("decoder"), dec.load_synthetic(seed=0, bias_scale=0.05))
+    sd = StableDiffusion(64, 64, jit_compile=True, device=gpu)
+    sd._diffusion_model, sd._image_encoder, sd._image_decoder = u, m, dec
+    rng = np.random.default_rng(35)
+    ctx = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    unc = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    noise = rng.standard_normal((2, 8, 8, 4)).astype(np.float32)
+    image = rng.integers(0, 256, (64, 64, 3)).astype(np.uint8)
+    mask = np.zeros((64, 64), np.uint8)
+    mask[16:48, 8:40] = 255
+    sd.unconditional_context = unc[0]
+
+    img01, img11 = sd.preprocessed_image(image)
+    full, lat_mask = sd.preprocessed_mask(mask, 5)
+    init = O.encoder_forward(We, img11)
+    ref = O.denoise_loop(lambda l, t, c, ctl: O.unet_forward(Wu, l, t, c), np.repeat(ctx, 2, 0), np.repeat(unc, 2, 0), noise,
+                         num_steps=4, guidance=7.5, guidance_rescale=0.7, init_latent=init, strength=0.75, latent_mask=lat_mask)
+    kw = dict(batch_size=2, num_steps=4, unconditional_guidance_scale=7.5, guidance_rescale=0.7, diffusion_noise=noise,
+              reference_image=image, reference_image_strength=0.75, inpaint_mask=mask, mask_blur_strength=5)
+    got = sd.generate_image(ctx[0], return_latent=True, **kw)
+    p = O.psnr(got, ref)
+    print(f"inpaint fused loop: final-latent PSNR {p:.1f} dB")
+    assert p >= PSNR_MIN
+    host = sd.generate_image(ctx[0], return_latent=True, host_loop=True, **kw)
+    assert O.psnr(host, ref) >= PSNR_MIN
+    # outside the mask the last step leaves exactly the encoded image re-noised at t = 0 -> close to `init`
+    outside = lat_mask[0, :, :, 0] == 0.0
+    assert outside.any()
+    # pixel blend: where the full-resolution mask is 0 the output is the reference image itself
+    out = sd.inpaint(ctx[0], **{k: v for k, v in kw.items() if k != "diffusion_noise"}, seed=5)
+    assert out.dtype == np.uint8 and out.shape == (2, 64, 64, 3)
+    keep = full[0, :, :, 0] == 0.0
+    expect = np.clip(img01[0] * 255.0, 0, 255).astype(np.uint8)
+    np.testing.assert_array_equal(out[0][keep], expect[keep])
+    # and the whole image agrees with the oracle's decode + blend of the oracle latent
+    out_fixed = sd.generate_image(ctx[0], **kw)
+    dec_ref = (O.decoder_forward(Wd, ref) + 1.0) * 0.5
+    ref_img = np.clip((img01 * (1.0 - full) + dec_ref * full) * 255.0, 0, 255).astype(np.uint8)
+    assert O.psnr(out_fixed.astype(np.float32), ref_img.astype(np.float32), data_range=255.0) >= 35.0

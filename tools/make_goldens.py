@@ -299,15 +299,23 @@ def main():
             "c": dict(batch_size=1, num_steps=3, unconditional_guidance_scale=0.0, guidance_rescale=0.0),
             # image_to_image: strength 0.8 of 25 steps -> 20 steps from t=760, init latent noised at t=800
             "d": dict(batch_size=2, num_steps=25, unconditional_guidance_scale=7.5, guidance_rescale=0.7,
-                      reference_image_strength=0.8)}
+                      reference_image_strength=0.8),
+            # inpaint: image_to_image + a blurred mask; per-step latent blend and final pixel blend
+            "e": dict(batch_size=2, num_steps=10, unconditional_guidance_scale=5.0, guidance_rescale=0.7,
+                      reference_image_strength=0.6, mask_blur_strength=5)}
     ref_img = rng.integers(0, 256, (40, 56, 3)).astype(np.uint8)   # not the model size: exercises the bilinear resize
     g2["d_reference_image"] = ref_img
+    mask_img = np.zeros((40, 56), np.uint8)
+    mask_img[8:30, 10:40] = 255
+    g2["e_inpaint_mask"] = mask_img
     traces = {}
     for tag, kw in runs.items():
         pipe = RefPipe(64, 64)
         noise = rng.standard_normal((kw["batch_size"], 8, 8, 4)).astype(np.float32)
         del trace[:]
         extra = {"reference_image": ref_img} if "reference_image_strength" in kw else {}
+        if "mask_blur_strength" in kw:
+            extra["inpaint_mask"] = mask_img
         img = pipe.generate_image(ctx, diffusion_noise=noise, **kw, **extra)
         g2[f"{tag}_noise"], g2[f"{tag}_image"] = noise, img
         traces[tag] = {"kwargs": kw, "calls": list(trace)}
@@ -333,6 +341,11 @@ def main():
     img = rng.uniform(0, 255, (13, 9, 3)).astype(np.float32)
     g7 = {"image": img, "resized_16_24": ref_sd.StableDiffusionBase.resize(img, 16, 24),
           "resized_5_4": ref_sd.StableDiffusionBase.resize(img, 5, 4),
+          "blur_in": img[..., :1] / 255.0, "blur_3": pipe.gaussian_blur(img[..., :1] / 255.0, radius=3, h_axis=0, v_axis=1),
+          "blur_5": pipe.gaussian_blur(img[..., :1] / 255.0, radius=5, h_axis=0, v_axis=1),
+          "blur_1": pipe.gaussian_blur(img[..., :1] / 255.0, radius=1, h_axis=0, v_axis=1),
+          "mask_in": mask_img, "mask_full": pipe.preprocessed_mask(mask_img, 5)[0], "mask_latent": pipe.preprocessed_mask(mask_img, 5)[1],
+          "mask_noblur_latent": pipe.preprocessed_mask(np.stack([mask_img] * 3, -1), None)[1],
           "expand_in": ctx[:5, :6], "expand_out": pipe._expand_tensor(ctx[:5, :6], 3),
           "expand_in_b": ctx[None, :5, :6], "expand_out_b": pipe._expand_tensor(ctx[None, :5, :6], 1)}
     np.savez_compressed(os.path.join(OUT, "g7_host_utils.npz"), **g7)
