@@ -221,8 +221,11 @@ int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream);
  *   eps:    fp32 [2*batch][n]  rows [0,batch) = unconditional, [batch,2*batch) = text-conditioned
  *           (guidance <= 0: fp32 [batch][n], used as is — stable_diffusion.py:462-467)
  *   latent: fp32 [batch][n], updated in place
- *   coef:   fp32 [steps][4] = {signal_rate[t], noise_rate[t], signal_rate[t_prev],
- *           noise_rate[t_prev]}; the last step's row holds {sr, nr, 1, 0} and is_last picks x0.
+ *   coef:   fp32 [steps][4] = {signal_rate[t], noise_rate[t], A, B}: x0 = (x - noise_rate eps) / signal_rate,
+ *           x' = A x0 + B eps.  Deterministic sampler: A, B = signal / noise rate of t_prev and {1, 0} on
+ *           the last step (x' = x0).  TCD sampler (scheduler.py:286-307): the gamma-sampling coefficients,
+ *           plus x' += noise_coef[step] * step_noise[step][b][:] when step_noise != NULL
+ *           (step_noise fp32 [steps][batch][n] = the per-step N(0,1) draws, noise_coef fp32 [steps]).
  *   The row used is coef[*step_ptr]; after the update the kernel increments *step_ptr when
  *   advance != 0.
  *   Inpainting (stable_diffusion.py:469-475), when inpaint_mask != NULL: after the sampler step
@@ -242,6 +245,8 @@ typedef struct MsdCfgStep {
     const float* inpaint_init;
     const float* inpaint_noise;
     const float* inpaint_mask;
+    const float* step_noise;
+    const float* noise_coef;
 } MsdCfgStep;
 
 int msd_cfg_step(const MsdCfgStep* p, msd_stream_t stream);

@@ -69,6 +69,7 @@ class MsdCfgStep(C.Structure):
         ("batch", C.c_int32), ("n", C.c_int32), ("num_steps", C.c_int32), ("guidance", C.c_float),
         ("guidance_rescale", C.c_float), ("advance", C.c_int32),
         ("inpaint_init", C.c_void_p), ("inpaint_noise", C.c_void_p), ("inpaint_mask", C.c_void_p),
+        ("step_noise", C.c_void_p), ("noise_coef", C.c_void_p),
     ]
 
 

@@ -12,6 +12,7 @@ struct CfgArgs {
     int batch, n, num_steps;
     float guidance, rescale;
     const float* ip_init; const float* ip_noise; const float* ip_mask;
+    const float* step_noise; const float* noise_coef;
 };
 
 __device__ __forceinline__ double block_sum_1024(double v, double* red) {
@@ -32,8 +33,9 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
     if (step > p.num_steps - 1) step = p.num_steps - 1;
     if (step < 0) step = 0;
     const float sr = p.coef[step * 4 + 0], nr = p.coef[step * 4 + 1];
-    const float sr_prev = p.coef[step * 4 + 2], nr_prev = p.coef[step * 4 + 3];
-    const bool last = (step == p.num_steps - 1);
+    const float ca = p.coef[step * 4 + 2], cb = p.coef[step * 4 + 3];   // x' = ca * x0 + cb * eps (+ cz * z)
+    const float cz = p.step_noise ? p.noise_coef[step] : 0.0f;
+    const float* z = p.step_noise ? p.step_noise + ((size_t)step * p.batch + b) * p.n : nullptr;
     float* lat = p.latent + (size_t)b * p.n;
     const bool cfg = p.guidance > 0.0f;
     const float* u = p.eps + (size_t)b * p.n;
@@ -60,7 +62,8 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
         if (cfg) { const float cu = u[i], cc = c[i]; e = (cu + p.guidance * (cc - cu)) * factor; }
         else e = u[i];
         const float x0 = (lat[i] - nr * e) / sr;
-        float x = last ? x0 : (sr_prev * x0 + nr_prev * e);
+        float x = ca * x0 + cb * e;
+        if (z) x += cz * z[i];
         if (p.ip_mask) {   // inpainting: keep the (re-noised) original outside the mask
             const float m = p.ip_mask[i];
             const float org = sr * p.ip_init[i] + nr * p.ip_noise[(size_t)b * p.n + i];
@@ -82,6 +85,8 @@ extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
     a.batch = q->batch; a.n = q->n; a.num_steps = q->num_steps; a.guidance = q->guidance; a.rescale = q->guidance_rescale;
     a.ip_init = q->inpaint_init; a.ip_noise = q->inpaint_noise; a.ip_mask = q->inpaint_mask;
     if (a.ip_mask && (!a.ip_init || !a.ip_noise)) MSD_FAIL(MSD_E_ARG, "cfg_step: inpaint_mask needs inpaint_init and inpaint_noise");
+    a.step_noise = q->step_noise; a.noise_coef = q->noise_coef;
+    if (a.step_noise && !a.noise_coef) MSD_FAIL(MSD_E_ARG, "cfg_step: step_noise needs noise_coef");
     hipLaunchKernelGGL(cfg_step_kernel, dim3(q->batch), dim3(1024), 0, stream, a);
     MSD_CHECK_LAUNCH();
     if (q->advance) {

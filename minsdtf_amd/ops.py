@@ -129,11 +129,13 @@ def softmax_rows(*, x, out, rows, cols, ld_in, ld_out, scale, name="softmax_rows
 
 
 def cfg_step(*, eps, latent, coef, step_ptr, batch, n, num_steps, guidance, guidance_rescale, advance=True,
-             inpaint_init=None, inpaint_noise=None, inpaint_mask=None, name="cfg_step") -> Call:
+             inpaint_init=None, inpaint_noise=None, inpaint_mask=None, step_noise=None, noise_coef=None,
+             name="cfg_step") -> Call:
     lib = _lib.load()
     s = _lib.MsdCfgStep()
     s.eps, s.latent, s.coef, s.step_ptr = _p(eps), _p(latent), _p(coef), _p(step_ptr)
     s.inpaint_init, s.inpaint_noise, s.inpaint_mask = _p(inpaint_init), _p(inpaint_noise), _p(inpaint_mask)
+    s.step_noise, s.noise_coef = _p(step_noise), _p(noise_coef)
     s.batch, s.n, s.num_steps = batch, n, num_steps
     s.guidance, s.guidance_rescale, s.advance = float(guidance), float(guidance_rescale), int(bool(advance))
     return Call(lib.msd_cfg_step, (C.byref(s),), name, keep=s)

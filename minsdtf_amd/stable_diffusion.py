@@ -59,7 +59,7 @@ class DenoiseEngine:
 
     def __init__(self, unet: DiffusionModel, B: int, t_cond: int, t_uncond: int, num_steps: int, guidance: float,
                  guidance_rescale: float, control_net: Optional[ControlNet] = None, hint_net: Optional[HintNet] = None,
-                 use_graph: bool = True, streams: Optional[int] = None, inpaint: bool = False):
+                 use_graph: bool = True, streams: Optional[int] = None, inpaint: bool = False, tcd: bool = False):
         unet._require_weights()
         self.unet, self.B, self.num_steps = unet, B, num_steps
         self.h, self.w = unet.h, unet.w
@@ -164,9 +164,13 @@ class DenoiseEngine:
                             "noise": torch.zeros(B, n, dtype=torch.float32, device=dev),
                             "mask": torch.ones(n, dtype=torch.float32, device=dev)}
         ip = self.inpaint or {}
+        # TCD sampler: one N(0,1) draw per step and sample, made on the host in the reference's order (prepare())
+        self.step_noise = torch.zeros(num_steps, B, n, dtype=torch.float32, device=dev) if tcd else None
+        self.noise_coef = torch.zeros(num_steps, dtype=torch.float32, device=dev) if tcd else None
         tail.rec(ops.cfg_step, eps=self.eps, latent=self.latent, coef=self.coef, step_ptr=self.step_ptr, batch=B, n=n,
                  num_steps=num_steps, guidance=guidance, guidance_rescale=guidance_rescale, advance=True,
-                 inpaint_init=ip.get("init"), inpaint_noise=ip.get("noise"), inpaint_mask=ip.get("mask"))
+                 inpaint_init=ip.get("init"), inpaint_noise=ip.get("noise"), inpaint_mask=ip.get("mask"),
+                 step_noise=self.step_noise, noise_coef=self.noise_coef)
         for pl in self.branches:
             pl.finalize()
         self.tail = tail if self.dual else None
@@ -271,6 +275,13 @@ class DenoiseEngine:
         temb = np.concatenate([get_timestep_embedding(int(t), 1) for t in scheduler.timesteps], axis=0)
         self.temb_in.copy_(torch.from_numpy(np.ascontiguousarray(temb, dtype=np.float32)))
         self.step_ptr.fill_(int(start_index))
+        if self.step_noise is not None:
+            # scheduler.py:301 draws np.random.randn(*latent.shape) once per executed step except the last
+            self.noise_coef.copy_(torch.from_numpy(scheduler.noise_coefficients()))
+            z = np.zeros((self.num_steps, self.B, self.h * self.w * 4), dtype=np.float32)
+            for i in range(int(start_index), self.num_steps - 1):
+                z[i] = np.random.randn(self.B, self.h, self.w, 4).astype(np.float32).reshape(self.B, -1)
+            self.step_noise.copy_(torch.from_numpy(z))
         if self.has_control:
             hi = np.ascontiguousarray(hint_image, dtype=np.float32)
             reps = self.hint_img.shape[0] // hi.shape[0]
@@ -552,13 +563,13 @@ class StableDiffusionBase:
         return self.image_decoder.decode_to_uint8(eng.latent).cpu().numpy()
 
     def _engine(self, B, tc, tu, steps, g, phi, control, inpaint=False) -> DenoiseEngine:
-        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams, inpaint)
+        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams, inpaint, self.active_tcd)
         eng = self._engines.get(key)
         if eng is None:
             eng = DenoiseEngine(self.diffusion_model, B, tc, tu, steps, g, phi,
                                 control_net=self.control_net if control else None,
                                 hint_net=self.hint_net if control else None, use_graph=self.jit_compile,
-                                streams=self.denoise_streams, inpaint=inpaint)
+                                streams=self.denoise_streams, inpaint=inpaint, tcd=self.active_tcd)
             self._engines = {key: eng}  # one resident engine: its arenas are the big allocations
         return eng
 

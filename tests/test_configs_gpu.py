@@ -111,3 +111,37 @@ def test_non_power_of_two_latent(gpu):
     ref = O.unet_forward(W, lat, te, ctx)
     got = m.predict_on_batch([lat, te, ctx])
     assert O.psnr(got, ref) >= PSNR_MIN
+
+
+@pytest.mark.parametrize("jit", [True, False])
+def test_tcd_sampler_fused_loop(gpu, nets, jit):
+    """StableDiffusion(active_tcd=True): TCD schedule + stochastic step (scheduler.py:136-237,286-307).  The
+    device loop (coefficients + pre-drawn per-step noise inside the sampler kernel) against the oracle's
+    loop and the host loop, all seeded through numpy's global generator like the reference."""
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+    from oracle import sd_oracle as O
+
+    sd = StableDiffusion(64, 64, jit_compile=jit, device=gpu, active_tcd=True)
+    sd._diffusion_model = nets["unet"]
+    rng = np.random.default_rng(25)
+    ctx = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    unc = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    noise = rng.standard_normal((2, 8, 8, 4)).astype(np.float32)
+    sd.unconditional_context = unc[0]
+    kw = dict(batch_size=2, num_steps=4, unconditional_guidance_scale=7.5, guidance_rescale=0.7, diffusion_noise=noise,
+              return_latent=True)
+    np.random.seed(77)
+    ref = O.denoise_loop(lambda l, t, c, ctl: O.unet_forward(nets["Wu"], l, t, c), np.repeat(ctx, 2, 0), np.repeat(unc, 2, 0), noise,
+                         num_steps=4, guidance=7.5, guidance_rescale=0.7, active_tcd=True)
+    np.random.seed(77)
+    got = sd.generate_image(ctx[0], **kw)
+    assert list(sd.scheduler.timesteps) == [999, 759, 499, 259]
+    p = O.psnr(got, ref)
+    print(f"TCD fused loop: final-latent PSNR {p:.1f} dB")
+    assert p >= PSNR_MIN
+    np.random.seed(77)
+    host = sd.generate_image(ctx[0], host_loop=True, **kw)
+    assert O.psnr(host, ref) >= PSNR_MIN
+    np.random.seed(78)
+    other = sd.generate_image(ctx[0], **kw)      # a different draw of the per-step noise gives a different sample
+    assert O.psnr(other, ref) < 30.0

@@ -55,10 +55,45 @@ def test_coefficient_table_reproduces_step():
     assert tab.shape == (25, 4) and tab.dtype == np.float32
     ts = s.timesteps
     for i, t in enumerate(ts):
-        tp = ts[i + 1] if i + 1 < 25 else t
-        np.testing.assert_allclose(tab[i], [s.signal_rates[t], s.noise_rates[t], s.signal_rates[tp], s.noise_rates[tp]], rtol=1e-7)
-    with pytest.raises(NotImplementedError):
-        Scheduler(active_tcd=True)
+        nxt = [s.signal_rates[ts[i + 1]], s.noise_rates[ts[i + 1]]] if i + 1 < 25 else [1.0, 0.0]   # last step: x' = x0
+        np.testing.assert_allclose(tab[i], [s.signal_rates[t], s.noise_rates[t]] + nxt, rtol=1e-7)
+    assert not s.noise_coefficients().any()
+
+
+@pytest.mark.parametrize("impl", ["product", "oracle"])
+def test_tcd_scheduler_matches_reference(impl):
+    """TCD schedule and stochastic step (scheduler.py:136-237,286-307) against the reference's outputs under the
+    same seed of numpy's global generator; and the {A, B, C} coefficient form the sampler kernel evaluates."""
+    if impl == "oracle":
+        from oracle.sd_oracle import OracleScheduler as Scheduler
+    else:
+        from minsdtf_amd.scheduler import Scheduler
+
+    g = gold("g1_scheduler.npz")
+    for n in (1, 4, 25, 50):
+        s = Scheduler(active_tcd=True)
+        s.set_timesteps(n)
+        np.testing.assert_array_equal(np.asarray(s.timesteps), g[f"tcd_timesteps_{n}"])
+    for n in (4, 8):
+        s = Scheduler(active_tcd=True)
+        s.set_timesteps(n)
+        x = g[f"tcd_run{n}_latent0"]
+        np.random.seed(1000 + n)
+        for i, t in enumerate(s.timesteps):
+            x = s.step(g[f"tcd_run{n}_eps"][i], int(t), x)
+            np.testing.assert_array_equal(np.asarray(x), g[f"tcd_run{n}_out"][i])
+        if impl == "oracle":
+            continue
+        tab, cz = s.coefficient_table().astype(np.float64), s.noise_coefficients().astype(np.float64)
+        assert cz[-1] == 0.0 and (cz[:-1] > 0).all()
+        x = g[f"tcd_run{n}_latent0"].astype(np.float64)
+        np.random.seed(1000 + n)
+        for i in range(n):
+            e = g[f"tcd_run{n}_eps"][i]
+            x = tab[i, 2] * ((x - tab[i, 1] * e) / tab[i, 0]) + tab[i, 3] * e
+            if i < n - 1:
+                x = x + cz[i] * np.random.randn(*e.shape).astype(np.float32)
+            np.testing.assert_allclose(x, g[f"tcd_run{n}_out"][i], rtol=0, atol=2e-5)
 
 
 # ------------------------------------------------------------------ G3 / G4 / G7: host helpers

@@ -234,6 +234,25 @@ def main():
             eps_all.append(eps)
         g1[f"run{n}_eps"] = np.stack(eps_all)
         g1[f"run{n}_out"] = np.stack(outs)
+    # TCD sampler (scheduler.py:136-237,286-307): schedule and the stochastic step under a seeded global numpy RNG
+    rng_t = np.random.default_rng(43)
+    for n in (1, 4, 25, 50):
+        S = sch_mod.Scheduler(active_tcd=True)
+        S.set_timesteps(n)
+        g1[f"tcd_timesteps_{n}"] = np.asarray(S.timesteps)
+    for n in (4, 8):
+        S = sch_mod.Scheduler(active_tcd=True)
+        S.set_timesteps(n)
+        x = rng_t.standard_normal((2, 8, 8, 4)).astype(np.float32)
+        g1[f"tcd_run{n}_latent0"] = x
+        np.random.seed(1000 + n)
+        outs, eps_all = [], []
+        for t in S.timesteps:
+            eps = rng_t.standard_normal((2, 8, 8, 4)).astype(np.float32)
+            x = S.step(eps, t, x)
+            outs.append(np.asarray(x, dtype=np.float64))
+            eps_all.append(eps)
+        g1[f"tcd_run{n}_eps"], g1[f"tcd_run{n}_out"] = np.stack(eps_all), np.stack(outs)
     np.savez_compressed(os.path.join(OUT, "g1_scheduler.npz"), **g1)
 
     # ---------------------------------------------------------------- G6 checkpoint tables
