@@ -314,6 +314,7 @@ class StableDiffusionBase:
         self._engines: Dict[tuple, DenoiseEngine] = {}
         self.denoise_streams = None  # None / 1: cond+uncond as one fused batch; 2: two concurrent HIP streams
         self.text_frontend = None
+        self.bpe_path = None  # local copy of CLIP's bpe_simple_vocab_16e6.txt.gz (or $MSD_BPE_PATH) for string prompts
         self.unconditional_context = None  # (77, 768) embedding of the empty prompt, supplied by the caller
 
     # ---- public entry points (reference :84-139)
@@ -355,9 +356,9 @@ class StableDiffusionBase:
         * an integer array of CLIP token ids, (77,) or (k, 77) (start / end / padding tokens included):
           run through the CLIP embedding + text transformer on the device (SURVEY.md §8f rank 3);
           k chunks are concatenated along the token axis like the reference's long prompts;
-        * a string: needs the BPE tokenizer and prompt weighting, which are not rebuilt here (the vocabulary
-          file is a download) — install ``text_frontend`` (any object with
-          ``encode(prompt, embedding_data) -> ndarray``)."""
+        * a string: tokenizer + prompt weighting (minsdtf_amd/text.py, reference :176-215) in front of the text
+          models; needs a local copy of CLIP's BPE merge list (``bpe_path`` / ``$MSD_BPE_PATH``), or a
+          ``text_frontend`` (any object with ``encode(prompt, embedding_data) -> ndarray``)."""
         if isinstance(prompt, torch.Tensor):
             prompt = prompt.detach().cpu().numpy()
         if isinstance(prompt, np.ndarray):
@@ -366,9 +367,50 @@ class StableDiffusionBase:
             return np.asarray(prompt, dtype=np.float32)
         if self.text_frontend is not None:
             return np.asarray(self.text_frontend.encode(prompt, embedding_data), dtype=np.float32)
-        raise NotImplementedError(
-            "string prompts need the CLIP tokenizer, which this path does not rebuild; pass CLIP token ids "
-            "(int array (77,)), the (77k,768) text embedding, or set StableDiffusion.text_frontend")
+        # reference :176-215: optional textual-inversion vectors, then tokenizer + prompt weighting + the text models
+        from .text import get_weighted_text_embeddings
+
+        embedding, count = None, 0
+        if embedding_data is not None and isinstance(embedding_data, str):
+            embedding = self.load_embedding(embedding_data)
+            if embedding is None:
+                raise ValueError(f"failed to load embedding file: {embedding_data}.")
+            count = embedding.shape[0]
+            embedding = np.expand_dims(embedding, axis=0)
+        return get_weighted_text_embeddings(self.tokenizer, self.text_clip_embedding, self.text_encoder, prompt,
+                                            model_max_length=MAX_PROMPT_LENGTH, embedding=embedding,
+                                            embedding_tokens_count=count, pad_token_id=49407)
+
+    def load_embedding(self, embedding_path):
+        """Textual-inversion file -> (n_vectors, 768) array or None (reference :71-82)."""
+        if not os.path.exists(str(embedding_path)):
+            return None
+        state = torch.load(embedding_path, map_location="cpu")
+        embedding = None
+        for value in (state.get("string_to_param", {}) if isinstance(state, dict) else {}).values():
+            if value.dtype in (torch.float32, torch.float16):
+                embedding = value.detach().numpy()
+        return embedding
+
+    @property
+    def tokenizer(self):
+        """CLIP BPE tokenizer (reference :533-541).  The merge list is a download in the reference; here it is a
+        local file: StableDiffusion.bpe_path or $MSD_BPE_PATH."""
+        if self._tokenizer is None:
+            path = getattr(self, "bpe_path", None) or os.environ.get("MSD_BPE_PATH")
+            if not path or not os.path.exists(path):
+                raise NotImplementedError(
+                    "string prompts need CLIP's BPE merge list (bpe_simple_vocab_16e6.txt.gz), which cannot be downloaded here: "
+                    "set StableDiffusion.bpe_path / $MSD_BPE_PATH, or pass CLIP token ids (int array (77,)), the (77k,768) "
+                    "text embedding, or set StableDiffusion.text_frontend")
+            from .text import SimpleTokenizer
+
+            self._tokenizer = SimpleTokenizer(path)
+        return self._tokenizer
+
+    @tokenizer.setter
+    def tokenizer(self, value):
+        self._tokenizer = value
 
     def encode_tokens(self, tokens) -> np.ndarray:
         """CLIP token ids (k, 77) -> context (77k, 768): embedding lookup + text transformer on the device

@@ -102,6 +102,115 @@ def fake_encoder(img):
     return np.concatenate([m, m.mean(axis=-1, keepdims=True)], axis=-1).astype(np.float32) * 0.7
 
 
+TOKENIZER_STRINGS = [
+    "a photograph of an astronaut riding a horse", "A PHOTOGRAPH, of an Astronaut!!  riding\ta horse...", "the cat's hat isn't here; they'll say we've won",
+    "3 dogs and 42 cats in 2024", "caf\u00e9 na\u00efve \u65e5\u672c\u8a9e \U0001f600", "&lt;b&gt;bold&amp;amp;brave&lt;/b&gt;", "  ", "*", "masterpiece,best quality,(ultra-detailed:1.2)",
+    "<|startoftext|>hello<|endoftext|>", "supercalifragilisticexpialidocious antidisestablishmentarianism",
+]
+PROMPTS = [
+    "a photograph of an astronaut riding a horse",
+    "a (very beautiful:1.3) [blurry] ((masterpiece)) of a cat, \\(literal\\)",
+    ", ".join(["a photograph of an (astronaut:1.2) riding a [horse] on the moon, highly detailed"] * 12),   # 150 < tokens <= 225: 3 windows
+    "",
+]
+
+
+def train_toy_bpe(n_merges=400):
+    """A small merge list in CLIP's file format, learnt from a toy corpus (the real list is a download)."""
+    sys.path.insert(0, ROOT)
+    from minsdtf_amd.text import byte_alphabet
+
+    corpus = ("a photograph of an astronaut riding a horse on the moon highly detailed masterpiece best quality ultra detailed "
+              "the cat hat is not here they will say we have won dogs and cats in bold brave very beautiful blurry literal "
+              "hello super cali fragilistic expiali docious anti dis establishment arianism cafe naive riding photo graph ") * 3
+    enc = byte_alphabet()
+    words = {}
+    for w in corpus.split():
+        sym = tuple(enc[b] for b in w.encode("utf-8"))
+        sym = sym[:-1] + (sym[-1] + "</w>",)
+        words[sym] = words.get(sym, 0) + 1
+    merges = []
+    for _ in range(n_merges):
+        counts = {}
+        for sym, c in words.items():
+            for p in zip(sym, sym[1:]):
+                counts[p] = counts.get(p, 0) + c
+        if not counts:
+            break
+        best = max(sorted(counts), key=lambda p: counts[p])
+        merges.append(best)
+        new_words = {}
+        for sym, c in words.items():
+            out, i = [], 0
+            while i < len(sym):
+                if i + 1 < len(sym) and (sym[i], sym[i + 1]) == best:
+                    out.append(sym[i] + sym[i + 1])
+                    i += 2
+                else:
+                    out.append(sym[i])
+                    i += 1
+            new_words[tuple(out)] = new_words.get(tuple(out), 0) + c
+        words = new_words
+    return "#version: toy\n" + "\n".join(" ".join(m) for m in merges)
+
+
+class FakeClipEmbedding:
+    """Deterministic numpy stand-ins for TextClipEmbedding / TextEncoder (dim 8) for the prompt-weighting goldens."""
+
+    def predict_on_batch(self, x):
+        ids, pos = np.asarray(x[0], dtype=np.float64), np.asarray(x[1], dtype=np.float64)
+        base = ids[..., None] * 0.37 + pos[..., None] * 0.11 + np.arange(8)[None, None, :] * 0.5
+        return np.sin(base).astype(np.float32)
+
+
+class FakeTextEncoder:
+    def predict_on_batch(self, emb):
+        emb = np.asarray(emb, dtype=np.float32)
+        mix = np.cumsum(emb, axis=1) / np.arange(1, emb.shape[1] + 1, dtype=np.float32)[None, :, None]   # causal mixing
+        return np.tanh(emb * 1.3 + mix + 0.2).astype(np.float32)
+
+
+def make_text_goldens():
+    """G10: the reference's SimpleTokenizer and get_weighted_text_embeddings on a toy merge list (needs the keras stub)."""
+    import gzip
+
+    import stable_diffusion.clip_tokenizer as ref_tok
+    import stable_diffusion.long_prompt_weighting as ref_lpw
+
+    bpe_path = os.path.join(OUT, "g10_toy_bpe_merges.txt.gz")
+    with gzip.GzipFile(bpe_path, "wb", mtime=0) as f:
+        f.write(train_toy_bpe().encode("utf-8"))
+    tok = ref_tok.SimpleTokenizer(bpe_path)
+    g10 = {"vocab_size": len(tok.vocab), "start": tok.start_of_text, "end": tok.end_of_text,
+           "encode": [[s, tok.encode(s)] for s in TOKENIZER_STRINGS],
+           "decode": [tok.decode(tok.encode(s)) for s in TOKENIZER_STRINGS[:4]]}
+    tok.add_tokens(["<cat-toy>", "the"])
+    g10["after_add"] = {"vocab_size": len(tok.vocab), "encode": tok.encode("a <cat-toy> on the moon")}
+    json.dump(g10, open(os.path.join(OUT, "g10_tokenizer.json"), "w"), indent=0)
+    tok = ref_tok.SimpleTokenizer(bpe_path)
+    arrays = {}
+    ti = np.random.default_rng(9).standard_normal((1, 3, 8)).astype(np.float32)
+    arrays["ti_embedding"] = ti
+    for i, prompt in enumerate(PROMPTS):
+        for nbm in (False, True):
+            arrays[f"p{i}_nbm{int(nbm)}"] = ref_lpw.get_weighted_text_embeddings(tok, FakeClipEmbedding(), FakeTextEncoder(), prompt,
+                                                                                  no_boseos_middle=nbm, pad_token_id=tok.end_of_text)
+    arrays["p1_skipw"] = ref_lpw.get_weighted_text_embeddings(tok, FakeClipEmbedding(), FakeTextEncoder(), PROMPTS[1], skip_weighting=True,
+                                                             pad_token_id=tok.end_of_text)
+    arrays["p2_mult2"] = ref_lpw.get_weighted_text_embeddings(tok, FakeClipEmbedding(), FakeTextEncoder(), PROMPTS[2], max_embeddings_multiples=2,
+                                                             pad_token_id=tok.end_of_text)
+    for i in (0, 2):
+        arrays[f"p{i}_ti"] = ref_lpw.get_weighted_text_embeddings(tok, FakeClipEmbedding(), FakeTextEncoder(), PROMPTS[i], embedding=ti,
+                                                                  embedding_tokens_count=3, pad_token_id=tok.end_of_text)
+    arrays["batch"] = ref_lpw.get_weighted_text_embeddings(tok, FakeClipEmbedding(), FakeTextEncoder(), [PROMPTS[0], PROMPTS[1]],
+                                                          pad_token_id=tok.end_of_text)
+    np.savez_compressed(os.path.join(OUT, "g10_prompt_weighting.npz"), **arrays)
+    cases = ["normal text", "an (important) word", "(unbalanced", "\\(literal\\]", "(unnecessary)(parens)", "a (((house:1.3)) [on] a (hill:0.5), sun, (((sky))).",
+             "", "\\", "a:b (c:d) :1.5) x", "[[x]] (y:+.5) (z:-2.)", "]) unopened ([ nested (a [b:1.2) c]"]
+    json.dump([{"prompt": c, "parsed": ref_lpw.parse_prompt_attention(c)} for c in cases],
+              open(os.path.join(OUT, "g5_prompt_attention.json"), "w"), indent=1)
+
+
 def lora_fixture(seed=11):
     """A small kohya-style LoRA state dict: every UNet layer type the reference can restore (names made
     from its own UNET_KEY_MAPPING), a few text-encoder entries and a few names it cannot restore."""
@@ -394,6 +503,7 @@ def main():
         ref_te.TextClipEmbedding(77, ckpt_path=tmp.name)
         g9["text_clip_embedding"] = [[k, p] for k, p in captured["mapping"]]
     json.dump(g9, open(os.path.join(OUT, "g9_text_tables.json"), "w"), indent=0, sort_keys=True)
+    make_text_goldens()
     print("goldens written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f:36s} {os.path.getsize(os.path.join(OUT, f)):8d} B")
