@@ -229,14 +229,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         bf16x8 pb[2][2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            float mx = fmaxf(fmaxf(sacc[0][f][0], sacc[0][f][1]), fmaxf(sacc[0][f][2], sacc[0][f][3]));
+            // linear max chain: every pair of scores folds into one v_max3_f32
+            float mx = fmaxf(sacc[0][f][0], sacc[0][f][1]);
+            mx = fmaxf(fmaxf(mx, sacc[0][f][2]), sacc[0][f][3]);
 #pragma unroll
-            for (int kf = 1; kf < 4; ++kf)
-                mx = fmaxf(fmaxf(fmaxf(mx, sacc[kf][f][0]), fmaxf(sacc[kf][f][1], sacc[kf][f][2])), sacc[kf][f][3]);
+            for (int kf = 1; kf < 4; ++kf) {
+                mx = fmaxf(fmaxf(mx, sacc[kf][f][0]), sacc[kf][f][1]);
+                mx = fmaxf(fmaxf(mx, sacc[kf][f][2]), sacc[kf][f][3]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[f], mx);
-            const float alpha = __builtin_amdgcn_exp2f((mrun[f] - mnew) * p.sl2);
+            // After the first tiles the running maximum rarely moves: when it did not move for ANY query of the
+            // wave the rescale factor is exactly 1, so skip its exp2 and the DF x 4 multiplies of O.
+            const bool moved = __builtin_amdgcn_ballot_w64(mnew > mrun[f]) != 0;
+            float alpha = 1.0f;
+            if (moved) alpha = __builtin_amdgcn_exp2f((mrun[f] - mnew) * p.sl2);
             mrun[f] = mnew;
             const float nm = -mnew * p.sl2;
             float ls = 0.f;
@@ -249,9 +257,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                     if (!ONES_ROW) ls += pv;
                 }
             if (!ONES_ROW) lrun[f] = lrun[f] * alpha + ls;
+            if (moved) {
 #pragma unroll
-            for (int df = 0; df < DF; ++df) {
-                oacc[df][f][0] *= alpha; oacc[df][f][1] *= alpha; oacc[df][f][2] *= alpha; oacc[df][f][3] *= alpha;
+                for (int df = 0; df < DF; ++df) {
+                    oacc[df][f][0] *= alpha; oacc[df][f][1] *= alpha; oacc[df][f][2] *= alpha; oacc[df][f][3] *= alpha;
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
