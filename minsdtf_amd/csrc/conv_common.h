@@ -16,6 +16,21 @@ struct CGArgs {
 
 static __device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows (one copy per TU)
 
+// In-kernel timeline stamps (tools/gemm_stamps.py; `make stamps` builds a separate instrumented
+// library, the product library never carries them): thread 0 of every workgroup records the 100 MHz
+// wall clock at a few points of conv_gemm_dma_kernel and its epilogue.
+#ifdef MSD_STAMPS
+static __device__ unsigned long long g_stamps[8 * 8192];
+#define MSD_STAMP(i)                                                                                             \
+    do {                                                                                                         \
+        if (threadIdx.x == 0) g_stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#define MSD_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define MSD_STAMP(i)
+#define MSD_STAMP_DRAIN()
+#endif
+
 // ---- epilogue for one group of 4 consecutive output columns of one row -----------------------
 __device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, int step, float v[4]) {
     if (p.bias) {
@@ -88,47 +103,146 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
         return;
     }
     const int step = p.step_ptr ? *p.step_ptr : 0;
+    // Two passes: every load of the epilogue first, then the arithmetic and the stores.  `out` may alias
+    // `residual` as far as the compiler knows, so in a single pass each group's loads wait behind the
+    // previous group's store: MI x NJ serial memory round trips (in-kernel stamps: 4.4 us of a 9 us launch
+    // for the 128x128 tile).  Batched, the epilogue is one load round trip plus the stores.
+    // The loads are UNCONDITIONAL per element (addresses clamped into the tensor; one wave-uniform branch
+    // around each whole batch) and end in one explicit vmcnt(0): a per-element "load or zero" select makes
+    // hipcc branch around every load and, at the control-flow joins, wait vmcnt(0) before every group —
+    // which on gfx9 also waits for the previous group's STORE (cdna_hip_programming.md §5, trap (c)).
+    float4 bv[NJ];
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + min(nbase + j * 16 + 4 * g, p.N - 4));
+    } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.act == MSD_ACT_GEGLU) {
+        if constexpr (NJ % 2 == 0) {   // (x|gate pairs: the host never sends GEGLU to an odd-NJ tile)
+            uint2 rr[MI][NJ / 2];
+            if (p.residual) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const size_t mo = (size_t)min(mrow[i] + r, p.M - 1) * p.res_ld;
+#pragma unroll
+                    for (int j = 0; j < NJ; j += 2)
+                        rr[i][j / 2] = *reinterpret_cast<const uint2*>(p.residual + mo + min(((nbase + j * 16) >> 1) + 4 * g, (p.N >> 1) - 4));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; j += 2) rr[i][j / 2] = make_uint2(0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every epilogue load has landed
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = mrow[i] + r;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < NJ; j += 2) {
+                    const int nb = nbase + j * 16;  // multiple of 32: x columns nb+[0,16), gate nb+16+[0,16)
+                    if (nb + 4 * g >= p.N) continue;
+                    float v[4];
+                    v[0] = geglu_f(acc[j][i][0] + bv[j].x, acc[j + 1][i][0] + bv[j + 1].x);
+                    v[1] = geglu_f(acc[j][i][1] + bv[j].y, acc[j + 1][i][1] + bv[j + 1].y);
+                    v[2] = geglu_f(acc[j][i][2] + bv[j].z, acc[j + 1][i][2] + bv[j + 1].z);
+                    v[3] = geglu_f(acc[j][i][3] + bv[j].w, acc[j + 1][i][3] + bv[j + 1].w);
+                    const int no = (nb >> 1) + 4 * g;
+                    const uint2 q = rr[i][j / 2];
+                    v[0] += bf_lo(q.x); v[1] += bf_hi(q.x); v[2] += bf_lo(q.y); v[3] += bf_hi(q.y);
+                    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
+                }
+            }
+        }
+        return;
+    }
+    const bool plain_res = p.split_mode == 0 && p.residual != nullptr;
+    uint2 rr[MI][NJ];
+    float4 rv[MI][NJ];
+    int bidx[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bidx[i] = (p.rowvec || p.split_mode) ? min(mrow[i] + r, p.M - 1) / p.hw_out : 0;
+    if (plain_res) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const size_t mo = (size_t)min(mrow[i] + r, p.M - 1) * p.res_ld;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                rr[i][j] = *reinterpret_cast<const uint2*>(p.residual + mo + min(nbase + j * 16 + 4 * g, p.N - 4));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rr[i][j] = make_uint2(0, 0);
+    }
+    if (p.rowvec) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float* rvp = p.rowvec + (size_t)step * p.rv_step_stride + (size_t)bidx[i] * p.rv_batch_stride;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rv[i][j] = *reinterpret_cast<const float4*>(rvp + min(nbase + j * 16 + 4 * g, p.N - 4));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every epilogue load has landed
+    MSD_STAMP_DRAIN();
+    MSD_STAMP(6);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mrow[i] + r;
         if (m >= p.M) continue;
-        const int b = m / p.hw_out;
-        if (p.act == MSD_ACT_GEGLU) {
-            if constexpr (NJ % 2 == 0) {   // (x|gate pairs: the host never sends GEGLU to an odd-NJ tile)
+        const int b = bidx[i];
 #pragma unroll
-            for (int j = 0; j < NJ; j += 2) {
-                const int nb = nbase + j * 16;  // multiple of 32: x columns nb+[0,16), gate nb+16+[0,16)
-                const int n = nb + 4 * g;
-                if (n >= p.N) continue;
-                float v[4];
-                float4 bx = make_float4(0, 0, 0, 0), bg = bx;
-                if (p.bias) {
-                    bx = *reinterpret_cast<const float4*>(p.bias + n);
-                    bg = *reinterpret_cast<const float4*>(p.bias + n + 16);
+        for (int j = 0; j < NJ; ++j) {
+            const int n = nbase + j * 16 + 4 * g;
+            if (n >= p.N) continue;
+            float v[4] = {acc[j][i][0] + bv[j].x + rv[i][j].x, acc[j][i][1] + bv[j].y + rv[i][j].y,
+                          acc[j][i][2] + bv[j].z + rv[i][j].z, acc[j][i][3] + bv[j].w + rv[i][j].w};
+            if (p.act == MSD_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            } else if (p.act == MSD_ACT_QUICK_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_rcp(1.0f + __expf(-1.702f * v[e]));
+            }
+            if (p.split_mode == 0) {
+                v[0] += bf_lo(rr[i][j].x); v[1] += bf_hi(rr[i][j].x); v[2] += bf_lo(rr[i][j].y); v[3] += bf_hi(rr[i][j].y);
+                if (p.out_f32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
                 }
-                v[0] = geglu_f(acc[j][i][0] + bx.x, acc[j + 1][i][0] + bg.x);
-                v[1] = geglu_f(acc[j][i][1] + bx.y, acc[j + 1][i][1] + bg.y);
-                v[2] = geglu_f(acc[j][i][2] + bx.z, acc[j + 1][i][2] + bg.z);
-                v[3] = geglu_f(acc[j][i][3] + bx.w, acc[j + 1][i][3] + bg.w);
-                const int no = (nb >> 1) + 4 * g;
-                if (p.residual) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.residual + (size_t)m * p.res_ld + no);
-                    v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
-                }
+            } else {
                 uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
-            }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = nbase + j * 16 + 4 * g;
-                if (n >= p.N) continue;
-                float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-                cg_store4(p, m, b, n, step, v);
+                if (n < p.ns0) {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+                } else if (n < p.ns0 + p.ns1) {
+                    *reinterpret_cast<uint2*>(p.out1 + (size_t)m * p.out1_ld + (n - p.ns0)) = o;
+                } else {
+                    const int nv = p.N - p.ns0 - p.ns1;
+                    const int nn = n - p.ns0 - p.ns1;
+                    const int sidx = m - b * p.hw_out;
+                    bf16_t* dst = p.out2 + ((size_t)b * nv + nn) * p.out2_ld + sidx;
+                    dst[0] = (bf16_t)(o.x & 0xFFFF);
+                    dst[(size_t)p.out2_ld] = (bf16_t)(o.x >> 16);
+                    dst[(size_t)2 * p.out2_ld] = (bf16_t)(o.y & 0xFFFF);
+                    dst[(size_t)3 * p.out2_ld] = (bf16_t)(o.y >> 16);
+                }
             }
         }
     }
+    MSD_STAMP(7);
 }
 
 // ---- LDS-DMA helpers (compiler-invisible on purpose: see cdna_hip_programming.md §5.7) ---------
@@ -144,6 +258,19 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+// same, source = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
+__device__ __forceinline__ void dma16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
 template <int N>

@@ -23,13 +23,27 @@
 //     reduced by a second tiny kernel, deterministically (no atomics).
 #include "conv_common.h"
 
+#ifdef MSD_STAMPS
+extern "C" int msd_debug_stamps(unsigned long long* host_out, int count) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count);
+}
+#endif
+
 // Tile configurations (BM x BN output tile, WGM x WGN waves, each wave (BM/WGM) x (BN/WGN)):
 //   128x128 / 2x4 waves (64x32 per wave)   128x64 / 2x2 (64x32)   64x64 / 2x2 (32x32)
 //   64x128 / 2x2 (32x64)                   256x128 / 4x2 (64x64)
 // Smaller tiles put more workgroups on the chip for the small-M layers of the 16x16 / 8x8 levels;
 // larger tiles move fewer L2->LDS bytes per FLOP (the per-CU LDS-DMA rate is what bounds this
 // kernel).  The host picks per layer shape (measured table, minsdtf_amd/tuning.py).
-template <int BM, int BN, int WGM, int WGN, int S>
+//
+// DENSE = true is the 1x1 / Dense form (ksize 1, stride 1, no upsampling): a row of A is one pixel's
+// channel vector, so the loader keeps ONE 32-bit byte offset per staged row and a K tile costs one
+// v_add + one LDS-DMA (scalar base + vector offset) per piece.  The general form generates tap /
+// padding / stride / upsampling addresses (two scalar divisions and a bounds test per piece) for every
+// K tile; in-kernel stamps showed that work sitting on the critical path of each K step (~1.2k cycles
+// per step against 128-256 of MFMA).  Both forms now issue the fragment ds_reads of the current tile
+// BEFORE the address generation + DMA of the tile S-1 ahead, so that work overlaps the LDS latency.
+template <int BM, int BN, int WGM, int WGN, int S, bool DENSE>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGArgs p) {
     constexpr int NW = WGM * WGN;               // waves per workgroup
     constexpr int NT = NW * 64;                 // threads
@@ -48,6 +62,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 15, g = lane >> 4;
+    MSD_STAMP(0);
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one),
     // so give each XCD a CONTIGUOUS run of tiles: neighbouring tiles re-read the same pixel rows
     // (9 taps, all n-tiles) and then hit that XCD's private 4 MiB L2 instead of the Infinity Cache.
@@ -69,11 +84,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     const int Wl = p.upsample ? 2 * p.w_in : p.w_in;
     const char* zero = reinterpret_cast<const char*>(g_zero_page) + cpos * 16;
     int ab[AR], ay[AR], ax[AR], asrc[AR];
+    uint32_t aoff0[AR], aoff1[AR], woff[BR];   // DENSE: byte offsets of the staged rows from a0 / a1 / w
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         const int row = lrow + RPP * i;
         const int m = m0 + row;
         asrc[i] = (cpos ^ ((row >> 1) & 7)) * 8;  // swizzle on the SOURCE chunk (LDS-DMA writes linearly)
+        if constexpr (DENSE) {
+            // rows past M re-read the last row: their accumulators are never stored
+            const uint32_t mc = (uint32_t)min(m, p.M - 1);
+            aoff0[i] = (mc * (uint32_t)p.c0 + (uint32_t)asrc[i]) * 2u;
+            aoff1[i] = (mc * (uint32_t)p.c1 + (uint32_t)asrc[i]) * 2u;
+            ab[i] = ay[i] = ax[i] = 0;
+            continue;
+        }
         if (m < p.M) {
             const int b = m / p.hw_out;
             const int rem = m - b * p.hw_out;
@@ -92,11 +116,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         const int row = lrow + RPP * i;
         const int n = n0 + row;
         wsrc[i] = (row < BN && n < p.N) ? (p.w + (size_t)n * p.K + (cpos ^ ((row >> 1) & 7)) * 8) : nullptr;
+        // DENSE: columns past N re-read the last weight row (never stored)
+        woff[i] = ((uint32_t)min(n, p.N - 1) * (uint32_t)p.K + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 8)) * 2u;
     }
     // LDS destination of this wave's pass i: 8 rows x 128 B, lane-linear
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
 
     auto issue_tile = [&](int kt, int stage) {
+        if constexpr (DENSE) {
+            const uint32_t sbase = lds_wave + (uint32_t)stage * ST_BYTES;
+            const int c = kt * 64;
+            const bool first = c < p.c0;                       // wave-uniform: which tensor of the concat
+            const bf16_t* abase = first ? p.a0 : p.a1;
+            const uint32_t cb = (uint32_t)(first ? c : c - p.c0) * 2u;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) dma16s(abase, (first ? aoff0[i] : aoff1[i]) + cb, sbase + (uint32_t)(RPP * i) * 128u);
+#pragma unroll
+            for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * 128u, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
+            return;
+        }
         const int tap = kt / p.nkc;
         const int c = (kt - tap * p.nkc) * 64;
         const int ky = tap / p.ksize;
@@ -129,6 +167,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < nkt) issue_tile(kt_begin + s, s);
+    MSD_STAMP(1);
 
     const int swz = r >> 1;  // (row>>1)&7 for row = 16*q + r
     int stage = 0;
@@ -137,33 +176,46 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         const int later = min(nkt, it + S - 1) - (it + 1);
         wait_vmcnt_tiles<L, S - 2>(later);
         __builtin_amdgcn_s_barrier();  // tile `it` visible to all waves; stage (it-1)%S free for reuse
-        if (it + S - 1 < nkt) {
+#ifdef MSD_STAMPS
+        if (it == 0) MSD_STAMP(2);
+        if (it == (nkt >> 1)) MSD_STAMP(5);
+#endif
+        const char* bA = smem + stage * ST_BYTES + (wm * WMT + r) * 128;
+        const char* bB = smem + stage * ST_BYTES + A_BYTES + (wn * WNT + r) * 128;
+        // fragments of tile `it` first (their LDS latency runs under the address generation + DMA issue of
+        // the tile S-1 ahead), then the MFMAs
+        bf16x8 af[2][MI], wf[2][NJ];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + g) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coff);
+        }
+        if (it + S - 1 < nkt) {   // stage (it-1)%S: every wave finished reading it before the barrier above
             int st = stage + S - 1;
             if (st >= S) st -= S;
             issue_tile(kt_begin + it + S - 1, st);
         }
-        const char* bA = smem + stage * ST_BYTES + (wm * WMT + r) * 128;
-        const char* bB = smem + stage * ST_BYTES + A_BYTES + (wn * WNT + r) * 128;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + g) ^ swz) << 4;
-            bf16x8 af[MI], wf[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coff);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        }
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
         if (++stage == S) stage = 0;
     }
+    MSD_STAMP(3);
     int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * WMT + i * 16;
     cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WNT, r, g);
+#ifdef MSD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
+    MSD_STAMP(4);
+#endif
 }
 
 // ---- first-generation kernel: register-staged, one tile ahead (kept for A/B runs) --------------
@@ -344,7 +396,9 @@ int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int varian
 
 static bool g_cg_attr_done = false;
 static int g_conv_impl = 1;  // 1 = LDS-DMA ring (default), 0 = register-staged first-generation kernel
+static int g_conv_dense = 1; // 1 = 1x1 / Dense layers take the DENSE loader (default), 0 = the general loader (A/B runs)
 void msd_set_conv_impl(int v) { g_conv_impl = v; }
+void msd_set_conv_dense(int v) { g_conv_dense = v; }
 
 int msd_conv_gemm_init() {
     if (g_cg_attr_done) return MSD_OK;
@@ -354,9 +408,12 @@ int msd_conv_gemm_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128);
-#define X(id, bm, bn, wgm, wgn, st, code)                                                                    \
-    if (e == hipSuccess)                                                                                     \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<bm, bn, wgm, wgn, st>),  \
+#define X(id, bm, bn, wgm, wgn, st, code)                                                                           \
+    if (e == hipSuccess)                                                                                            \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<bm, bn, wgm, wgn, st, false>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, cfg_lds(bm, bn, wgm * wgn * 64, st));   \
+    if (e == hipSuccess)                                                                                            \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<bm, bn, wgm, wgn, st, true>),   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg_lds(bm, bn, wgm * wgn * 64, st));
     MSD_TILE_CFGS(X)
 #undef X
@@ -493,12 +550,20 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.tiles_m = tiles_m;
     a.m_fast = (a.N > a.M) ? 1 : 0;   // weights are the bigger operand: keep each weight panel on one XCD
     dim3 grid(tiles_m * a.tiles_n, slices);
+    // 1x1 / Dense form: 32-bit byte offsets from the tensor bases
+    const bool dense = g_conv_dense && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in &&
+                       (long long)a.M * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 < (1ll << 32) - 4096 &&
+                       (long long)a.N * a.K * 2 < (1ll << 32) - 4096;
     if (g_conv_impl == 1) {
         switch (cfg) {
 #define X(id, bm_, bn_, wgm, wgn, st, code)                                                                             \
     case id:                                                                                                            \
-        hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st>), grid, dim3(wgm * wgn * 64),                  \
-                           cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, a);                                           \
+        if (dense)                                                                                                      \
+            hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st, true>), grid, dim3(wgm * wgn * 64),        \
+                               cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, a);                                       \
+        else                                                                                                            \
+            hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st, false>), grid, dim3(wgm * wgn * 64),       \
+                               cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, a);                                       \
         break;
             MSD_TILE_CFGS(X)
 #undef X

@@ -1,0 +1,88 @@
+"""In-kernel timeline of conv_gemm_dma_kernel on one layer shape (needs `make -C minsdtf_amd/csrc stamps`).
+
+    python tools/gemm_stamps.py --m 512 --n 1280 --k 1280 --tile 64x64 [--stages 0] [--splitk 1] [--ksize 1]
+
+Thread 0 of every workgroup stamps the 100 MHz wall clock at: 0 entry, 1 ring primed (S-1 tiles issued),
+2 first tile landed (first barrier passed), 5 half of the K loop, 3 K loop done, 4 stores retired.  Printed:
+percentiles over workgroups of each interval, the spread of entry times (launch ramp) and the span from the
+first entry to the last exit (= the kernel's duration)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="512x1280x1280:64x64:0:1,8192x320x320:128x128:0:1",
+                    help="comma list of MxNxK:tile:stages:splitk (dense, ksize 1; M = 2*h*h)")
+    ap.add_argument("--dense", type=int, default=1, help="0 = general loader for 1x1 layers (A/B)")
+    args = ap.parse_args()
+    from minsdtf_amd import _lib
+
+    _lib.LIB_PATH = os.path.join(ROOT, "tools", "_build", "libminsdtf_hip_stamps.so")
+    from minsdtf_amd import ops
+
+    lib = _lib.load()
+    lib.msd_init()
+    lib.msd_set_option(b"conv_dense", args.dense)
+    lib.msd_debug_stamps.restype = C.c_int
+    lib.msd_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream()
+    for spec in args.shapes.split(","):
+        mnk, tile, stg, sk = spec.split(":")
+        M, N, K = (int(v) for v in mnk.split("x"))
+        tm, tn = (int(v) for v in tile.split("x"))
+        stg, sk = int(stg), int(sk)
+        h = int(round((M // 2) ** 0.5))
+        assert 2 * h * h == M
+        x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        ws = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(max(2, (300 << 20) // (N * K * 2)))][:24]
+        bias = torch.randn(N, device=dev)
+        res = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32)
+        calls = [ops.conv_gemm(a0=x, w=wi, out=out, batch=2, h_in=h, w_in=h, c0=K, N=N, ksize=1, bias=bias, residual=res,
+                               workspace=wsf, workspace_floats=wsf.numel(), splitk=sk, tile_m=tm, tile_n=tn, stages=stg)
+                 for wi in ws]
+        for c in calls:          # the last call's stamps survive; weights rotate so they come from HBM
+            c(st.cuda_stream)
+        torch.cuda.synchronize()
+        bm = tm
+        nwg = ((M + bm - 1) // bm) * ((N + tn - 1) // tn) * sk
+        buf = np.zeros(8 * 8192, np.uint64)
+        rc = lib.msd_debug_stamps(buf.ctypes.data, buf.size)
+        assert rc == 0, rc
+        t = buf.reshape(8192, 8)[:min(nwg, 8192)].astype(np.int64)
+        t0 = t[:, 0].min()
+        us = lambda a: a / 100.0  # 100 MHz ticks -> us
+
+        def pct(a):
+            return " ".join(f"{us(np.percentile(a, q)):6.2f}" for q in (0, 25, 50, 75, 100))
+
+        nk = K // 64 // sk
+        print(f"--- M={M} N={N} K={K} tile {tm}x{tn} stages {stg} splitk {sk}: {nwg} workgroups, {nk} K tiles each")
+        print(f"   percentiles over workgroups (us)        min    p25    p50    p75    max")
+        print(f"   entry time after first entry        {pct(t[:, 0] - t0)}")
+        print(f"   prologue (entry -> ring primed)      {pct(t[:, 1] - t[:, 0])}")
+        print(f"   first tile (primed -> landed)        {pct(t[:, 2] - t[:, 1])}")
+        print(f"   K loop first half                    {pct(t[:, 5] - t[:, 2])}")
+        print(f"   K loop second half                   {pct(t[:, 3] - t[:, 5])}")
+        print(f"   epilogue: loop done -> loads back    {pct(t[:, 6] - t[:, 3])}")
+        print(f"   epilogue: arithmetic + store issue   {pct(t[:, 7] - t[:, 6])}")
+        print(f"   epilogue: stores retired             {pct(t[:, 4] - t[:, 7])}")
+        print(f"   workgroup lifetime                   {pct(t[:, 4] - t[:, 0])}")
+        print(f"   exit time after first entry          {pct(t[:, 4] - t0)}")
+        print(f"   kernel span {us(t[:, 4].max() - t0):.2f} us; per K tile in the loop {us(np.median(t[:, 3] - t[:, 2])) / max(1, nk - 1):.3f} us",
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()
