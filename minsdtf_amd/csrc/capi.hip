@@ -26,6 +26,7 @@ extern "C" int msd_init(void) {
 void msd_set_conv_impl(int v);
 void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
+void msd_set_gn_wide(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "conv_impl" (1 = LDS-DMA ring
  * [default], 0 = first-generation register-staged kernel); "gn_impl" (1 = single-launch per-group
  * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
@@ -36,6 +37,10 @@ extern "C" int msd_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "conv_dense") == 0) {   // 1 = DENSE loader for 1x1 / Dense layers [default], 0 = general loader
         msd_set_conv_dense(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "gn_wide") == 0) {   // 1 = 1024-thread GroupNorm workgroups for mid-sized tensors [default]
+        msd_set_gn_wide(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "gn_impl") == 0) {

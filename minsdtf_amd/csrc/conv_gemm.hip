@@ -170,6 +170,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     MSD_STAMP(1);
 
     const int swz = r >> 1;  // (row>>1)&7 for row = 16*q + r
+    struct Frags { bf16x8 a[2][MI], w[2][NJ]; };
+    auto read_frags = [&](Frags& f, int stg) {
+        const char* bA = smem + stg * ST_BYTES + (wm * WMT + r) * 128;
+        const char* bB = smem + stg * ST_BYTES + A_BYTES + (wn * WNT + r) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + g) ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) f.a[ks][i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) f.w[ks][j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coff);
+        }
+    };
+    auto mfma_tile = [&](const Frags& f) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[ks][j], f.a[ks][i], acc[j][i], 0, 0, 0);
+    };
+    // (Tried: reading the fragments of tile it+1 into a second register set before the MFMAs of tile it, for
+    //  rings of 4+ stages — 0.37 vs 0.31 us per K tile on the 64x64 tile: one tile fewer in flight costs more
+    //  than the overlapped LDS reads gain.)
     int stage = 0;
     for (int it = 0; it < nkt; ++it) {
         // retire tile `it`: all but the tiles issued after it may stay in flight
@@ -180,31 +205,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         if (it == 0) MSD_STAMP(2);
         if (it == (nkt >> 1)) MSD_STAMP(5);
 #endif
-        const char* bA = smem + stage * ST_BYTES + (wm * WMT + r) * 128;
-        const char* bB = smem + stage * ST_BYTES + A_BYTES + (wn * WNT + r) * 128;
         // fragments of tile `it` first (their LDS latency runs under the address generation + DMA issue of
         // the tile S-1 ahead), then the MFMAs
-        bf16x8 af[2][MI], wf[2][NJ];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + g) ^ swz) << 4;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coff);
-        }
+        Frags f;
+        read_frags(f, stage);
         if (it + S - 1 < nkt) {   // stage (it-1)%S: every wave finished reading it before the barrier above
             int st = stage + S - 1;
             if (st >= S) st -= S;
             issue_tile(kt_begin + it + S - 1, st);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+        mfma_tile(f);
         if (++stage == S) stage = 0;
     }
     MSD_STAMP(3);
@@ -377,11 +387,17 @@ struct TileCfg { int bm, bn, threads, lds, stages; };
     X(10, 128, 80, 4, 1, 4, 4) \
     X(11, 64, 64, 2, 4, 4, 14) \
     X(12, 128, 64, 4, 2, 3, 13) \
-    X(13, 64, 128, 2, 4, 3, 13)
+    X(13, 64, 128, 2, 4, 3, 13) \
+    X(14, 128, 128, 2, 2, 3, 23) \
+    X(15, 128, 128, 2, 2, 4, 24) \
+    X(16, 128, 64, 2, 1, 4, 24)  \
+    X(17, 64, 128, 1, 2, 4, 24)
 // Last column = the `stages` request that selects the entry (the first entry of a tile size is its
 // default).  Codes 10 + depth are the same tile on 8 waves (32x16 / 32x32 per wave): two waves per SIMD
 // even when a launch puts one workgroup on a CU, so one wave's LDS-DMA issue and LDS latency overlap the
-// other's MFMAs.
+// other's MFMAs.  Codes 20 + depth: 64x64 per wave (4 / 2 waves): the fewest fragment ds_reads per MFMA (8 reads
+// feed 16 MFMAs) — with 32x32 or 64x32 wave tiles the LDS read port (128 B/clk per CU), not the matrix
+// cores, bounds the K loop.
 // (128x80: for N = 320 / 640 at small batch — 64 x 4 = 256 workgroups at M = 8192, one per CU, where
 //  64-wide tiles make 320 and 128-wide ones 192; the 80 weight rows are staged as 96)
 constexpr int cfg_lds(int bm, int bn, int threads, int st) { return st * (bm + (bn + threads / 8 - 1) / (threads / 8) * (threads / 8)) * 128; }
@@ -390,7 +406,7 @@ static const TileCfg g_cfgs[] = {
     MSD_TILE_CFGS(X)
 #undef X
 };
-constexpr int NUM_TILE_CFGS = 14;
+constexpr int NUM_TILE_CFGS = 18;
 
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream);
 
@@ -538,7 +554,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     }
     int cfg = -1;
     // (GEGLU pairs the fragments of a wave: the 8-wave 64x64 tile has a single one per wave)
-    const int stages_req = (q->act == MSD_ACT_GEGLU && q->stages >= 10) ? 0 : q->stages;
+    const int stages_req = (q->act == MSD_ACT_GEGLU && q->stages >= 10 && q->stages < 20) ? 0 : q->stages;
     for (int i = 0; i < NUM_TILE_CFGS; ++i)
         if (g_cfgs[i].bm == bm && g_cfgs[i].bn == bn && (cfg < 0 || g_cfgs[i].stages == stages_req)) cfg = i;
     // (the first entry of a tile size is its default ring depth; `stages` selects a deeper ring: more

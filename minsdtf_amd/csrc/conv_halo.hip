@@ -143,6 +143,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         // it-S+2 .. it-1 (loads complete in order, so "at most N outstanding" retires everything older).
         halo_wait<BR, HR, S - 2>(min(S - 2, nkt - 1 - it), since_halo <= S - 2);
         __builtin_amdgcn_s_barrier();
+        // fragments of this K step first, then the DMA issue of the tiles ahead (it runs under the LDS latency), then the MFMAs
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const char* bW = smem + 2 * H_BYTES + stage * W_BYTES + (wn * WNT + r) * 128;
+        const char* bH = smem + hbuf * H_BYTES;
+        int hrow[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) hrow[i] = (wm * MI + i + ky) * HW_ + kx + r;
+        bf16x8 af[2][MI], wf[2][NJ];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int wc = ((ks * 4 + g) ^ (r >> 1)) << 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[ks][i] = *reinterpret_cast<const bf16x8*>(bH + hrow[i] * 128 + (((ks * 4 + g) ^ ((hrow[i] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bW + j * 16 * 128 + wc);
+        }
         if (tap == 0 && c + 1 < c_end) { issue_halo(c + 1, hbuf ^ 1); since_halo = 0; }
         if (it + S - 1 < nkt) {
             issue_w(cw, tw, sw);
@@ -150,27 +167,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
             if (++sw == S) sw = 0;
         }
         ++since_halo;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const char* bW = smem + 2 * H_BYTES + stage * W_BYTES + (wn * WNT + r) * 128;
-        const char* bH = smem + hbuf * H_BYTES;
-        int hrow[MI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) hrow[i] = (wm * MI + i + ky) * HW_ + kx + r;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[MI], wf[NJ];
-            const int wc = ((ks * 4 + g) ^ (r >> 1)) << 4;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(bH + hrow[i] * 128 + (((ks * 4 + g) ^ ((hrow[i] >> 1) & 7)) << 4));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(bW + j * 16 * 128 + wc);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        }
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
         if (++stage == S) stage = 0;
         if (++tap == 9) { tap = 0; ++c; hbuf ^= 1; }
     }

@@ -16,8 +16,11 @@ struct GNArgs {
     float eps;
 };
 
-template <int VPT>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs p) {
+// NT threads per workgroup: 256, or 1024 for the mid-sized tensors (the UNet's 64x64 level) where a
+// workgroup's whole 64-pixel chunk is then in flight at once — those launches are bounded by memory
+// latency x bytes in flight, not by bandwidth.
+template <int VPT, int NT>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const GNArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* part = reinterpret_cast<float*>(smem_raw);  // [pl][C][2]
     float* chan = part + (size_t)p.pl * p.C * 2;        // [C][2]
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs p) {
         }
     }
     __syncthreads();
-    for (int c = t; c < p.C; c += 256) {
+    for (int c = t; c < p.C; c += NT) {
         float a = 0.f, q = 0.f;
         for (int l = 0; l < p.pl; ++l) {
             a += part[((size_t)l * p.C + c) * 2 + 0];
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const GNArgs p, int n
 
 // FUSED: few chunks (<= 64) -> every workgroup reduces the partial moments itself, in the same fixed
 // order, and the separate finalize launch disappears (small tensors are launch-bound, not byte-bound)
-template <int VPT, bool FUSED>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p, int nchunks) {
+template <int VPT, bool FUSED, int NT>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const GNArgs p, int nchunks) {
     __shared__ float s_mean[32], s_rstd[32];
-    __shared__ float red[4][64];
+    __shared__ float red[NT / 64][64];
     constexpr int U = 4;  // pixels in flight per thread
     const int t = threadIdx.x, b = blockIdx.y;
     const int cvi = t % p.tpp, pli = t / p.tpp;
@@ -175,11 +178,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p, int nchun
         const int col = t & 63, rg = t >> 6;
         const float* src = p.partials + (size_t)b * nchunks * 64 + col;
         float part = 0.f;
-        for (int c = rg; c < nchunks; c += 4) part += src[(size_t)c * 64];
+        for (int c = rg; c < nchunks; c += NT / 64) part += src[(size_t)c * 64];
         red[rg][col] = part;
         __syncthreads();
         if (t < 64) {
-            const float acc = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+            float acc = red[0][t];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) acc += red[w][t];   // fixed order: bit-reproducible
             const float other = __shfl_xor(acc, 1);
             const float sum = (t & 1) ? other : acc, sq = (t & 1) ? acc : other;
             const float cnt = (float)p.hw * (float)(p.C / 32);
@@ -340,7 +345,9 @@ static void gn_group_launch(const GNArgs& a, int upp, int npt, dim3 grid, hipStr
 }
 
 static int g_gn_impl = 1;  // 1 = single-launch per-group kernel where the group slab fits, 0 = always stats/finalize/apply
+static int g_gn_wide = 1;  // 1 = 1024-thread stats / apply workgroups for mid-sized tensors, 0 = always 256 (A/B runs)
 void msd_set_gn_impl(int v) { g_gn_impl = v; }
+void msd_set_gn_wide(int v) { g_gn_wide = v; }
 
 extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -357,8 +364,11 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     a.x0 = (const bf16_t*)q->x0; a.x1 = (const bf16_t*)q->x1; a.gamma = q->gamma; a.beta = q->beta;
     a.stats = q->stats; a.partials = q->partials; a.out = (bf16_t*)q->out;
     a.batch = q->batch; a.hw = q->hw; a.c0 = q->c0; a.c1 = q->c1; a.C = C; a.cv = C / 8;
+    // mid-sized tensors (the UNet's 64x64 level at batch 1-8): 1024-thread workgroups, see gn_stats_kernel
+    const bool wide = g_gn_wide && (long long)q->hw * C >= (1ll << 20) && (long long)q->hw * C <= (4ll << 20) && C <= 2048;
+    const int NT = wide ? 1024 : 256;
     a.tpp = a.cv < 256 ? a.cv : 256;
-    a.pl = 256 / a.tpp;
+    a.pl = NT / a.tpp;
     a.silu = q->silu ? 1 : 0; a.eps = q->eps;
     {
         // single-launch path: V = words per thread-unit (widest that divides the group's run), at most
@@ -390,7 +400,7 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     long long target_blocks = small ? 64 : 1024 / q->batch;
     if (target_blocks < 1) target_blocks = 1;
     int ppb = (int)((q->hw + target_blocks - 1) / target_blocks);
-    const int min_ppb = a.pl * 4;
+    const int min_ppb = wide ? a.pl : a.pl * 4;
     if (ppb < min_ppb) ppb = min_ppb;
     if (ppb > q->hw) ppb = q->hw;
     a.ppb = ppb;
@@ -401,19 +411,39 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
                  (long long)q->partials_floats, (long long)q->batch * nchunks * 64);
     dim3 grid(nchunks, q->batch);
     const size_t lds = ((size_t)a.pl * C * 2 + (size_t)C * 2) * sizeof(float);
-    if (vpt == 1) hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), lds, stream, a);
+    if (wide) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_stats_kernel<1, 1024>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(gn_stats): %s", hipGetErrorString(e));
+            attr_done = true;
+        }
+        if (vpt != 1 || lds > 160 * 1024) MSD_FAIL(MSD_E_UNSUPPORTED, "group_norm: wide path needs C <= 2048");
+        hipLaunchKernelGGL((gn_stats_kernel<1, 1024>), grid, dim3(1024), lds, stream, a);
+        MSD_CHECK_LAUNCH();
+        if (fused) hipLaunchKernelGGL((gn_apply_kernel<1, true, 1024>), grid, dim3(1024), 0, stream, a, nchunks);
+        else {
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(1024), 0, stream, a, nchunks);
+            MSD_CHECK_LAUNCH();
+            hipLaunchKernelGGL((gn_apply_kernel<1, false, 1024>), grid, dim3(1024), 0, stream, a, nchunks);
+        }
+        MSD_CHECK_LAUNCH();
+        return MSD_OK;
+    }
+    if (vpt == 1) hipLaunchKernelGGL((gn_stats_kernel<1, 256>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((gn_stats_kernel<2, 256>), grid, dim3(256), lds, stream, a);
     MSD_CHECK_LAUNCH();
     if (!fused) {
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(1024), 0, stream, a, nchunks);
         MSD_CHECK_LAUNCH();
     }
     if (vpt == 1) {
-        if (fused) hipLaunchKernelGGL((gn_apply_kernel<1, true>), grid, dim3(256), 0, stream, a, nchunks);
-        else hipLaunchKernelGGL((gn_apply_kernel<1, false>), grid, dim3(256), 0, stream, a, nchunks);
+        if (fused) hipLaunchKernelGGL((gn_apply_kernel<1, true, 256>), grid, dim3(256), 0, stream, a, nchunks);
+        else hipLaunchKernelGGL((gn_apply_kernel<1, false, 256>), grid, dim3(256), 0, stream, a, nchunks);
     } else {
-        if (fused) hipLaunchKernelGGL((gn_apply_kernel<2, true>), grid, dim3(256), 0, stream, a, nchunks);
-        else hipLaunchKernelGGL((gn_apply_kernel<2, false>), grid, dim3(256), 0, stream, a, nchunks);
+        if (fused) hipLaunchKernelGGL((gn_apply_kernel<2, true, 256>), grid, dim3(256), 0, stream, a, nchunks);
+        else hipLaunchKernelGGL((gn_apply_kernel<2, false, 256>), grid, dim3(256), 0, stream, a, nchunks);
     }
     MSD_CHECK_LAUNCH();
     return MSD_OK;

@@ -20,7 +20,8 @@ _table: Optional[Dict[str, list]] = None
 # 3x3 kernel with 8x16 / 16x16 pixel tiles.
 TILES = ((128, 128, 0), (128, 64, 0), (64, 64, 0), (64, 128, 0), (256, 128, 0),
          (128, 128, 4), (64, 64, 8), (64, 128, 5), (128, 64, 5), (128, 80, 0), (128, 80, 4),
-         (64, 64, 14), (128, 64, 13), (64, 128, 13))   # stages 10 + depth: the tile on 8 waves
+         (64, 64, 14), (128, 64, 13), (64, 128, 13),   # stages 10 + depth: the tile on 8 waves
+         (128, 128, 23), (128, 128, 24), (128, 64, 24), (64, 128, 24))   # 20 + depth: 64x64 per wave (4 / 2 waves)
 HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (1256, 80, 0),
               (1128, 64, 8), (1128, 128, 6), (1128, 80, 8), (1256, 80, 5), (2128, 64, 0), (2128, 80, 0))
 

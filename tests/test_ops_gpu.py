@@ -73,6 +73,11 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=1, H=8, W=8, c0=256, N=320, ks=3, tile_m=64, tile_n=128, stages=13, stride=2),
     dict(B=2, H=12, W=20, c0=128, N=320, ks=1, tile_m=128, tile_n=80),               # generic 128x80, ragged M
     dict(B=2, H=12, W=20, c0=192, N=168, ks=3, tile_m=128, tile_n=80, stages=4, splitk=3),
+    dict(B=2, H=12, W=20, c0=128, N=320, ks=1, tile_m=128, tile_n=128, stages=23),    # 64x64 per wave (4 waves), DENSE loader, ragged M / N
+    dict(B=2, H=12, W=20, c0=64, c1=128, N=192, ks=1, tile_m=128, tile_n=128, stages=24, splitk=2),   # + concat + split-K
+    dict(B=3, H=12, W=20, c0=128, N=200, ks=3, tile_m=128, tile_n=64, stages=24),     # 2 waves of 64x64, general loader
+    dict(B=2, H=12, W=20, c0=192, N=320, ks=1, tile_m=64, tile_n=128, stages=24),
+    dict(B=1, H=12, W=20, c0=64, N=100, ks=1, tile_m=64, tile_n=64),                  # DENSE loader: M and N tails inside one tile
     dict(B=2, H=16, W=16, c0=128, N=128, ks=3, stride=2, asym=True),                 # VAE encoder downsampler: pad bottom/right only
     dict(B=1, H=10, W=18, c0=64, N=192, ks=3, stride=2, asym=True, splitk=3, tile_m=64, tile_n=64),
 ])
@@ -234,6 +239,8 @@ def test_conv_direct(gpu, case):
     dict(B=1, hw=1024, c0=1280, c1=640, silu=False),   # C=1920: 8-byte units, 16 per thread
     dict(B=2, hw=1000, c0=1280, silu=True),            # 16-byte units, ragged last pass
     dict(B=1, hw=4096, c0=640, c1=320, silu=True),     # slab too big for registers -> three-launch path
+    dict(B=2, hw=4096, c0=320, silu=True),             # the UNet's 64x64 level: 1024-thread stats / apply workgroups
+    dict(B=1, hw=4100, c0=320, c1=320, silu=False),    # same path, concat, ragged last chunk
     dict(B=2, hw=256, c0=1280, c1=640, silu=True, impl=0),   # three-launch path forced on a small tensor
     dict(B=2, hw=64, c0=320, silu=True, impl=0),
 ])
