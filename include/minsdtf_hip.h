@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 3
+#define MSD_ABI_VERSION 4
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -59,7 +59,17 @@ int msd_set_option(const char* key, int value);
  *   W is pre-packed [N][K] bf16 (k contiguous) — see minsdtf_amd/packing.py.
  * Requirements: c0 % 64 == 0, c1 % 64 == 0, N % 4 == 0, all pointers 16-byte aligned,
  *               leading dimensions multiples of 4 elements.
- * Epilogue order: + bias[n] -> + rowvec[step, b, n] -> act -> + residual[m, n] -> store.
+ * Epilogue order: [LayerNorm fold] -> + bias[n] -> + rowvec[step, b, n] -> act -> + residual[m, n] -> store.
+ *
+ * LayerNorm fold (diffusion_model.py:84-88 followed by a Dense, :102-108 / :146): LN(x) W^T =
+ * rstd[m] * (x (gamma*W)^T - mean[m] * colsum[n]) + (beta W^T)[n], so the LayerNormalization in front of
+ * a Dense is this GEMM on the RAW rows with gamma folded into W (packing.py), corrected per row in the
+ * epilogue; the row moments come from the GEMM that PRODUCED x: with `ln_out` set, a launch writes, per
+ * output row and per column tile, the partial (sum, sum of squares) of the bf16 values it stored
+ * (float2 [M][ln_out_slots], ln_out_slots = ceil(N / tile_n)); a launch with `ln_in` set sums the
+ * `ln_in_slots` partials of each of its rows in a fixed order (bit-reproducible) and applies
+ * acc <- rstd * (acc - mean * ln_colsum[n]) before the rest of the epilogue (bias then carries beta W^T + b).
+ * Both are plain-K only (no split-K); `ln_out` needs plain mode with a bf16 output.
  */
 #define MSD_ACT_NONE 0
 #define MSD_ACT_SILU 1
@@ -103,8 +113,19 @@ typedef struct MsdConvGemm {
                             they make the workgroup count a multiple of the 256 CUs */
     int32_t stages;      /* 0 = default LDS ring depth of the tile; deeper rings built: 128x128:4 64x64:8 64x128:5 128x64:5
                             128x80:4; halo tiles 1128x64:8 1128x128:6 1128x80:8 1256x80:5 (an unknown depth = the default);
-                            10 + depth = the tile on 8 waves (two per SIMD): 64x64:14 128x64:13 64x128:13 */
+                            10 + depth = the tile on 8 waves (two per SIMD): 64x64:14 128x64:13 64x128:13;
+                            20 + depth = 64x64 per wave: 128x128:23/24 128x64:24 64x128:24 */
+    const float* ln_in;      /* float2 [M][ln_in_slots] row-moment partials of the input rows, or NULL */
+    const float* ln_colsum;  /* [N]: sum_k W[n][k] of the gamma-folded bf16 weights (with ln_in) */
+    float* ln_out;           /* float2 [M][ln_out_slots] row-moment partials of the stored output, or NULL */
+    int32_t ln_in_slots;     /* 1..20 */
+    int32_t ln_out_slots;    /* must equal ceil(N / tile_n) of this launch (msd_conv_gemm_ln_slots) */
+    float ln_eps;
 } MsdConvGemm;
+
+/* Number of row-moment partials per row a launch with these parameters writes to `ln_out`
+ * (= its number of column tiles), or a negative MSD_E_* code. */
+int msd_conv_gemm_ln_slots(const MsdConvGemm* p);
 
 int msd_conv_gemm(const MsdConvGemm* p, msd_stream_t stream);
 

@@ -11,7 +11,7 @@ import os
 
 LIB_NAME = "libminsdtf_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -32,6 +32,8 @@ class MsdConvGemm(C.Structure):
         ("out_ld", C.c_int32), ("res_ld", C.c_int32), ("rv_step_stride", C.c_int32), ("rv_batch_stride", C.c_int32),
         ("split_mode", C.c_int32), ("ns0", C.c_int32), ("ns1", C.c_int32), ("out1_ld", C.c_int32),
         ("out2_ld", C.c_int32), ("splitk", C.c_int32), ("tile_n", C.c_int32), ("tile_m", C.c_int32), ("stages", C.c_int32),
+        ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_out", C.c_void_p),
+        ("ln_in_slots", C.c_int32), ("ln_out_slots", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -80,6 +82,7 @@ SYMBOLS = {
     "msd_init": (C.c_int, []),
     "msd_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "msd_conv_gemm": (C.c_int, [C.POINTER(MsdConvGemm), C.c_void_p]),
+    "msd_conv_gemm_ln_slots": (C.c_int, [C.POINTER(MsdConvGemm)]),
     "msd_conv_direct": (C.c_int, [C.POINTER(MsdConvDirect), C.c_void_p]),
     "msd_group_norm": (C.c_int, [C.POINTER(MsdGroupNorm), C.c_void_p]),
     "msd_layer_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,

@@ -12,6 +12,9 @@ struct CGArgs {
     int tiles_m, m_fast;   // m_fast: consecutive tiles (= same XCD) share the WEIGHT rows instead of the pixel rows
     int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
     int split_mode, ns0, ns1, out1_ld, out2_ld;
+    const float* ln_in; const float* ln_colsum; float* ln_out;   // LayerNorm fold (minsdtf_hip.h)
+    int ln_in_slots, ln_out_slots;
+    float ln_eps, ln_inv_k;
 };
 
 static __device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows (one copy per TU)
@@ -84,8 +87,13 @@ __device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, 
 // n..n+3 (n = nbase + 16j + 4g) of pixel m (= mbase + 16i + r).
 // Rows: fragment i of the wave covers pixels mrow[i] + r (r = 0..15), so a spatially blocked tile
 // (conv_halo) and a linear one (conv_gemm: mrow[i] = mbase + 16 i) share the epilogue.
+constexpr int LN_MAX_SLOTS = 20;   // row-moment partials per row (column tiles of the producing launch)
+// `lnred` (with ln_out): LDS scratch of WGN x BM float2, free for reuse (the caller has passed a barrier after
+// its last fragment read); `wn` / `wgn`: this wave's column slab and the number of slabs; `row0`: first row
+// of the wave's tile inside the workgroup tile; `tile_n`: column tile index = the partial's slot.
 template <int MI, int NJ>
-__device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI], const int (&mrow)[MI], int nbase, int r, int g) {
+__device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI], const int (&mrow)[MI], int nbase, int r, int g,
+                                            float* lnred = nullptr, int wn = 0, int wgn = 1, int row0 = 0, int bm = 0, int tile_n = 0) {
     if (gridDim.y > 1) {
         float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
@@ -119,6 +127,41 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // LayerNorm fold, consumer side: partial row moments (lane group g takes slots g, g+4, ...) and column sums
+    constexpr int LNS = LN_MAX_SLOTS / 4;
+    float2 lnp[MI][LNS];
+    float4 lcs[NJ];
+    if (p.ln_in) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float2* src = reinterpret_cast<const float2*>(p.ln_in) + (size_t)min(mrow[i] + r, p.M - 1) * p.ln_in_slots;
+#pragma unroll
+            for (int k = 0; k < LNS; ++k) lnp[i][k] = src[min(g + 4 * k, p.ln_in_slots - 1)];   // (clamped: masked below)
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) lcs[j] = *reinterpret_cast<const float4*>(p.ln_colsum + min(nbase + j * 16 + 4 * g, p.N - 4));
+    }
+    auto ln_apply = [&]() {   // after the vmcnt(0): acc <- rstd * (acc - mean * colsum)
+        if (!p.ln_in) return;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNS; ++k)
+                if (g + 4 * k < p.ln_in_slots) { s1 += lnp[i][k].x; s2 += lnp[i][k].y; }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);   // fixed order: (g0+g1) + (g2+g3) on every lane
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            const float mean = s1 * p.ln_inv_k;
+            const float rstd = rsqrtf(fmaxf(s2 * p.ln_inv_k - mean * mean, 0.f) + p.ln_eps);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[j][i][0] = rstd * (acc[j][i][0] - mean * lcs[j].x);
+                acc[j][i][1] = rstd * (acc[j][i][1] - mean * lcs[j].y);
+                acc[j][i][2] = rstd * (acc[j][i][2] - mean * lcs[j].z);
+                acc[j][i][3] = rstd * (acc[j][i][3] - mean * lcs[j].w);
+            }
+        }
+    };
     if (p.act == MSD_ACT_GEGLU) {
         if constexpr (NJ % 2 == 0) {   // (x|gate pairs: the host never sends GEGLU to an odd-NJ tile)
             uint2 rr[MI][NJ / 2];
@@ -137,6 +180,7 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
                     for (int j = 0; j < NJ; j += 2) rr[i][j / 2] = make_uint2(0, 0);
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every epilogue load has landed
+            ln_apply();
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = mrow[i] + r;
@@ -194,6 +238,10 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
             for (int j = 0; j < NJ; ++j) rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every epilogue load has landed
+    ln_apply();
+    float ls1[MI], ls2[MI];   // ln_out: this wave's partial row moments of the values it stores
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { ls1[i] = 0.f; ls2[i] = 0.f; }
     MSD_STAMP_DRAIN();
     MSD_STAMP(6);
 #pragma unroll
@@ -222,6 +270,11 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
                 } else {
                     uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+                    if (p.ln_out) {   // moments of the ROUNDED values: what a LayerNorm reading `out` would see
+                        const float q0 = bf_lo(o.x), q1 = bf_hi(o.x), q2 = bf_lo(o.y), q3 = bf_hi(o.y);
+                        ls1[i] += (q0 + q1) + (q2 + q3);
+                        ls2[i] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                    }
                 }
             } else {
                 uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
@@ -243,6 +296,35 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
         }
     }
     MSD_STAMP(7);
+    if (p.ln_out) {
+        __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the ring can be reused
+        // lanes of one row (g = 0..3) -> wave partial; the WGN column slabs of the workgroup are summed in
+        // slab order by the wn == 0 wave through LDS -> one (sum, sumsq) per row and column tile
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            ls1[i] += __shfl_xor(ls1[i], 16); ls2[i] += __shfl_xor(ls2[i], 16);
+            ls1[i] += __shfl_xor(ls1[i], 32); ls2[i] += __shfl_xor(ls2[i], 32);
+            if (g == 0) {
+                lnred[((size_t)wn * bm + row0 + i * 16 + r) * 2 + 0] = ls1[i];
+                lnred[((size_t)wn * bm + row0 + i * 16 + r) * 2 + 1] = ls2[i];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the partials are in LDS (raw barrier: the stores stay in flight)
+        __builtin_amdgcn_s_barrier();
+        if (wn == 0 && g == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = mrow[i] + r;
+                if (m >= p.M) continue;
+                float a = 0.f, q = 0.f;
+                for (int w = 0; w < wgn; ++w) {
+                    a += lnred[((size_t)w * bm + row0 + i * 16 + r) * 2 + 0];
+                    q += lnred[((size_t)w * bm + row0 + i * 16 + r) * 2 + 1];
+                }
+                reinterpret_cast<float2*>(p.ln_out)[(size_t)m * p.ln_out_slots + tile_n] = make_float2(a, q);
+            }
+        }
+    }
 }
 
 // ---- LDS-DMA helpers (compiler-invisible on purpose: see cdna_hip_programming.md §5.7) ---------

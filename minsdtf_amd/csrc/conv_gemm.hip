@@ -221,7 +221,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * WMT + i * 16;
-    cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WNT, r, g);
+    cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WNT, r, g, reinterpret_cast<float*>(smem), wn, WGN, wm * WMT, BM, tile_n);
 #ifdef MSD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
     MSD_STAMP(4);
@@ -438,6 +438,21 @@ int msd_conv_gemm_init() {
     return MSD_OK;
 }
 
+// tile width the launch will use (same rules as msd_conv_gemm below)
+static int cg_effective_bn(const MsdConvGemm* q) {
+    int bn = q->tile_n;
+    if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
+    if (bn == 80 && (q->act == MSD_ACT_GEGLU || g_conv_impl != 1)) bn = 64;
+    return bn;
+}
+
+extern "C" int msd_conv_gemm_ln_slots(const MsdConvGemm* q) {
+    if (!q || q->N <= 0) MSD_FAIL(MSD_E_ARG, "conv_gemm_ln_slots: bad arguments");
+    if (q->tile_m >= 1000 && q->ksize == 3) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm_ln_slots: 1x1 / dense launches only");
+    const int bn = cg_effective_bn(q);
+    return (q->N + bn - 1) / bn;
+}
+
 extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!q) MSD_FAIL(MSD_E_ARG, "conv_gemm: null params");
@@ -508,7 +523,25 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.rv_step_stride = q->rv_step_stride; a.rv_batch_stride = q->rv_batch_stride;
     a.split_mode = q->split_mode; a.ns0 = q->ns0; a.ns1 = q->ns1; a.out1_ld = q->out1_ld; a.out2_ld = q->out2_ld;
 
+    a.ln_in = q->ln_in; a.ln_colsum = q->ln_colsum; a.ln_out = q->ln_out;
+    a.ln_in_slots = q->ln_in_slots; a.ln_out_slots = q->ln_out_slots; a.ln_eps = q->ln_eps;
+    a.ln_inv_k = 1.0f / (float)a.K;
+    if (q->ln_in) {
+        if (!q->ln_colsum || q->ln_in_slots < 1 || q->ln_in_slots > LN_MAX_SLOTS || q->ksize != 1 || !(q->ln_eps > 0.f))
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: LayerNorm fold needs ln_colsum, 1 <= ln_in_slots <= %d, ksize 1, ln_eps > 0", LN_MAX_SLOTS);
+        if (!msd_aligned16(q->ln_colsum) || (((uintptr_t)q->ln_in) & 7u)) MSD_FAIL(MSD_E_ALIGN, "conv_gemm: ln_in / ln_colsum alignment");
+    }
+    if (q->ln_out) {
+        if (q->split_mode || q->out_dtype != MSD_OUT_BF16 || q->act == MSD_ACT_GEGLU || q->ksize != 1 || q->tile_m >= 1000 ||
+            (((uintptr_t)q->ln_out) & 7u) || g_conv_impl != 1)
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out needs a plain 1x1 launch with a bf16 output");
+        if (q->ln_out_slots != msd_conv_gemm_ln_slots(q))
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out_slots=%d, this launch writes %d partials per row", q->ln_out_slots,
+                     msd_conv_gemm_ln_slots(q));
+    }
+
     int splitk = q->splitk < 1 ? 1 : q->splitk;
+    if ((q->ln_in || q->ln_out) && splitk > 1) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold is plain-K only (splitk=%d)", splitk);
     // halo variant (tile_m = 1000 + pixels per tile: 1128 = 8x16, 1256 = 16x16): spatially blocked 3x3
     int halo_th = 0;
     if (q->tile_m >= 1000) {
@@ -533,9 +566,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
                      (long long)q->workspace_floats, (long long)slices * a.M * a.N);
     }
     // tile configuration: explicit (tile_m, tile_n) or the size heuristic
-    int bm = q->tile_m, bn = q->tile_n;
-    if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
-    if (bn == 80 && (q->act == MSD_ACT_GEGLU || g_conv_impl != 1)) bn = 64;   // (80 = 5 fragments: no x|gate pairing)
+    int bm = q->tile_m, bn = cg_effective_bn(q);   // (80 = 5 fragments: no x|gate pairing -> 64 for GEGLU)
     if (bm == 0 || bm >= 1000) bm = 128;   // a halo request that is not eligible falls back to 128-row tiles
     if (halo_th) {
         if (halo_th == 16 && bn != 80) bn = 128;

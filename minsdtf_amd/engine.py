@@ -116,6 +116,7 @@ class Act:
     H: int
     W: int
     C: int
+    ln: Optional[tuple] = None   # (buffer, slots): row-moment partials written by the producing GEMM (LayerNorm fold)
 
     @property
     def M(self) -> int:
@@ -219,6 +220,12 @@ def pick_splitk(M: int, N: int, nk: int) -> int:
     return max(1, s)
 
 
+# LayerNorm fold (include/minsdtf_hip.h): the three LayerNormalizations of a transformer block run inside the
+# epilogues of the GEMMs around them instead of as 48 launches per UNet forward.  False = separate
+# msd_layer_norm launches (A/B runs, and any weight dict without the folded tensors).
+LN_FOLD = True
+
+
 # ----------------------------------------------------------------------------- layer emitters
 class Emitter:
     """Emits the calls of the reference's layer types into a Plan. `W` maps logical weight names to
@@ -230,7 +237,9 @@ class Emitter:
     # conv / dense on the MFMA path; x may be a single Act or a (Act, Act) channel concat
     def conv(self, x, name, N, ksize=1, stride=1, upsample=False, act=ops.ACT_NONE, residual: Optional[Act] = None,
              rowvec=None, out_dtype=ops.OUT_BF16, bias=True, wkey=None, split=None, out: Optional[Act] = None,
-             asym_pad: bool = False) -> Act:
+             asym_pad: bool = False, ln_out: bool = False, ln_in: Optional[tuple] = None) -> Act:
+        """ln_out: also write the row-moment partials of the output (returned Act carries them in .ln);
+        ln_in = (buffer, slots): the input rows are LayerNormalized through the fold (weights <name>.lnw/.lncs/.lnb)."""
         p = self.p
         x0, x1 = (x if isinstance(x, tuple) else (x, None))
         cin = x0.C + (x1.C if x1 is not None else 0)
@@ -243,6 +252,8 @@ class Emitter:
         nk = ksize * ksize * (cin // 64)
         can_split = not (split is not None or act == ops.ACT_GEGLU)
         tile_m, tile_n, sk, stages = tuning.lookup(x0.B, x0.H, x0.W, cin, N, ksize, stride, upsample, M, nk, can_split)
+        if ln_out or ln_in is not None:
+            sk = 1   # the fold is plain-K only
         if sk > 1:
             p.ws_floats = max(p.ws_floats, sk * M * N)
         if out is None and split is None:
@@ -256,6 +267,14 @@ class Emitter:
                   workspace=p.ws if sk > 1 else None, workspace_floats=sk * M * N if sk > 1 else 0, splitk=sk,
                   tile_m=tile_m, tile_n=tile_n, stages=stages, pad=pad_lead, pad_end=pad_end,
                   step_ptr=self.step_ptr if rowvec is not None else None, name=name)
+        if ln_in is not None:
+            wn = wkey or name
+            kw.update(w=self.W[wn + ".lnw"], bias=self.W[wn + ".lnb"], ln_in=ln_in[0], ln_in_slots=ln_in[1],
+                      ln_colsum=self.W[wn + ".lncs"], ln_eps=EPS)
+        if ln_out:
+            slots = ops.conv_gemm_ln_slots(N=N, tile_n=tile_n, tile_m=tile_m, ksize=ksize, act=act)
+            out.ln = (p.alloc(M * slots * 8), slots)
+            kw.update(ln_out=out.ln[0], ln_out_slots=slots)
         if rowvec is not None:
             kw.update(rowvec=rowvec[0], rv_step_stride=rowvec[1], rv_batch_stride=rowvec[2])
         if split is not None:
@@ -312,37 +331,50 @@ class Emitter:
         S = H * Wd
         d = C // heads
         tb = name + ".transformer_blocks.0"
+        fold = LN_FOLD and (tb + ".attn1.qkv.lnw") in self.W
         g = self.group_norm(x, name + ".norm", silu=False)
-        t0 = self.conv(g, name + ".proj_in", C)
+        t0 = self.conv(g, name + ".proj_in", C, ln_out=fold)
         p.free(g)
         # self-attention: fused q|k|v projection, v written transposed for the PV product
-        n1 = self.layer_norm(t0, tb + ".norm1")
         q, k = p.act(B, H, Wd, C), p.act(B, H, Wd, C)
         sp = (S + 7) // 8 * 8  # V^T rows are read in 16-byte chunks
         vt = p.alloc(B * C * sp * 2)
-        self.conv(n1, tb + ".attn1.qkv", 3 * C, bias=False, split=(C, C, q.buf, k.buf, vt, sp))
-        p.free(n1)
+        if fold:   # LayerNorm(norm1) inside the q|k|v GEMM
+            self.conv(t0, tb + ".attn1.qkv", 3 * C, bias=False, split=(C, C, q.buf, k.buf, vt, sp), ln_in=t0.ln)
+            p.free(t0.ln[0])
+        else:
+            n1 = self.layer_norm(t0, tb + ".norm1")
+            self.conv(n1, tb + ".attn1.qkv", 3 * C, bias=False, split=(C, C, q.buf, k.buf, vt, sp))
+            p.free(n1)
         a1 = p.act(B, H, Wd, C)
         p.rec(ops.attention, q=q.buf, k=k.buf, vt=vt, out=a1.buf, batch=B, heads=heads, head_dim=d, s=S, t=S, q_ld=C,
               k_ld=C, vt_ld=sp, o_ld=C, scale=d ** -0.5, name=tb + ".attn1")
         p.free(q, k, vt)
-        t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0)
+        t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0, ln_out=fold)
         p.free(a1, t0)
         # cross-attention over the text context (k, v^T precomputed once per prompt)
-        n2 = self.layer_norm(t1, tb + ".norm2")
-        q2 = self.conv(n2, tb + ".attn2.to_q", C, bias=False)
-        p.free(n2)
+        if fold:
+            q2 = self.conv(t1, tb + ".attn2.to_q", C, bias=False, ln_in=t1.ln)
+            p.free(t1.ln[0])
+        else:
+            n2 = self.layer_norm(t1, tb + ".norm2")
+            q2 = self.conv(n2, tb + ".attn2.to_q", C, bias=False)
+            p.free(n2)
         kc, vtc, tp = ctx_kv[tb + ".attn2"]
         a2 = p.act(B, H, Wd, C)
         p.rec(ops.attention, q=q2.buf, k=kc, vt=vtc, out=a2.buf, batch=B, heads=heads, head_dim=d, s=S, t=ctx_len, q_ld=C,
               k_ld=C, vt_ld=tp, o_ld=C, scale=d ** -0.5, name=tb + ".attn2")
         p.free(q2)
-        t2 = self.conv(a2, tb + ".attn2.to_out.0", C, residual=t1)
+        t2 = self.conv(a2, tb + ".attn2.to_out.0", C, residual=t1, ln_out=fold)
         p.free(a2, t1)
         # feed-forward: GEGLU fused into the first GEMM's epilogue
-        n3 = self.layer_norm(t2, tb + ".norm3")
-        ff = self.conv(n3, tb + ".ff.net.0.proj", 8 * C, act=ops.ACT_GEGLU)
-        p.free(n3)
+        if fold:
+            ff = self.conv(t2, tb + ".ff.net.0.proj", 8 * C, act=ops.ACT_GEGLU, bias=False, ln_in=t2.ln)
+            p.free(t2.ln[0])
+        else:
+            n3 = self.layer_norm(t2, tb + ".norm3")
+            ff = self.conv(n3, tb + ".ff.net.0.proj", 8 * C, act=ops.ACT_GEGLU)
+            p.free(n3)
         t3 = self.conv(ff, tb + ".ff.net.2", C, residual=t2)
         p.free(ff, t2)
         out = self.conv(t3, name + ".proj_out", C, residual=x)

@@ -156,6 +156,22 @@ class HipModel:
                 base = n[: -len("." + trio[0])]
                 W[base + ".qkv.w"] = packing.pack_dense_stack([get(base + "." + k, "dense_w") for k in trio], d)
                 W[base + ".qkv.b"] = packing.dev_f32(np.concatenate([get(base + "." + k, "bias") for k in trio]), d)
+        # LayerNorm folds of the transformer blocks (engine.Emitter.attentions): norm1 -> q|k|v, norm2 -> attn2.to_q,
+        # norm3 -> GEGLU projection.  Keys: <consumer>.lnw (bf16 gamma-folded), .lncs (column sums), .lnb (W beta + b)
+        for n in names:
+            if not n.endswith(".transformer_blocks.0.norm1"):
+                continue
+            tb = n[: -len(".norm1")]
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).t().contiguous()  # noqa: E731  (in,out) -> [out][in]
+            qkv = torch.cat([t(get(tb + ".attn1." + k, "dense_w")) for k in ("to_q", "to_k", "to_v")], dim=0)
+            W[tb + ".attn1.qkv.lnw"], W[tb + ".attn1.qkv.lncs"], W[tb + ".attn1.qkv.lnb"] = packing.fold_layer_norm(
+                qkv, None, get(tb + ".norm1", "gamma"), get(tb + ".norm1", "beta"), d)
+            W[tb + ".attn2.to_q.lnw"], W[tb + ".attn2.to_q.lncs"], W[tb + ".attn2.to_q.lnb"] = packing.fold_layer_norm(
+                t(get(tb + ".attn2.to_q", "dense_w")), None, get(tb + ".norm2", "gamma"), get(tb + ".norm2", "beta"), d)
+            gw, gb = get(tb + ".ff.net.0.proj", "dense_w"), get(tb + ".ff.net.0.proj", "bias")
+            order = packing.geglu_row_order(gw.shape[1] // 2)
+            W[tb + ".ff.net.0.proj.lnw"], W[tb + ".ff.net.0.proj.lncs"], W[tb + ".ff.net.0.proj.lnb"] = packing.fold_layer_norm(
+                t(gw)[torch.from_numpy(order)], np.asarray(gb)[order], get(tb + ".norm3", "gamma"), get(tb + ".norm3", "beta"), d)
         if tproj_w:
             W["time_emb_proj_cat.w"] = packing.dev_f32(np.concatenate(tproj_w, axis=1).reshape(1, 1, 1280, -1), d)
             W["time_emb_proj_cat.b"] = packing.dev_f32(np.concatenate(tproj_b), d)

@@ -55,5 +55,21 @@ def pack_geglu(w_io: np.ndarray, b: np.ndarray, device):
     return _dev_bf16(wt, device), dev_f32(np.asarray(b)[order], device)
 
 
+def fold_layer_norm(w_oi: torch.Tensor, bias, gamma: np.ndarray, beta: np.ndarray, device):
+    """LayerNormalization (diffusion_model.py:84-88) folded into the Dense that follows it.
+
+    ``w_oi``: fp32 [out][in] (already in the row order the kernel wants); ``bias``: fp32 [out] in the same
+    order or None.  LN(x) W^T + b = rstd * (x (gamma*W)^T - mean * colsum) + (W beta + b), so this returns
+    (bf16 gamma-folded weights on device, fp32 colsum of the ROUNDED folded weights, fp32 W beta + b)."""
+    g = torch.from_numpy(np.ascontiguousarray(gamma, dtype=np.float32))
+    bt = torch.from_numpy(np.ascontiguousarray(beta, dtype=np.float32))
+    wf = (w_oi * g[None, :]).to(torch.bfloat16)
+    colsum = wf.to(torch.float64).sum(dim=1).to(torch.float32)
+    c = (w_oi.to(torch.float64) @ bt.to(torch.float64)).to(torch.float32)
+    if bias is not None:
+        c = c + torch.from_numpy(np.ascontiguousarray(bias, dtype=np.float32))
+    return wf.contiguous().to(device), colsum.contiguous().to(device), c.contiguous().to(device)
+
+
 def dev_f32(a: np.ndarray, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)

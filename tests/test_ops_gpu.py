@@ -24,6 +24,7 @@ def close(got, ref, rtol=1e-2, atol=None, what=""):
     ref = ref.detach().float().cpu()
     if atol is None:
         atol = 1e-2 * float(ref.abs().max()) + 1e-6
+    assert bool(torch.isfinite(got).all()), f"{what}: {int((~torch.isfinite(got)).sum())}/{got.numel()} non-finite outputs"
     err = (got - ref).abs()
     bad = err > (atol + rtol * ref.abs())
     assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {float(err.max()):.4g}, ref max {float(ref.abs().max()):.4g}"
@@ -145,6 +146,84 @@ def test_conv_gemm_geglu(gpu):
                          act=ops.ACT_GEGLU)
     run_calls(call)
     close(out, ref, what="geglu")
+
+
+@pytest.mark.parametrize("case", [
+    dict(M=200, C=320, tile=(128, 128, 0), mode="dense"),      # 3 column tiles x 4 wave slabs, ragged M
+    dict(M=192, C=320, tile=(128, 80, 0), mode="qkv"),         # 80-wide producer tiles, q|k|v^T epilogue
+    dict(M=128, C=640, tile=(64, 64, 0), mode="geglu"),        # 10 partials per row, GEGLU consumer
+    dict(M=130, C=1280, tile=(64, 64, 14), mode="dense"),      # 20 partials per row (the maximum), 8-wave producer
+    dict(M=256, C=320, tile=(64, 128, 24), mode="dense"),      # one slab per tile
+])
+def test_conv_gemm_layer_norm_fold(gpu, case):
+    """LayerNormalization folded into the GEMMs around it (diffusion_model.py:84-88 + Dense): the producer
+    (Dense + residual) writes row-moment partials, the consumer normalises through its epilogue.  Reference:
+    fp32 LayerNorm of the producer's bf16 output, then the Dense.  rtol 1e-2 (bf16 output) + 2 % of max."""
+    from minsdtf_amd import ops, packing
+
+    torch.manual_seed(11)
+    M, C = case["M"], case["C"]
+    tm, tn, stg = case["tile"]
+    x = bf(torch.randn(M, C))
+    res = bf(torch.randn(M, C) * 2 + 0.5)                      # non-zero row means
+    w0 = bf(torch.randn(C, C) / math.sqrt(C))
+    b0 = torch.randn(C) * 0.1
+    t = bf(x @ w0 + b0 + res)                                  # what the producer stores (bf16)
+    gamma, beta = 1 + 0.3 * torch.randn(C), 0.2 * torch.randn(C)
+    ln = F.layer_norm(t, (C,), gamma, beta, eps=1e-5)
+    d = gpu
+    tdev = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
+    slots = ops.conv_gemm_ln_slots(N=C, tile_n=tn, tile_m=tm)
+    assert slots == -(-C // tn)
+    stats = torch.full((M, slots, 2), float("nan"), dtype=torch.float32, device=d)
+    keep = [x.to(torch.bfloat16).to(d), packing.pack_dense(w0.numpy(), d), b0.to(d), res.to(torch.bfloat16).to(d)]   # (Calls hold raw pointers)
+    prod = ops.conv_gemm(a0=keep[0], w=keep[1], out=tdev, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=keep[2], residual=keep[3],
+                         tile_m=tm, tile_n=tn, stages=stg, ln_out=stats, ln_out_slots=slots)
+    mode = case["mode"]
+    if mode == "geglu":
+        w1 = bf(torch.randn(C, 8 * C) / math.sqrt(C))
+        b1 = torch.randn(8 * C) * 0.1
+        h = ln @ w1 + b1
+        a, gate = h[:, :4 * C], h[:, 4 * C:]
+        ref = a * 0.5 * gate * (1 + torch.tanh(gate * 0.7978845608 * (1 + 0.044715 * gate ** 2)))
+        order = torch.from_numpy(packing.geglu_row_order(4 * C))
+        wf, cs, cb = packing.fold_layer_norm(w1.t().contiguous()[order], b1.numpy()[order.numpy()], gamma.numpy(), beta.numpy(), d)
+        out = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device=d)
+        cons = ops.conv_gemm(a0=tdev, w=wf, out=out, batch=1, h_in=M, w_in=1, c0=C, N=8 * C, bias=cb, act=ops.ACT_GEGLU,
+                             ln_in=stats, ln_in_slots=slots, ln_colsum=cs)
+        run_calls([prod, cons])
+        close(out, ref, atol=2e-2 * float(ref.abs().max()), what=str(case))
+    elif mode == "qkv":
+        w1 = bf(torch.randn(C, 3 * C) / math.sqrt(C))
+        ref = ln @ w1
+        wf, cs, cb = packing.fold_layer_norm(w1.t().contiguous(), None, gamma.numpy(), beta.numpy(), d)
+        q = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
+        k = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
+        sp = (M + 7) // 8 * 8
+        vt = torch.zeros((1, C, sp), dtype=torch.bfloat16, device=d)
+        cons = ops.conv_gemm(a0=tdev, w=wf, out=q, batch=1, h_in=M, w_in=1, c0=C, N=3 * C, bias=cb, split=(C, C, k, C, vt, sp),
+                             ln_in=stats, ln_in_slots=slots, ln_colsum=cs)
+        run_calls([prod, cons])
+        atol = 2e-2 * float(ref.abs().max())
+        close(q, ref[:, :C], atol=atol, what=str(case) + " q")
+        close(k, ref[:, C:2 * C], atol=atol, what=str(case) + " k")
+        close(vt[0, :, :M].t(), ref[:, 2 * C:], atol=atol, what=str(case) + " v^T")
+    else:
+        w1 = bf(torch.randn(C, C) / math.sqrt(C))
+        b1 = torch.randn(C) * 0.1
+        ref = ln @ w1 + b1
+        wf, cs, cb = packing.fold_layer_norm(w1.t().contiguous(), b1.numpy(), gamma.numpy(), beta.numpy(), d)
+        out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
+        cons = ops.conv_gemm(a0=tdev, w=wf, out=out, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=cb, ln_in=stats, ln_in_slots=slots,
+                             ln_colsum=cs)
+        run_calls([prod, cons])
+        close(out, ref, atol=2e-2 * float(ref.abs().max()), what=str(case))
+    close(tdev, t, what=str(case) + " producer output")
+    # the partials themselves: sum / sum of squares of the stored bf16 values
+    tt = tdev.float().cpu()
+    st = stats.cpu()
+    assert torch.allclose(st[:, :, 0].sum(1), tt.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[:, :, 1].sum(1), (tt * tt).sum(1), rtol=1e-4, atol=1e-2)
 
 
 @pytest.mark.parametrize("nq", [1, 0])
