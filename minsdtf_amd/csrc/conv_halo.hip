@@ -17,6 +17,12 @@
 // w % 16 == 0, h % TH == 0.
 #include "conv_common.h"
 
+#ifdef MSD_STAMPS
+extern "C" int msd_debug_stamps_halo(unsigned long long* host_out, int count) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count);
+}
+#endif
+
 // wait until at most min(later, MAXL) weight tiles (BR instructions each) + optionally one halo (HR) are in flight
 template <int BR, int HR, int MAXL>
 __device__ __forceinline__ void halo_wait(int later, bool halo) {
@@ -54,6 +60,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int r = lane & 15, g = lane >> 4;
+    MSD_STAMP(0);
 
     // ---- which tile: (n tile, sample, tile row, tile column), XCD-aware order ------------------
     const int tiles_x = p.w_in / TW, tiles_y = p.h_in / TH;
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         for (int s = 0; s < S - 1; ++s)
             if (s < nkt) issue_w(c_begin, s, s);
     }
+    MSD_STAMP(1);
     int c = c_begin, tap = 0, stage = 0, hbuf = 0;
     int cw = c_begin, tw = S - 1, sw = S - 1;   // (chunk, tap, stage) of the next weight tile to issue
     if (tw >= 9) { tw -= 9; ++cw; }
@@ -143,6 +151,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         // it-S+2 .. it-1 (loads complete in order, so "at most N outstanding" retires everything older).
         halo_wait<BR, HR, S - 2>(min(S - 2, nkt - 1 - it), since_halo <= S - 2);
         __builtin_amdgcn_s_barrier();
+#ifdef MSD_STAMPS
+        if (it == 0) MSD_STAMP(2);
+        if (it == (nkt >> 1)) MSD_STAMP(5);
+#endif
         // fragments of this K step first, then the DMA issue of the tiles ahead (it runs under the LDS latency), then the MFMAs
         const int ky = tap / 3, kx = tap - ky * 3;
         const char* bW = smem + 2 * H_BYTES + stage * W_BYTES + (wn * WNT + r) * 128;
@@ -177,10 +189,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         if (++stage == S) stage = 0;
         if (++tap == 9) { tap = 0; ++c; hbuf ^= 1; }
     }
+    MSD_STAMP(3);
     int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) mrow[i] = (b * p.h_in + ty0 + wm * MI + i) * p.w_in + tx0;
     cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WNT, r, g);
+#ifdef MSD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MSD_STAMP(4);
+#endif
 }
 
 // (tile height, BN, waves m x n).  BN = 80 exists for the N = 320 / 640 layers at batch 1-2: 8x16-pixel

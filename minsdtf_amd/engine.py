@@ -224,6 +224,8 @@ def pick_splitk(M: int, N: int, nk: int) -> int:
 # epilogues of the GEMMs around them instead of as 48 launches per UNet forward.  False = separate
 # msd_layer_norm launches (A/B runs, and any weight dict without the folded tensors).
 LN_FOLD = True
+# ff.net.2 + proj_out of a transformer block as one GEMM over the concat [ff | t2] (weights folded at pack time)
+FF_PROJ_FOLD = True
 
 
 # ----------------------------------------------------------------------------- layer emitters
@@ -375,10 +377,14 @@ class Emitter:
             n3 = self.layer_norm(t2, tb + ".norm3")
             ff = self.conv(n3, tb + ".ff.net.0.proj", 8 * C, act=ops.ACT_GEGLU)
             p.free(n3)
-        t3 = self.conv(ff, tb + ".ff.net.2", C, residual=t2)
-        p.free(ff, t2)
-        out = self.conv(t3, name + ".proj_out", C, residual=x)
-        p.free(t3)
+        if FF_PROJ_FOLD and (name + ".ffproj.w") in self.W:   # ff.net.2 and proj_out as one GEMM over [ff | t2]
+            out = self.conv((ff, t2), name + ".ffproj", C, residual=x)
+            p.free(ff, t2)
+        else:
+            t3 = self.conv(ff, tb + ".ff.net.2", C, residual=t2)
+            p.free(ff, t2)
+            out = self.conv(t3, name + ".proj_out", C, residual=x)
+            p.free(t3)
         if free_input:
             p.free(x)
         return out

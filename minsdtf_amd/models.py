@@ -172,6 +172,21 @@ class HipModel:
             order = packing.geglu_row_order(gw.shape[1] // 2)
             W[tb + ".ff.net.0.proj.lnw"], W[tb + ".ff.net.0.proj.lncs"], W[tb + ".ff.net.0.proj.lnb"] = packing.fold_layer_norm(
                 t(gw)[torch.from_numpy(order)], np.asarray(gb)[order], get(tb + ".norm3", "gamma"), get(tb + ".norm3", "beta"), d)
+        # ff.net.2 followed by proj_out (diffusion_model.py:146-147 and :66-67: two Dense layers with only the
+        # residual add of t2 between them) as ONE GEMM over the channel concat [ff | t2]:
+        #   proj_out(ff W2 + b2 + t2) = ff (W2 Wp) + t2 Wp + (b2 Wp + bp)        key <attentions>.ffproj
+        for n in names:
+            if not n.endswith(".transformer_blocks.0.ff.net.2"):
+                continue
+            att = n[: -len(".transformer_blocks.0.ff.net.2")]
+            w2, b2 = get(n, "dense_w"), get(n, "bias")
+            wp, bp = get(att + ".proj_out", "conv_w"), get(att + ".proj_out", "bias")
+            if w2 is None or wp is None:
+                continue
+            w2d, wpd = np.asarray(w2, np.float64), np.asarray(wp, np.float64).reshape(wp.shape[-2], wp.shape[-1])
+            wcat = np.concatenate([w2d @ wpd, wpd], axis=0)                       # (4C + C, C) as (in, out)
+            W[att + ".ffproj.w"] = packing.pack_dense(wcat.astype(np.float32), d)
+            W[att + ".ffproj.b"] = packing.dev_f32((np.asarray(b2, np.float64) @ wpd + np.asarray(bp, np.float64)).astype(np.float32), d)
         if tproj_w:
             W["time_emb_proj_cat.w"] = packing.dev_f32(np.concatenate(tproj_w, axis=1).reshape(1, 1, 1280, -1), d)
             W["time_emb_proj_cat.b"] = packing.dev_f32(np.concatenate(tproj_b), d)

@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="512x1280x1280:64x64:0:1,8192x320x320:128x128:0:1",
-                    help="comma list of MxNxK:tile:stages:splitk (dense, ksize 1; M = 2*h*h)")
+                    help="comma list of MxNxK:tile:stages:splitk (M = 2*h*h; K = channels, or 9*channels with --ks 3)")
+    ap.add_argument("--ks", type=int, default=1, help="1 = dense / 1x1, 3 = 3x3 conv (tile 1128 / 1256 / 2128 x N = halo kernel)")
     ap.add_argument("--dense", type=int, default=1, help="0 = general loader for 1x1 layers (A/B)")
     args = ap.parse_args()
     from minsdtf_amd import _lib
@@ -32,8 +33,9 @@ def main():
     lib = _lib.load()
     lib.msd_init()
     lib.msd_set_option(b"conv_dense", args.dense)
-    lib.msd_debug_stamps.restype = C.c_int
-    lib.msd_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+    for fn in (lib.msd_debug_stamps, lib.msd_debug_stamps_halo):
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int]
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream()
     for spec in args.shapes.split(","):
@@ -43,22 +45,24 @@ def main():
         stg, sk = int(stg), int(sk)
         h = int(round((M // 2) ** 0.5))
         assert 2 * h * h == M
-        x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        cin = K // (args.ks * args.ks)
+        x = torch.randn(M, cin, device=dev).to(torch.bfloat16)
         ws = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(max(2, (300 << 20) // (N * K * 2)))][:24]
         bias = torch.randn(N, device=dev)
         res = torch.randn(M, N, device=dev).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32)
-        calls = [ops.conv_gemm(a0=x, w=wi, out=out, batch=2, h_in=h, w_in=h, c0=K, N=N, ksize=1, bias=bias, residual=res,
+        calls = [ops.conv_gemm(a0=x, w=wi, out=out, batch=2, h_in=h, w_in=h, c0=cin, N=N, ksize=args.ks, bias=bias, residual=res,
                                workspace=wsf, workspace_floats=wsf.numel(), splitk=sk, tile_m=tm, tile_n=tn, stages=stg)
                  for wi in ws]
         for c in calls:          # the last call's stamps survive; weights rotate so they come from HBM
             c(st.cuda_stream)
         torch.cuda.synchronize()
-        bm = tm
+        halo = tm >= 1000
+        bm = (tm % 1000) if halo else tm
         nwg = ((M + bm - 1) // bm) * ((N + tn - 1) // tn) * sk
         buf = np.zeros(8 * 8192, np.uint64)
-        rc = lib.msd_debug_stamps(buf.ctypes.data, buf.size)
+        rc = (lib.msd_debug_stamps_halo if halo else lib.msd_debug_stamps)(buf.ctypes.data, buf.size)
         assert rc == 0, rc
         t = buf.reshape(8192, 8)[:min(nwg, 8192)].astype(np.int64)
         t0 = t[:, 0].min()
@@ -68,6 +72,8 @@ def main():
             return " ".join(f"{us(np.percentile(a, q)):6.2f}" for q in (0, 25, 50, 75, 100))
 
         nk = K // 64 // sk
+        if sk > 1:
+            print("   (split-K: the stamps cover the slab kernel only, not splitk_finalize)")
         print(f"--- M={M} N={N} K={K} tile {tm}x{tn} stages {stg} splitk {sk}: {nwg} workgroups, {nk} K tiles each")
         print(f"   percentiles over workgroups (us)        min    p25    p50    p75    max")
         print(f"   entry time after first entry        {pct(t[:, 0] - t0)}")

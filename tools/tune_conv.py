@@ -32,7 +32,14 @@ def collect_shapes(quick=False):
 
     tuning.lookup = hook
     engine.tuning.lookup = hook
-    W = collections.defaultdict(lambda: None)
+    class _AnyW(dict):   # every weight "exists" (so the folded layer forms are the ones walked), none is real
+        def __contains__(self, k):
+            return True
+
+        def __missing__(self, k):
+            return None
+
+    W = _AnyW()
 
     class _T:  # stands in for device tensors / buffers while walking the topology
         ptr = 0
