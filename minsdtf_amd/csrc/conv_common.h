@@ -23,10 +23,10 @@ static __device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // so
 // library, the product library never carries them): thread 0 of every workgroup records the 100 MHz
 // wall clock at a few points of conv_gemm_dma_kernel and its epilogue.
 #ifdef MSD_STAMPS
-static __device__ unsigned long long g_stamps[8 * 8192];
+static __device__ unsigned long long g_stamps[16 * 8192];
 #define MSD_STAMP(i)                                                                                             \
     do {                                                                                                         \
-        if (threadIdx.x == 0) g_stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 8 + (i)] = wall_clock64(); \
+        if (threadIdx.x == 0) g_stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] = wall_clock64(); \
     } while (0)
 #define MSD_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else

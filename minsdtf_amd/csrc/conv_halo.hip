@@ -149,11 +149,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         // Retire W(it) (and, being older in the queue, the halo of this chunk).  Younger than W(it):
         // W(it+1) .. W(it+S-2) as far as they exist, plus the halo if one was issued in iterations
         // it-S+2 .. it-1 (loads complete in order, so "at most N outstanding" retires everything older).
+#ifdef MSD_STAMPS
+        const bool probe = it == 20 || (nkt <= 20 && it == nkt - 2);   // one K step under the microscope (slots 10..15)
+        if (probe) MSD_STAMP(10);
+#endif
         halo_wait<BR, HR, S - 2>(min(S - 2, nkt - 1 - it), since_halo <= S - 2);
+#ifdef MSD_STAMPS
+        if (probe) MSD_STAMP(11);
+#endif
         __builtin_amdgcn_s_barrier();
 #ifdef MSD_STAMPS
         if (it == 0) MSD_STAMP(2);
         if (it == (nkt >> 1)) MSD_STAMP(5);
+        if (probe) MSD_STAMP(12);
 #endif
         // fragments of this K step first, then the DMA issue of the tiles ahead (it runs under the LDS latency), then the MFMAs
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -179,6 +187,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
             if (++sw == S) sw = 0;
         }
         ++since_halo;
+#ifdef MSD_STAMPS
+        if (probe) {
+            MSD_STAMP(13);                                           // fragment reads + DMA issued
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MSD_STAMP(14);                                           // fragments in registers
+        }
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -186,6 +201,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+#ifdef MSD_STAMPS
+        if (probe) {
+            asm volatile("v_mov_b32 %0, %0" : "+v"(acc[NJ - 1][MI - 1][3]));   // last MFMA of the step has retired
+            MSD_STAMP(15);
+        }
+#endif
         if (++stage == S) stage = 0;
         if (++tap == 9) { tap = 0; ++c; hbuf ^= 1; }
     }
@@ -205,6 +226,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
 // (a second, quarter-full round) and 128-wide ones 192.
 // Last column: weight-ring depth.  3 is the default of every tile; the deeper rings (selected with
 // MsdConvGemm.stages) are for launches that put a single workgroup on a CU.
+// (Tried: 64 pixels x 64 channels per wave on 4 waves — 16x16 x 64 and 8x16 x 128 tiles, fewer fragment ds_reads
+//  per MFMA — and a deeper ring for 16x16 x 128: none beat the tiles below on any UNet / VAE shape.)
 // Variant 1 (tile_m 2128): the same tile on 8 waves — two waves per SIMD even when the launch puts a
 // single workgroup on a CU, so one wave's LDS-DMA issue stalls and LDS latency hide under the other's MFMAs.
 #define MSD_HALO_CFGS(X)   \

@@ -61,10 +61,10 @@ def main():
         halo = tm >= 1000
         bm = (tm % 1000) if halo else tm
         nwg = ((M + bm - 1) // bm) * ((N + tn - 1) // tn) * sk
-        buf = np.zeros(8 * 8192, np.uint64)
+        buf = np.zeros(16 * 8192, np.uint64)
         rc = (lib.msd_debug_stamps_halo if halo else lib.msd_debug_stamps)(buf.ctypes.data, buf.size)
         assert rc == 0, rc
-        t = buf.reshape(8192, 8)[:min(nwg, 8192)].astype(np.int64)
+        t = buf.reshape(8192, 16)[:min(nwg, 8192)].astype(np.int64)
         t0 = t[:, 0].min()
         us = lambda a: a / 100.0  # 100 MHz ticks -> us
 
@@ -84,6 +84,12 @@ def main():
         print(f"   epilogue: loop done -> loads back    {pct(t[:, 6] - t[:, 3])}")
         print(f"   epilogue: arithmetic + store issue   {pct(t[:, 7] - t[:, 6])}")
         print(f"   epilogue: stores retired             {pct(t[:, 4] - t[:, 7])}")
+        if halo and t[:, 15].min() > 0:
+            print(f"   one K step: vmcnt wait              {pct(t[:, 11] - t[:, 10])}")
+            print(f"   one K step: barrier                 {pct(t[:, 12] - t[:, 11])}")
+            print(f"   one K step: ds_read + DMA issue     {pct(t[:, 13] - t[:, 12])}")
+            print(f"   one K step: fragments landed        {pct(t[:, 14] - t[:, 13])}")
+            print(f"   one K step: MFMAs issued + retired  {pct(t[:, 15] - t[:, 14])}")
         print(f"   workgroup lifetime                   {pct(t[:, 4] - t[:, 0])}")
         print(f"   exit time after first entry          {pct(t[:, 4] - t0)}")
         print(f"   kernel span {us(t[:, 4].max() - t0):.2f} us; per K tile in the loop {us(np.median(t[:, 3] - t[:, 2])) / max(1, nk - 1):.3f} us",
