@@ -226,6 +226,8 @@ def pick_splitk(M: int, N: int, nk: int) -> int:
 LN_FOLD = True
 # ff.net.2 + proj_out of a transformer block as one GEMM over the concat [ff | t2] (weights folded at pack time)
 FF_PROJ_FOLD = True
+# UNet conv_out (320 -> 4, 3x3) on the MFMA path instead of the vector-FMA kernel
+MFMA_CONV_OUT = True
 
 
 # ----------------------------------------------------------------------------- layer emitters
@@ -513,8 +515,13 @@ def emit_unet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w:
             x = y
     g = e.group_norm(x, "conv_norm_out", silu=True)
     p.free(x)
-    p.rec(ops.conv_direct, x=g.buf, w=e.W["conv_out.w"], bias=e.W["conv_out.b"], out=eps_out_f32, batch=NB, h_in=h, w_in=w,
-          c_in=320, c_out=4, ksize=3, in_dtype=ops.OUT_BF16, out_dtype=ops.OUT_F32, name="conv_out")
+    if MFMA_CONV_OUT and "conv_out.m.w" in e.W:
+        # 320 -> 4 channels: N is tiny but K = 2880, so the implicit-GEMM kernel (bf16 weights, fp32 accumulate,
+        # fp32 output) beats the vector-FMA kernel 3x; the 60 unused columns of the tile cost nothing that matters
+        e.conv(g, "conv_out", 4, ksize=3, out_dtype=ops.OUT_F32, wkey="conv_out.m", out=Act(eps_out_f32, NB, h, w, 4))
+    else:
+        p.rec(ops.conv_direct, x=g.buf, w=e.W["conv_out.w"], bias=e.W["conv_out.b"], out=eps_out_f32, batch=NB, h_in=h, w_in=w,
+              c_in=320, c_out=4, ksize=3, in_dtype=ops.OUT_BF16, out_dtype=ops.OUT_F32, name="conv_out")
     p.free(g)
 
 

@@ -130,6 +130,9 @@ class HipModel:
                 w = cw if cw is not None else dw.reshape(1, 1, *dw.shape)
                 W[n + ".w"] = packing.dev_f32(w, d)
                 W[n + ".b"] = packing.dev_f32(b, d)
+                if n == "conv_out" and cw is not None and cw.shape[2] % 64 == 0:
+                    # 320 -> 4: K = 2880 fills MFMA tiles even though N does not; 48 -> ~15 us per step (engine.MFMA_CONV_OUT)
+                    W[n + ".m.w"], W[n + ".m.b"] = packing.pack_conv(cw, d), W[n + ".b"]
                 continue
             if n.endswith(".ff.net.0.proj"):
                 W[n + ".w"], W[n + ".b"] = packing.pack_geglu(dw, b, d)
