@@ -15,19 +15,12 @@ struct CfgArgs {
     const float* step_noise; const float* noise_coef;
 };
 
-__device__ __forceinline__ double block_sum_1024(double v, double* red) {
-    // wave reduce then 16 waves through LDS
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = 0.0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
-    return t;
-}
-
+// One 1024-thread workgroup per sample.  eps (uncond / cond) is read ONCE into registers (up to NPT elements per
+// thread; larger latents take the re-reading loop) and the four moments go through one block reduction with the
+// same summation order as four separate ones (wave butterfly, then the 16 wave sums in wave order).
+template <int NPT>
 __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
-    __shared__ double red[16];
+    __shared__ double red[16][4];
     const int b = blockIdx.x, t = threadIdx.x;
     int step = p.step_ptr ? *p.step_ptr : 0;
     if (step > p.num_steps - 1) step = p.num_steps - 1;
@@ -40,28 +33,52 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
     const bool cfg = p.guidance > 0.0f;
     const float* u = p.eps + (size_t)b * p.n;
     const float* c = cfg ? p.eps + (size_t)(p.batch + b) * p.n : u;
+    float ru[NPT > 0 ? NPT : 1], rc[NPT > 0 ? NPT : 1], rl[NPT > 0 ? NPT : 1];
+    if (NPT > 0) {   // everything this thread touches, issued up front
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int i = min(t + k * 1024, p.n - 1);
+            ru[k] = u[i]; rc[k] = c[i]; rl[k] = lat[i];
+        }
+    }
     float factor = 1.0f;
     if (cfg && p.rescale > 0.0f) {
-        double s_c = 0, q_c = 0, s_g = 0, q_g = 0;
-        for (int i = t; i < p.n; i += 1024) {
-            const float cu = u[i], cc = c[i];
+        double m4[4] = {0, 0, 0, 0};   // s_c, q_c, s_g, q_g
+        auto acc = [&](float cu, float cc) {
             const float gq = cu + p.guidance * (cc - cu);
-            s_c += cc; q_c += (double)cc * cc; s_g += gq; q_g += (double)gq * gq;
+            m4[0] += cc; m4[1] += (double)cc * cc; m4[2] += gq; m4[3] += (double)gq * gq;
+        };
+        if (NPT > 0) {
+#pragma unroll
+            for (int k = 0; k < NPT; ++k)
+                if (t + k * 1024 < p.n) acc(ru[k], rc[k]);
+        } else {
+            for (int i = t; i < p.n; i += 1024) acc(u[i], c[i]);
         }
-        s_c = block_sum_1024(s_c, red); q_c = block_sum_1024(q_c, red);
-        s_g = block_sum_1024(s_g, red); q_g = block_sum_1024(q_g, red);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            for (int o = 32; o >= 1; o >>= 1) m4[q] += __shfl_xor(m4[q], o);
+        if ((t & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[t >> 6][q] = m4[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double s = 0.0;
+            for (int w = 0; w < 16; ++w) s += red[w][q];
+            m4[q] = s;
+        }
         const double n = (double)p.n;
-        const double mc = s_c / n, mg = s_g / n;
-        const double vc = fmax(q_c / n - mc * mc, 0.0), vg = fmax(q_g / n - mg * mg, 0.0);
+        const double mc = m4[0] / n, mg = m4[2] / n;
+        const double vc = fmax(m4[1] / n - mc * mc, 0.0), vg = fmax(m4[3] / n - mg * mg, 0.0);
         const float std_text = (float)sqrt(vc);
         const float std_cfg = (float)sqrt(vg) + 1e-5f;
         factor = p.rescale * (std_text / std_cfg) + (1.0f - p.rescale);
     }
-    for (int i = t; i < p.n; i += 1024) {
-        float e;
-        if (cfg) { const float cu = u[i], cc = c[i]; e = (cu + p.guidance * (cc - cu)) * factor; }
-        else e = u[i];
-        const float x0 = (lat[i] - nr * e) / sr;
+    auto update = [&](int i, float cu, float cc, float l) {
+        const float e = cfg ? (cu + p.guidance * (cc - cu)) * factor : cu;
+        const float x0 = (l - nr * e) / sr;
         float x = ca * x0 + cb * e;
         if (z) x += cz * z[i];
         if (p.ip_mask) {   // inpainting: keep the (re-noised) original outside the mask
@@ -70,6 +87,13 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
             x = org * (1.0f - m) + x * m;
         }
         lat[i] = x;
+    };
+    if (NPT > 0) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            if (t + k * 1024 < p.n) update(t + k * 1024, ru[k], rc[k], rl[k]);
+    } else {
+        for (int i = t; i < p.n; i += 1024) update(i, u[i], c[i], lat[i]);
     }
 }
 
@@ -87,7 +111,9 @@ extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
     if (a.ip_mask && (!a.ip_init || !a.ip_noise)) MSD_FAIL(MSD_E_ARG, "cfg_step: inpaint_mask needs inpaint_init and inpaint_noise");
     a.step_noise = q->step_noise; a.noise_coef = q->noise_coef;
     if (a.step_noise && !a.noise_coef) MSD_FAIL(MSD_E_ARG, "cfg_step: step_noise needs noise_coef");
-    hipLaunchKernelGGL(cfg_step_kernel, dim3(q->batch), dim3(1024), 0, stream, a);
+    if (q->n <= 16 * 1024) hipLaunchKernelGGL(cfg_step_kernel<16>, dim3(q->batch), dim3(1024), 0, stream, a);        // <= 64x64 latents
+    else if (q->n <= 36 * 1024) hipLaunchKernelGGL(cfg_step_kernel<36>, dim3(q->batch), dim3(1024), 0, stream, a);   // 96x96
+    else hipLaunchKernelGGL(cfg_step_kernel<0>, dim3(q->batch), dim3(1024), 0, stream, a);
     MSD_CHECK_LAUNCH();
     if (q->advance) {
         hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, stream, q->step_ptr);
