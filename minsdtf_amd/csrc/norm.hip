@@ -397,7 +397,8 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     // sample, which the apply kernel reduces itself (2 launches).  Large tensors (VAE at 256^2 /
     // 512^2) are byte-bound: ~1024 workgroups chip-wide and a separate ordered finalize (3 launches).
     const bool small = (long long)q->hw * C <= (4ll << 20);
-    long long target_blocks = small ? 64 : 1024 / q->batch;
+    // (wide: 128 chunks per sample — 256 workgroups at batch 2, one per CU; 64 leave half the chip idle)
+    long long target_blocks = small ? (wide ? 128 : 64) : 1024 / q->batch;
     if (target_blocks < 1) target_blocks = 1;
     int ppb = (int)((q->hw + target_blocks - 1) / target_blocks);
     const int min_ppb = wide ? a.pl : a.pl * 4;
@@ -405,7 +406,7 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     if (ppb > q->hw) ppb = q->hw;
     a.ppb = ppb;
     const int nchunks = (q->hw + ppb - 1) / ppb;
-    const bool fused = nchunks <= 64;
+    const bool fused = nchunks <= (wide ? 128 : 64);
     if (q->partials_floats < (long long)q->batch * nchunks * 64)
         MSD_FAIL(MSD_E_WORKSPACE, "group_norm: partials scratch too small (%lld < %lld floats)",
                  (long long)q->partials_floats, (long long)q->batch * nchunks * 64);
