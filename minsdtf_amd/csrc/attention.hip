@@ -26,10 +26,14 @@ struct AArgs {
     int batch, heads, s, t, q_ld, k_ld, vt_ld, o_ld;
     float sl2;  // scale * log2(e)
     int causal; // key index > query index is masked (CLIP text encoder, text_encoder.py:75-78)
+    int prio;   // raise the wave's priority inside the MFMA sections (pays when a SIMD holds 3+ waves)
 };
 
-template <int D, bool PIPE>
+// QF = 16-query MFMA column blocks per wave: 2 (128 queries per workgroup) or 1 (64 queries per workgroup: twice the
+// workgroups — for launches whose 128-query grid leaves CUs idle or a SIMD with fewer than 3 waves).
+template <int D, bool PIPE, int QF = 2>
 __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
+    constexpr int QT = 64 * QF;          // queries per workgroup
     constexpr int DPAD = ((D + 31) / 32) * 32;
     constexpr int KS = DPAD / 32;        // k-steps of QK^T
     constexpr int DF = (D + 15) / 16;    // 16-row blocks of O^T
@@ -44,11 +48,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     const int r = lane & 15, g = lane >> 4;
     // 1-D grid, XCD-aware: all query tiles of one (batch, head) run on one XCD so its K / V^T
     // (655 KB at S=4096, d=40) stay in that XCD's L2 instead of every XCD streaming all heads
-    const int qtiles = (p.s + 127) / 128;
+    const int qtiles = (p.s + QT - 1) / QT;
     const int wi = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = wi / qtiles;
     const int h = bh % p.heads, b = bh / p.heads;
-    const int q0 = (wi - bh * qtiles) * 128 + wave * 32;
+    const int q0 = (wi - bh * qtiles) * QT + wave * (16 * QF);
 
     // zero the whole LDS image once: pad columns / pad rows are never written afterwards
     for (int off = tid * 16; off < (PIPE ? 2 : 1) * BUF_BYTES; off += 256 * 16)
@@ -63,9 +67,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         }
     }
 
-    bf16x8 qf[2][KS];
+    bf16x8 qf[QF][KS];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < QF; ++f) {
         int qrow = q0 + f * 16 + r;
         if (qrow > p.s - 1) qrow = p.s - 1;
         const bf16_t* qp = p.q + ((size_t)b * p.s + qrow) * p.q_ld + h * D;
@@ -80,14 +84,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     // Retire the Q loads HERE: otherwise hipcc's wait for them lands on their first use inside the
     // tile loop as vmcnt(0), which also drains the K/V prefetch issued just before it every iteration.
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < QF; ++f)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[f][ks]));
 
-    f32x4 oacc[DF][2];
+    f32x4 oacc[DF][QF];
 #pragma unroll
-    for (int df = 0; df < DF; ++df) { oacc[df][0] = (f32x4){0, 0, 0, 0}; oacc[df][1] = (f32x4){0, 0, 0, 0}; }
-    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int f = 0; f < QF; ++f) oacc[df][f] = (f32x4){0, 0, 0, 0};
+    float mrun[QF], lrun[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) { mrun[f] = -1e30f; lrun[f] = 0.f; }
 
     const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
     const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
@@ -192,18 +200,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         }
 
         // ---- S^T = K Q^T ------------------------------------------------------------------
-        f32x4 sacc[4][2];
+        // (s_setprio: two waves share a SIMD; the one in an MFMA section goes first so the matrix core is fed while
+        //  the other wave's softmax VALU work fills the issue slots in between)
+        if (p.prio) __builtin_amdgcn_s_setprio(1);
+        f32x4 sacc[4][QF];
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf) { sacc[kf][0] = (f32x4){0, 0, 0, 0}; sacc[kf][1] = (f32x4){0, 0, 0, 0}; }
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) sacc[kf][f] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
                 const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sK + (kf * 16 + r) * KROW + ks * 64 + g * 16);
-                sacc[kf][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[0][ks], sacc[kf][0], 0, 0, 0);
-                sacc[kf][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[1][ks], sacc[kf][1], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[f][ks], sacc[kf][f], 0, 0, 0);
             }
         }
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
         // ---- online softmax: lane holds keys t0 + kf*16 + 4g + e of query f*16 + r ----------
         // Scores stay RAW (unscaled) in the accumulators: the running max is tracked on raw scores
         // (scale > 0, so the max commutes with it) and the scale is folded into the exponent with
@@ -213,11 +228,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (t0 + kf * 16 + 4 * g + e >= p.t) { sacc[kf][0][e] = -1e30f; sacc[kf][1][e] = -1e30f; }
+                    if (t0 + kf * 16 + 4 * g + e >= p.t) {
+#pragma unroll
+                        for (int f = 0; f < QF; ++f) sacc[kf][f][e] = -1e30f;
+                    }
         }
         if (p.causal) {       // every query keeps key 0, so no row is ever fully masked
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
+            for (int f = 0; f < QF; ++f) {
                 const int qi = q0 + f * 16 + r;
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
@@ -226,9 +244,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                         if (t0 + kf * 16 + 4 * g + e > qi) sacc[kf][f][e] = -1e30f;
             }
         }
-        bf16x8 pb[2][2];
+        bf16x8 pb[2][QF];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < QF; ++f) {
             // linear max chain: every pair of scores folds into one v_max3_f32
             float mx = fmaxf(sacc[0][f][0], sacc[0][f][1]);
             mx = fmaxf(fmaxf(mx, sacc[0][f][2]), sacc[0][f][3]);
@@ -274,6 +292,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
             }
         }
         // ---- O^T += V^T P^T -----------------------------------------------------------------
+        if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int df = 0; df < DF; ++df) {
 #pragma unroll
@@ -282,10 +301,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                 const char* vp = sV + (df * 16 + r) * VROW + kk * 64 + g * 8;
                 vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
                 vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 32);
-                oacc[df][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[kk][0], oacc[df][0], 0, 0, 0);
-                oacc[df][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[kk][1], oacc[df][1], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    oacc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[kk][f], oacc[df][f], 0, 0, 0);
             }
         }
+        if (p.prio) __builtin_amdgcn_s_setprio(0);
         if (PIPE && tile + 1 < ntiles) {
             char* nK = smem + (buf ^ 1) * BUF_BYTES;
             lstore(nK, nK + 64 * KROW, t0 + 64);
@@ -293,7 +314,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     }
 
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < QF; ++f) {
         float lt;
         if (ONES_ROW) {
             // row D of V^T is all ones, so O^T[D][q] accumulated sum_k P[k][q] on the matrix core
@@ -331,23 +352,37 @@ static constexpr int attn_lds_bytes() {
 }
 
 static bool g_attn_attr_done = false;
+static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = queries per wave / 16 forced (A/B runs)
+static int g_attn_prio = -1;  // -1 = automatic, 0 / 1 forced
+void msd_set_attn_qf(int v) { g_attn_qf = v; }
+void msd_set_attn_prio(int v) { g_attn_prio = v; }
+
+template <int D, int QF>
+static hipError_t attn_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D, attn_pipe<D>(), QF>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<D>());
+}
 int msd_attention_init() {
     if (g_attn_attr_done) return MSD_OK;
-    hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<40, attn_pipe<40>()>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<40>());
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<80, attn_pipe<80>()>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<80>());
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<160, attn_pipe<160>()>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<160>());
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<64, attn_pipe<64>()>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<64>());
+    hipError_t e = attn_attr<40, 2>();
+    if (e == hipSuccess) e = attn_attr<40, 1>();
+    if (e == hipSuccess) e = attn_attr<80, 2>();
+    if (e == hipSuccess) e = attn_attr<80, 1>();
+    if (e == hipSuccess) e = attn_attr<160, 2>();
+    if (e == hipSuccess) e = attn_attr<160, 1>();
+    if (e == hipSuccess) e = attn_attr<64, 2>();
+    if (e == hipSuccess) e = attn_attr<64, 1>();
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
     g_attn_attr_done = true;
     return MSD_OK;
+}
+
+template <int D>
+static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
+    const int qt = 64 * qf;
+    dim3 grid(((a.s + qt - 1) / qt) * a.heads * a.batch);
+    if (qf == 1) hipLaunchKernelGGL((attention_kernel<D, attn_pipe<D>(), 1>), grid, dim3(256), attn_lds_bytes<D>(), stream, a);
+    else hipLaunchKernelGGL((attention_kernel<D, attn_pipe<D>(), 2>), grid, dim3(256), attn_lds_bytes<D>(), stream, a);
 }
 
 extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
@@ -370,12 +405,19 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     a.sl2 = q->scale * 1.4426950408889634f;
     a.causal = q->causal ? 1 : 0;
     if (a.causal && q->s != q->t) MSD_FAIL(MSD_E_ARG, "attention: causal masking needs s == t");
-    dim3 grid(((q->s + 127) / 128) * q->heads * q->batch);
+    // Workgroup size in queries: 128, or 64 when the 128-query grid has fewer workgroups than ~1.5 x the CUs (S = 1024
+    // and below at batch 2: 128 / 32 / 8 workgroups).  Measured on one box (us, 128 vs 64 queries per workgroup): S=4096
+    // d=40 116 / 125; S=1024 d=80 35 / 28; S=256 d=160 17 / 13; S=4096 T=77 8.8 / 9.8; S=9216 525 / 584.
+    // s_setprio in the MFMA sections: 0-4 % either way; on (116 vs 121 us at S=4096, 389 vs 397 at batch 8).
+    const long long wgs128 = (long long)((q->s + 127) / 128) * q->heads * q->batch;
+    int qf = g_attn_qf ? g_attn_qf : (wgs128 < 384 ? 1 : 2);
+    if (qf != 1) qf = 2;
+    a.prio = g_attn_prio >= 0 ? g_attn_prio : 1;
     switch (q->head_dim) {
-        case 40: hipLaunchKernelGGL((attention_kernel<40, attn_pipe<40>()>), grid, dim3(256), attn_lds_bytes<40>(), stream, a); break;
-        case 80: hipLaunchKernelGGL((attention_kernel<80, attn_pipe<80>()>), grid, dim3(256), attn_lds_bytes<80>(), stream, a); break;
-        case 160: hipLaunchKernelGGL((attention_kernel<160, attn_pipe<160>()>), grid, dim3(256), attn_lds_bytes<160>(), stream, a); break;
-        case 64: hipLaunchKernelGGL((attention_kernel<64, attn_pipe<64>()>), grid, dim3(256), attn_lds_bytes<64>(), stream, a); break;
+        case 40: attn_launch<40>(a, qf, stream); break;
+        case 80: attn_launch<80>(a, qf, stream); break;
+        case 160: attn_launch<160>(a, qf, stream); break;
+        case 64: attn_launch<64>(a, qf, stream); break;
         default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 64, 80, 160)", q->head_dim);
     }
     MSD_CHECK_LAUNCH();

@@ -27,6 +27,8 @@ void msd_set_conv_impl(int v);
 void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
+void msd_set_attn_qf(int v);
+void msd_set_attn_prio(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "conv_impl" (1 = LDS-DMA ring
  * [default], 0 = first-generation register-staged kernel); "gn_impl" (1 = single-launch per-group
  * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
@@ -37,6 +39,14 @@ extern "C" int msd_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "conv_dense") == 0) {   // 1 = DENSE loader for 1x1 / Dense layers [default], 0 = general loader
         msd_set_conv_dense(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "attn_qf") == 0) {     // 0 = automatic [default], 1 / 2 = 64 / 128 queries per workgroup
+        msd_set_attn_qf(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "attn_prio") == 0) {   // -1 = automatic [default], 0 / 1 = s_setprio in the MFMA sections off / on
+        msd_set_attn_prio(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "gn_wide") == 0) {   // 1 = 1024-thread GroupNorm workgroups for mid-sized tensors [default]

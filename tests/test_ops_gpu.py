@@ -385,8 +385,9 @@ def test_layer_norm(gpu, rows, c):
     dict(B=1, H=2, d=40, S=72, T=72),        # ragged queries
     dict(B=1, H=8, d=80, S=256, T=256, spike=True),  # forces online-softmax rescales
 ])
-def test_attention(gpu, case):
-    from minsdtf_amd import ops
+@pytest.mark.parametrize("qf", [2, 1])   # 128 / 64 queries per workgroup (the library picks by grid size; both forced here)
+def test_attention(gpu, case, qf):
+    from minsdtf_amd import _lib, ops
 
     torch.manual_seed(7)
     B, H, d, S, T = case["B"], case["H"], case["d"], case["S"], case["T"]
@@ -408,12 +409,17 @@ def test_attention(gpu, case):
     vt = torch.zeros(B, C, Tp, dtype=torch.bfloat16, device=gpu)
     vt[:, :, :T] = v.permute(0, 2, 1).to(torch.bfloat16).to(gpu)
     out = torch.full((B, S, C), float("nan"), dtype=torch.bfloat16, device=gpu)
-    call = ops.attention(q=qbuf.data_ptr() + 2 * C, k=k.to(torch.bfloat16).to(gpu), vt=vt, out=out, batch=B, heads=H,
+    kd = k.to(torch.bfloat16).to(gpu)
+    call = ops.attention(q=qbuf.data_ptr() + 2 * C, k=kd, vt=vt, out=out, batch=B, heads=H,
                          head_dim=d, s=S, t=T, q_ld=3 * C, k_ld=C, vt_ld=Tp, o_ld=C, scale=scale)
-    run_calls(call)
+    _lib.load().msd_set_option(b"attn_qf", qf)
+    try:
+        run_calls(call)
+    finally:
+        _lib.load().msd_set_option(b"attn_qf", 0)
     # P is rounded to bf16 before the PV product (relative 2^-9 per term): the error scales with the
     # magnitude of the summed terms, so the absolute floor is 1.5e-2 of max(1, max|O|)
-    close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=str(case))
+    close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"{case} qf={qf}")
 
 
 def test_softmax_rows(gpu):

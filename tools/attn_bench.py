@@ -24,11 +24,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--qf", type=int, default=0, help="0 = automatic, 1 / 2 = 64 / 128 queries per workgroup")
+    ap.add_argument("--prio", type=int, default=-1, help="-1 = automatic, 0 / 1 = s_setprio in the MFMA sections")
     args = ap.parse_args()
     from minsdtf_amd import _lib, ops
 
     lib = _lib.load()
     lib.msd_init()
+    lib.msd_set_option(b"attn_qf", args.qf)
+    lib.msd_set_option(b"attn_prio", args.prio)
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream()
     for idx, (name, B, H, d, S, T) in enumerate(SHAPES):
