@@ -363,9 +363,17 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, in
     const int m = (int)(idx / nq);
     const int n = (int)(idx - (long long)m * nq) * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < slices; ++z) {
-        const float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    // 8 slab loads in flight per thread (a one-load-per-iteration loop pays a full memory round trip per slice:
+    // 6 us for 12 slices of a 128 x 1280 layer); the adds keep the slice order, so the result is unchanged
+    const float* src = p.ws + (size_t)m * p.N + n;
+    const size_t zs = (size_t)p.M * p.N;
+    for (int z0 = 0; z0 < slices; z0 += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)min(z0 + u, slices - 1) * zs);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (z0 + u < slices) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
     }
     const int step = p.step_ptr ? *p.step_ptr : 0;
     cg_store4(p, m, m / p.hw_out, n, step, v);
