@@ -421,10 +421,22 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
             attr_done = true;
         }
         if (vpt != 1 || lds > 160 * 1024) MSD_FAIL(MSD_E_UNSUPPORTED, "group_norm: wide path needs C <= 2048");
+        if (fused) {
+            // The statistics pass runs on 4x coarser chunks than the apply pass: every apply workgroup re-reduces ALL
+            // the partial moments of its sample (fixed order), and with one partial set per apply chunk that is as
+            // many bytes as the tensor itself (128 chunks x 256 B per workgroup x 256 workgroups = 8 MB).
+            GNArgs as = a;
+            as.ppb = ppb * 4 < q->hw ? ppb * 4 : q->hw;
+            const int nchunks_s = (q->hw + as.ppb - 1) / as.ppb;
+            hipLaunchKernelGGL((gn_stats_kernel<1, 1024>), dim3(nchunks_s, q->batch), dim3(1024), lds, stream, as);
+            MSD_CHECK_LAUNCH();
+            hipLaunchKernelGGL((gn_apply_kernel<1, true, 1024>), grid, dim3(1024), 0, stream, a, nchunks_s);
+            MSD_CHECK_LAUNCH();
+            return MSD_OK;
+        }
         hipLaunchKernelGGL((gn_stats_kernel<1, 1024>), grid, dim3(1024), lds, stream, a);
         MSD_CHECK_LAUNCH();
-        if (fused) hipLaunchKernelGGL((gn_apply_kernel<1, true, 1024>), grid, dim3(1024), 0, stream, a, nchunks);
-        else {
+        {
             hipLaunchKernelGGL(gn_finalize_kernel, dim3(q->batch), dim3(1024), 0, stream, a, nchunks);
             MSD_CHECK_LAUNCH();
             hipLaunchKernelGGL((gn_apply_kernel<1, false, 1024>), grid, dim3(1024), 0, stream, a, nchunks);
