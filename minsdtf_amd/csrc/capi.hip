@@ -23,20 +23,14 @@ extern "C" int msd_init(void) {
     return msd_attention_init();
 }
 
-void msd_set_conv_impl(int v);
 void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
 void msd_set_attn_qf(int v);
 void msd_set_attn_prio(int v);
-/* Tuning / A-B switches (not needed for normal use). Known keys: "conv_impl" (1 = LDS-DMA ring
- * [default], 0 = first-generation register-staged kernel); "gn_impl" (1 = single-launch per-group
+/* Tuning / A-B switches (not needed for normal use). Known keys: "gn_impl" (1 = single-launch per-group
  * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
 extern "C" int msd_set_option(const char* key, int value) {
-    if (key && strcmp(key, "conv_impl") == 0) {
-        msd_set_conv_impl(value);
-        return MSD_OK;
-    }
     if (key && strcmp(key, "conv_dense") == 0) {   // 1 = DENSE loader for 1x1 / Dense layers [default], 0 = general loader
         msd_set_conv_dense(value);
         return MSD_OK;

@@ -228,133 +228,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
 #endif
 }
 
-// ---- first-generation kernel: register-staged, one tile ahead (kept for A/B runs) --------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const CGArgs p) {
-    constexpr int WM = BM / 2, WN = BN / 2;      // 2 x 2 waves
-    constexpr int MI = WM / 16, NJ = WN / 16;    // 16x16 fragments per wave tile
-    constexpr int AR = BM / 32, BR = BN / 32;    // rows staged per thread (256 threads = 32 rows x 8 chunks)
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;
-    char* sB = smem + 2 * A_BYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 15, g = lane >> 4;
-    const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kt_begin = blockIdx.y * p.nk_per;
-    const int kt_end = min(p.nk, kt_begin + p.nk_per);
-
-    const int chunk = tid & 7, lrow = tid >> 3;
-    const int Hl = p.upsample ? 2 * p.h_in : p.h_in;
-    const int Wl = p.upsample ? 2 * p.w_in : p.w_in;
-    int ab[AR], ay[AR], ax[AR];
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        if (m < p.M) {
-            const int b = m / p.hw_out;
-            const int rem = m - b * p.hw_out;
-            const int y = rem / p.w_out;
-            const int x = rem - y * p.w_out;
-            ab[i] = b * p.h_in * p.w_in;
-            ay[i] = y * p.stride - p.pad;
-            ax[i] = x * p.stride - p.pad;
-        } else {
-            ab[i] = 0; ay[i] = -(1 << 20); ax[i] = -(1 << 20);
-        }
-    }
-    const bf16_t* wrow[BR];
-    bool wok[BR];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-        const int n = n0 + lrow + 32 * i;
-        wok[i] = n < p.N;
-        wrow[i] = p.w + (size_t)(wok[i] ? n : 0) * p.K + chunk * 8;
-    }
-
-    uint4 ra[AR], rb[BR];
-    auto load_tile = [&](int kt) {
-        const int tap = kt / p.nkc;
-        const int c = (kt - tap * p.nkc) * 64;
-        const int ky = tap / p.ksize;
-        const int kx = tap - ky * p.ksize;
-        const bf16_t* src; int csrc, coff;
-        if (c < p.c0) { src = p.a0; csrc = p.c0; coff = c; } else { src = p.a1; csrc = p.c1; coff = c - p.c0; }
-        coff += chunk * 8;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            int iy = ay[i] + ky, ix = ax[i] + kx;
-            const bool ok = ((unsigned)iy < (unsigned)Hl) && ((unsigned)ix < (unsigned)Wl);
-            if (p.upsample) { iy >>= 1; ix >>= 1; }
-            if (ok) {
-                ra[i] = *reinterpret_cast<const uint4*>(src + (size_t)(ab[i] + iy * p.w_in + ix) * csrc + coff);
-            } else {
-                ra[i] = make_uint4(0, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            if (wok[i]) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (size_t)kt * 64);
-            else rb[i] = make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int row = lrow + 32 * i;
-            *reinterpret_cast<uint4*>(sA + buf * A_BYTES + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const int row = lrow + 32 * i;
-            *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = rb[i];
-        }
-    };
-
-    f32x4 acc[NJ][MI];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-    const int swz = r >> 1;  // (row>>1)&7 for row = 16*q + r
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        const bool more = (kt + 1) < kt_end;
-        if (more) load_tile(kt + 1);
-        const char* bA = sA + buf * A_BYTES + (wm * WM + r) * 128;
-        const char* bB = sB + buf * B_BYTES + (wn * WN + r) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + g) ^ swz) << 4;
-            bf16x8 af[MI], wf[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-    int mrow[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * WM + i * 16;
-    cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WN, r, g);
-}
-
 // split-K: sum the fp32 slabs in slice order, then the same epilogue (plain mode only)
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, int slices) {
     const int nq = p.N >> 2;
@@ -419,19 +292,13 @@ constexpr int NUM_TILE_CFGS = 18;
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream);
 
 static bool g_cg_attr_done = false;
-static int g_conv_impl = 1;  // 1 = LDS-DMA ring (default), 0 = register-staged first-generation kernel
 static int g_conv_dense = 1; // 1 = 1x1 / Dense layers take the DENSE loader (default), 0 = the general loader (A/B runs)
-void msd_set_conv_impl(int v) { g_conv_impl = v; }
 void msd_set_conv_dense(int v) { g_conv_dense = v; }
 
 int msd_conv_gemm_init() {
     if (g_cg_attr_done) return MSD_OK;
     hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 128>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128, 64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 64) * 128);
+    e = hipSuccess;
 #define X(id, bm, bn, wgm, wgn, st, code)                                                                           \
     if (e == hipSuccess)                                                                                            \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dma_kernel<bm, bn, wgm, wgn, st, false>),  \
@@ -450,7 +317,7 @@ int msd_conv_gemm_init() {
 static int cg_effective_bn(const MsdConvGemm* q) {
     int bn = q->tile_n;
     if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
-    if (bn == 80 && (q->act == MSD_ACT_GEGLU || g_conv_impl != 1)) bn = 64;
+    if (bn == 80 && q->act == MSD_ACT_GEGLU) bn = 64;
     return bn;
 }
 
@@ -541,7 +408,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     }
     if (q->ln_out) {
         if (q->split_mode || q->out_dtype != MSD_OUT_BF16 || q->act == MSD_ACT_GEGLU || q->ksize != 1 || q->tile_m >= 1000 ||
-            (((uintptr_t)q->ln_out) & 7u) || g_conv_impl != 1)
+            (((uintptr_t)q->ln_out) & 7u))
             MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out needs a plain 1x1 launch with a bf16 output");
         if (q->ln_out_slots != msd_conv_gemm_ln_slots(q))
             MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out_slots=%d, this launch writes %d partials per row", q->ln_out_slots,
@@ -554,7 +421,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     int halo_th = 0;
     if (q->tile_m >= 1000) {
         const int th = (q->tile_m % 1000) / 16;   // 1128 / 1256: 8x16 / 16x16 pixels; 2128: 8x16 on 8 waves
-        const bool ok = g_conv_impl == 1 && q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
+        const bool ok = q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
                         q->w_out == q->w_in && !q->upsample && (q->w_in % 16) == 0 &&
                         (th == 8 || th == 16) && (q->h_in % th) == 0;
         if (ok) halo_th = th;
@@ -598,7 +465,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         if (g_cfgs[i].bm == bm && g_cfgs[i].bn == bn && (cfg < 0 || g_cfgs[i].stages == stages_req)) cfg = i;
     // (the first entry of a tile size is its default ring depth; `stages` selects a deeper ring: more
     //  bytes in flight per CU for the weight-streaming small-M layers that run one workgroup per CU)
-    if (cfg < 0 || (g_conv_impl != 1 && bm != 128))
+    if (cfg < 0)
         MSD_FAIL(MSD_E_ARG, "conv_gemm: unsupported tile %dx%d (have 128x128 128x64 64x64 64x128 256x128)", bm, bn);
     const int tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = (a.N + bn - 1) / bn;
@@ -609,8 +476,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     const bool dense = g_conv_dense && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in &&
                        (long long)a.M * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 < (1ll << 32) - 4096 &&
                        (long long)a.N * a.K * 2 < (1ll << 32) - 4096;
-    if (g_conv_impl == 1) {
-        switch (cfg) {
+    switch (cfg) {
 #define X(id, bm_, bn_, wgm, wgn, st, code)                                                                             \
     case id:                                                                                                            \
         if (dense)                                                                                                      \
@@ -620,14 +486,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
             hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st, false>), grid, dim3(wgm * wgn * 64),       \
                                cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, a);                                       \
         break;
-            MSD_TILE_CFGS(X)
+        MSD_TILE_CFGS(X)
 #undef X
-        }
-    } else {
-        if (bn == 128)
-            hipLaunchKernelGGL((conv_gemm_kernel<128, 128>), grid, dim3(256), 2 * (128 + 128) * 128, stream, a);
-        else
-            hipLaunchKernelGGL((conv_gemm_kernel<128, 64>), grid, dim3(256), 2 * (128 + 64) * 128, stream, a);
     }
     MSD_CHECK_LAUNCH();
     if (slices > 1) {

@@ -35,14 +35,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--iters", type=int, default=30)
-    ap.add_argument("--impl", type=int, default=1)
     ap.add_argument("--tile-n", type=int, default=0)
     args = ap.parse_args()
     from minsdtf_amd import _lib, ops
 
     lib = _lib.load()
     lib.msd_init()
-    lib.msd_set_option(b"conv_impl", args.impl)
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream()
     for idx, (name, B, H, W, c0, c1, N, ks, sk) in enumerate(SHAPES):
