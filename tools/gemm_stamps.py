@@ -24,6 +24,7 @@ def main():
                     help="comma list of MxNxK:tile:stages:splitk (M = 2*h*h; K = channels, or 9*channels with --ks 3)")
     ap.add_argument("--ks", type=int, default=1, help="1 = dense / 1x1, 3 = 3x3 conv (tile 1128 / 1256 / 2128 x N = halo kernel)")
     ap.add_argument("--dense", type=int, default=1, help="0 = general loader for 1x1 layers (A/B)")
+    ap.add_argument("--hot", action="store_true", help="one weight buffer (L2 / Infinity-Cache resident) instead of > 256 MiB of rotating copies")
     args = ap.parse_args()
     from minsdtf_amd import _lib
 
@@ -47,7 +48,9 @@ def main():
         assert 2 * h * h == M
         cin = K // (args.ks * args.ks)
         x = torch.randn(M, cin, device=dev).to(torch.bfloat16)
-        ws = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(max(2, (300 << 20) // (N * K * 2)))][:24]
+        ws = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(1 if args.hot else max(2, (300 << 20) // (N * K * 2)))][:24]
+        if args.hot:
+            ws = ws * 6
         bias = torch.randn(N, device=dev)
         res = torch.randn(M, N, device=dev).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
