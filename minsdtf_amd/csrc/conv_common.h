@@ -12,12 +12,23 @@ struct CGArgs {
     int tiles_m, m_fast;   // m_fast: consecutive tiles (= same XCD) share the WEIGHT rows instead of the pixel rows
     int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
     int split_mode, ns0, ns1, out1_ld, out2_ld;
+    uint32_t mg_tdiv, mg_hw, mg_tps, mg_tx;   // floor(2^32 / d) for d = tile-mapping divisor, hw_out, tiles per sample, tiles per row (udiv_magic)
     const float* ln_in; const float* ln_colsum; float* ln_out;   // LayerNorm fold (minsdtf_hip.h)
     int ln_in_slots, ln_out_slots;
     float ln_eps, ln_inv_k;
 };
 
 static __device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows (one copy per TU)
+
+// x / d for 0 <= x < 2^31 with magic = floor(2^32 / d) precomputed on the host: umulhi gives floor(x/d) or one less,
+// one compare fixes it — 4 instructions instead of the ~25 dependent ones of an integer division by a runtime value
+// (the kernels' prologues and epilogues are latency chains of exactly such scalar code).
+__device__ __forceinline__ int udiv_magic(int x, int d, uint32_t magic) {
+    int q = (int)__umulhi((uint32_t)x, magic);
+    if (x - q * d >= d) ++q;
+    return q;
+}
+static inline uint32_t udiv_magic_of(int d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint64_t)d); }
 
 // In-kernel timeline stamps (tools/gemm_stamps.py; `make stamps` builds a separate instrumented
 // library, the product library never carries them): thread 0 of every workgroup records the 100 MHz
@@ -209,7 +220,7 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
     float4 rv[MI][NJ];
     int bidx[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) bidx[i] = (p.rowvec || p.split_mode) ? min(mrow[i] + r, p.M - 1) / p.hw_out : 0;
+    for (int i = 0; i < MI; ++i) bidx[i] = (p.rowvec || p.split_mode) ? udiv_magic(min(mrow[i] + r, p.M - 1), p.hw_out, p.mg_hw) : 0;
     if (plain_res) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     // which operand the XCD-contiguous run shares: the pixel rows (n fastest) when the activation
     // tensor is the bigger one, the weight rows (m fastest) for the weight-heavy small-M layers —
     // otherwise every XCD's L2 pulls its own copy of up to 59 MB of weights per layer
-    const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;   // ONE integer division (a scalar division is ~25 dependent instructions)
-    const int tq = tile / tdiv, tr = tile - tq * tdiv;
+    const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;   // one division, by a host-prepared magic number
+    const int tq = udiv_magic(tile, tdiv, p.mg_tdiv), tr = tile - tq * tdiv;
     const int tile_n = p.m_fast ? tq : tr;
     const int tile_m = p.m_fast ? tr : tq;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, in
             if (z0 + u < slices) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
     }
     const int step = p.step_ptr ? *p.step_ptr : 0;
-    cg_store4(p, m, m / p.hw_out, n, step, v);
+    cg_store4(p, m, udiv_magic(m, p.hw_out, p.mg_hw), n, step, v);
 }
 
 // ---- tile configurations of the LDS-DMA kernel ------------------------------------------------
@@ -388,6 +388,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.h_out = q->h_out; a.w_out = q->w_out; a.ksize = q->ksize; a.stride = q->stride; a.pad = q->pad;
     a.upsample = q->upsample ? 1 : 0;
     a.hw_out = q->h_out * q->w_out;
+    a.mg_hw = udiv_magic_of(a.hw_out);
     const long long M = (long long)q->batch * a.hw_out;
     if (M > (1ll << 30)) MSD_FAIL(MSD_E_ARG, "conv_gemm: M too large");
     a.M = (int)M; a.N = q->N;
@@ -450,6 +451,9 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         a.tiles_n = (a.N + bn - 1) / bn;
         a.tiles_m = a.batch * (a.h_in / halo_th) * (a.w_in / 16);
         a.m_fast = (a.N > a.M) ? 1 : 0;
+        a.mg_tdiv = udiv_magic_of(a.m_fast ? a.tiles_m : a.tiles_n);
+        a.mg_tps = udiv_magic_of((a.h_in / halo_th) * (a.w_in / 16));
+        a.mg_tx = udiv_magic_of(a.w_in / 16);
         rc = msd_conv_halo_launch(a, halo_th, bn, q->stages, q->tile_m >= 2000 ? 1 : 0, slices, stream);
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
@@ -473,6 +477,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.tiles_n = (a.N + bn - 1) / bn;
     a.tiles_m = tiles_m;
     a.m_fast = (a.N > a.M) ? 1 : 0;   // weights are the bigger operand: keep each weight panel on one XCD
+    a.mg_tdiv = udiv_magic_of(a.m_fast ? a.tiles_m : a.tiles_n);
+    a.mg_tps = a.mg_tx = 0;
     dim3 grid(tiles_m * a.tiles_n, slices);
     // 1x1 / Dense form: 32-bit byte offsets from the tensor bases
     const bool dense = g_conv_dense && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in &&

@@ -66,13 +66,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     const int tiles_x = p.w_in / TW, tiles_y = p.h_in / TH;
     const int tps = tiles_x * tiles_y;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;   // ONE integer division (a scalar division is ~25 dependent instructions)
-    const int tq = tile / tdiv, tr = tile - tq * tdiv;
+    const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;   // divisions by host-prepared magic numbers
+    const int tq = udiv_magic(tile, tdiv, p.mg_tdiv), tr = tile - tq * tdiv;
     const int tile_n = p.m_fast ? tq : tr;
     const int tmi = p.m_fast ? tr : tq;
-    const int b = tmi / tps;
+    const int b = udiv_magic(tmi, tps, p.mg_tps);
     const int trem = tmi - b * tps;
-    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;
+    const int tyi = udiv_magic(trem, tiles_x, p.mg_tx);
+    const int ty0 = tyi * TH, tx0 = (trem - tyi * tiles_x) * TW;
     const int n0 = tile_n * BN;
     const int nchunks = p.nkc;                             // 64-channel chunks of the (concatenated) input
     const int c_begin = blockIdx.y * p.nk_per;             // split-K is over chunks here
