@@ -101,9 +101,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
             continue;
         }
         if (m < p.M) {
-            const int b = m / p.hw_out;
+            const int b = udiv_magic(m, p.hw_out, p.mg_hw);
             const int rem = m - b * p.hw_out;
-            const int y = rem / p.w_out;
+            const int y = udiv_magic(rem, p.w_out, p.mg_w);
             const int x = rem - y * p.w_out;
             ab[i] = b * p.h_in * p.w_in;
             ay[i] = y * p.stride - p.pad;
@@ -389,6 +389,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.upsample = q->upsample ? 1 : 0;
     a.hw_out = q->h_out * q->w_out;
     a.mg_hw = udiv_magic_of(a.hw_out);
+    a.mg_w = udiv_magic_of(a.w_out);
     const long long M = (long long)q->batch * a.hw_out;
     if (M > (1ll << 30)) MSD_FAIL(MSD_E_ARG, "conv_gemm: M too large");
     a.M = (int)M; a.N = q->N;
