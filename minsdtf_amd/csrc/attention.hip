@@ -27,6 +27,7 @@ struct AArgs {
     float sl2;  // scale * log2(e)
     int causal; // key index > query index is masked (CLIP text encoder, text_encoder.py:75-78)
     int prio;   // raise the wave's priority inside the MFMA sections (pays when a SIMD holds 3+ waves)
+    uint32_t mg_qtiles, mg_heads;   // floor(2^32 / d) for the workgroup-id decomposition (udiv_magic)
 };
 
 // QF = 16-query MFMA column blocks per wave: 2 (128 queries per workgroup) or 1 (64 queries per workgroup: twice the
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     // (655 KB at S=4096, d=40) stay in that XCD's L2 instead of every XCD streaming all heads
     const int qtiles = (p.s + QT - 1) / QT;
     const int wi = xcd_remap(blockIdx.x, gridDim.x);
-    const int bh = wi / qtiles;
-    const int h = bh % p.heads, b = bh / p.heads;
+    const int bh = udiv_magic(wi, qtiles, p.mg_qtiles);
+    const int b = udiv_magic(bh, p.heads, p.mg_heads), h = bh - b * p.heads;
     const int q0 = (wi - bh * qtiles) * QT + wave * (16 * QF);
 
     // zero the whole LDS image once: pad columns / pad rows are never written afterwards
@@ -413,6 +414,8 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     int qf = g_attn_qf ? g_attn_qf : (wgs128 < 384 ? 1 : 2);
     if (qf != 1) qf = 2;
     a.prio = g_attn_prio >= 0 ? g_attn_prio : 1;
+    a.mg_qtiles = udiv_magic_of((q->s + 64 * qf - 1) / (64 * qf));
+    a.mg_heads = udiv_magic_of(q->heads);
     switch (q->head_dim) {
         case 40: attn_launch<40>(a, qf, stream); break;
         case 80: attn_launch<80>(a, qf, stream); break;

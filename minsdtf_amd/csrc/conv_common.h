@@ -20,15 +20,6 @@ struct CGArgs {
 
 static __device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows (one copy per TU)
 
-// x / d for 0 <= x < 2^31 with magic = floor(2^32 / d) precomputed on the host: umulhi gives floor(x/d) or one less,
-// one compare fixes it — 4 instructions instead of the ~25 dependent ones of an integer division by a runtime value
-// (the kernels' prologues and epilogues are latency chains of exactly such scalar code).
-__device__ __forceinline__ int udiv_magic(int x, int d, uint32_t magic) {
-    int q = (int)__umulhi((uint32_t)x, magic);
-    if (x - q * d >= d) ++q;
-    return q;
-}
-static inline uint32_t udiv_magic_of(int d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint64_t)d); }
 
 // In-kernel timeline stamps (tools/gemm_stamps.py; `make stamps` builds a separate instrumented
 // library, the product library never carries them): thread 0 of every workgroup records the 100 MHz

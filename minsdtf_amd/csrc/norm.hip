@@ -14,6 +14,7 @@ struct GNArgs {
     float* stats; float* partials; bf16_t* out;
     int batch, hw, c0, c1, C, cv, tpp, pl, ppb, silu;
     float eps;
+    uint32_t mg_tpp, mg_cpg;   // floor(2^32 / d) for d = tpp, C / 32 (udiv_magic: these launches are latency chains of scalar code)
 };
 
 // NT threads per workgroup: 256, or 1024 for the mid-sized tensors (the UNet's 64x64 level) where a
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const GNArgs p) {
     float* part = reinterpret_cast<float*>(smem_raw);  // [pl][C][2]
     float* chan = part + (size_t)p.pl * p.C * 2;        // [C][2]
     const int t = threadIdx.x, b = blockIdx.y;
-    const int cvi = t % p.tpp, pli = t / p.tpp;
+    const int pli = udiv_magic(t, p.tpp, p.mg_tpp), cvi = t - pli * p.tpp;
     const bool active = pli < p.pl;
     const int p_begin = blockIdx.x * p.ppb;
     const int p_end = min(p.hw, p_begin + p.ppb);
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const GNArgs p, int nchunk
     __shared__ float red[NT / 64][64];
     constexpr int U = 4;  // pixels in flight per thread
     const int t = threadIdx.x, b = blockIdx.y;
-    const int cvi = t % p.tpp, pli = t / p.tpp;
+    const int pli = udiv_magic(t, p.tpp, p.mg_tpp), cvi = t - pli * p.tpp;
     const bool active = pli < p.pl;
     const int p_begin = blockIdx.x * p.ppb;
     const int p_end = min(p.hw, p_begin + p.ppb);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const GNArgs p, int nchunk
         const float bt[8] = {b0[v].x, b0[v].y, b0[v].z, b0[v].w, b1[v].x, b1[v].y, b1[v].z, b1[v].w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = on[v] ? (c0 + e) / cpg : 0;
+            const int g = on[v] ? udiv_magic(c0 + e, cpg, p.mg_cpg) : 0;
             const float a = s_rstd[g] * gm[e];
             ca[v][e] = a;
             cb[v][e] = bt[e] - s_mean[g] * a;
@@ -256,7 +257,7 @@ template <> struct gn_vec<2> { typedef uint2 type; };
 template <> struct gn_vec<4> { typedef uint4 type; };
 
 template <int NPT, int V>
-__global__ __launch_bounds__(1024) void gn_group_kernel(const GNArgs p, int upp) {
+__global__ __launch_bounds__(1024) void gn_group_kernel(const GNArgs p, int upp, int ppp, uint32_t mg_upp) {
     typedef typename gn_vec<V>::type vec_t;
     __shared__ float red[16][2];
     __shared__ float s_stat[2];
@@ -264,8 +265,8 @@ __global__ __launch_bounds__(1024) void gn_group_kernel(const GNArgs p, int upp)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = slot >> 2, g = xcd * 4 + (slot & 3);
     const int cpg = p.C / 32;
-    const int ppp = 1024 / upp;                 // pixels per pass of the workgroup
-    const int pl = t / upp, u = t - pl * upp;   // my pixel lane, my unit inside the group's run
+    // (ppp = 1024 / upp: pixels per pass of the workgroup)
+    const int pl = udiv_magic(t, upp, mg_upp), u = t - pl * upp;   // my pixel lane, my unit inside the group's run
     const bool active = pl < ppp;
     const int c = g * cpg + u * 2 * V;          // first of my 2V channels
     const size_t row0 = (size_t)b * p.hw;
@@ -338,10 +339,12 @@ __global__ __launch_bounds__(1024) void gn_group_kernel(const GNArgs p, int upp)
 template <int V>
 static void gn_group_launch(const GNArgs& a, int upp, int npt, dim3 grid, hipStream_t stream) {
     const dim3 block(1024);
-    if (npt <= 2) hipLaunchKernelGGL((gn_group_kernel<2, V>), grid, block, 0, stream, a, upp);
-    else if (npt <= 4) hipLaunchKernelGGL((gn_group_kernel<4, V>), grid, block, 0, stream, a, upp);
-    else if (npt <= 8) hipLaunchKernelGGL((gn_group_kernel<8, V>), grid, block, 0, stream, a, upp);
-    else if constexpr (V < 4) hipLaunchKernelGGL((gn_group_kernel<16, V>), grid, block, 0, stream, a, upp);
+    const int ppp = 1024 / upp;
+    const uint32_t mg = udiv_magic_of(upp);
+    if (npt <= 2) hipLaunchKernelGGL((gn_group_kernel<2, V>), grid, block, 0, stream, a, upp, ppp, mg);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_group_kernel<4, V>), grid, block, 0, stream, a, upp, ppp, mg);
+    else if (npt <= 8) hipLaunchKernelGGL((gn_group_kernel<8, V>), grid, block, 0, stream, a, upp, ppp, mg);
+    else if constexpr (V < 4) hipLaunchKernelGGL((gn_group_kernel<16, V>), grid, block, 0, stream, a, upp, ppp, mg);
 }
 
 static int g_gn_impl = 1;  // 1 = single-launch per-group kernel where the group slab fits, 0 = always stats/finalize/apply
@@ -369,6 +372,8 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     const int NT = wide ? 1024 : 256;
     a.tpp = a.cv < 256 ? a.cv : 256;
     a.pl = NT / a.tpp;
+    a.mg_tpp = udiv_magic_of(a.tpp);
+    a.mg_cpg = udiv_magic_of(C / 32);
     a.silu = q->silu ? 1 : 0; a.eps = q->eps;
     {
         // single-launch path: V = words per thread-unit (widest that divides the group's run), at most
