@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     // 1-D grid, XCD-aware: all query tiles of one (batch, head) run on one XCD so its K / V^T
     // (655 KB at S=4096, d=40) stay in that XCD's L2 instead of every XCD streaming all heads
     const int qtiles = (p.s + QT - 1) / QT;
-    const int wi = xcd_remap(blockIdx.x, gridDim.x);
+    const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);   // (= gridDim.x, without reading the implicit arguments)
     const int bh = udiv_magic(wi, qtiles, p.mg_qtiles);
     const int b = udiv_magic(bh, p.heads, p.mg_heads), h = bh - b * p.heads;
     const int q0 = (wi - bh * qtiles) * QT + wave * (16 * QF);

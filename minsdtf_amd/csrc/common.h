@@ -60,7 +60,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ int xcd_remap(int bid, int n) {
     const int xcd = bid & 7, loc = bid >> 3;
     const int q = n >> 3, r = n & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    return xcd * q + min(xcd, r) + loc;   // = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc, branch-free
 }
 
 // x / d for 0 <= x < 2^31 with magic = floor(2^32 / d) precomputed on the host: umulhi gives floor(x/d) or one less,

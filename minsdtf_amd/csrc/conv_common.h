@@ -9,6 +9,8 @@ struct CGArgs {
     const bf16_t* residual; void* out; bf16_t* out1; bf16_t* out2; float* ws;
     int batch, h_in, w_in, c0, c1, h_out, w_out, ksize, stride, pad, upsample;
     int M, N, K, hw_out, nkc, nk, nk_per, tiles_n;
+    int nslices;           // split-K slices (= gridDim.y; kept in the argument block so that no kernel reads the implicit
+                           // grid-size arguments: that is a second, dependent scalar-memory round trip at kernel start)
     int tiles_m, m_fast;   // m_fast: consecutive tiles (= same XCD) share the WEIGHT rows instead of the pixel rows
     int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
     int split_mode, ns0, ns1, out1_ld, out2_ld;
@@ -96,7 +98,7 @@ constexpr int LN_MAX_SLOTS = 20;   // row-moment partials per row (column tiles 
 template <int MI, int NJ>
 __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI], const int (&mrow)[MI], int nbase, int r, int g,
                                             float* lnred = nullptr, int wn = 0, int wgn = 1, int row0 = 0, int bm = 0, int tile_n = 0) {
-    if (gridDim.y > 1) {
+    if (p.nslices > 1) {
         float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {

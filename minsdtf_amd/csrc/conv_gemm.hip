@@ -67,7 +67,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     // so give each XCD a CONTIGUOUS run of tiles: neighbouring tiles re-read the same pixel rows
     // (9 taps, all n-tiles) and then hit that XCD's private 4 MiB L2 instead of the Infinity Cache.
     // Pure speed: any placement computes the same result.
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);   // (= gridDim.x)
     // which operand the XCD-contiguous run shares: the pixel rows (n fastest) when the activation
     // tensor is the bigger one, the weight rows (m fastest) for the weight-heavy small-M layers —
     // otherwise every XCD's L2 pulls its own copy of up to 59 MB of weights per layer
@@ -438,6 +438,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         a.nk_per = (a.nk + splitk - 1) / splitk;
     }
     const int slices = halo_th ? (a.nkc + a.nk_per - 1) / a.nk_per : (a.nk + a.nk_per - 1) / a.nk_per;
+    a.nslices = slices;
     if (slices > 1) {
         if (q->split_mode || q->act == MSD_ACT_GEGLU) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: split-K needs plain mode");
         if (!q->workspace || q->workspace_floats < (long long)slices * a.M * a.N)

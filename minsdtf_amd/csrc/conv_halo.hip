@@ -65,7 +65,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     // ---- which tile: (n tile, sample, tile row, tile column), XCD-aware order ------------------
     const int tiles_x = p.w_in / TW, tiles_y = p.h_in / TH;
     const int tps = tiles_x * tiles_y;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);   // (= gridDim.x)
     const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;   // divisions by host-prepared magic numbers
     const int tq = udiv_magic(tile, tdiv, p.mg_tdiv), tr = tile - tq * tdiv;
     const int tile_n = p.m_fast ? tq : tr;

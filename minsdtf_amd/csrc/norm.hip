@@ -15,6 +15,7 @@ struct GNArgs {
     int batch, hw, c0, c1, C, cv, tpp, pl, ppb, silu;
     float eps;
     uint32_t mg_tpp, mg_cpg;   // floor(2^32 / d) for d = tpp, C / 32 (udiv_magic: these launches are latency chains of scalar code)
+    int nchunks_stats;         // grid x of the statistics pass (kept here: reading gridDim costs a second kernarg round trip)
 };
 
 // NT threads per workgroup: 256, or 1024 for the mid-sized tensors (the UNet's 64x64 level) where a
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const GNArgs p) {
         float a = 0.f, q = 0.f;
         for (int c = t * cpg; c < (t + 1) * cpg; ++c) { a += chan[c * 2]; q += chan[c * 2 + 1]; }
         // per-workgroup partial moments; summed in a fixed order by gn_finalize_kernel (deterministic)
-        float* dst = p.partials + (((size_t)b * gridDim.x + blockIdx.x) * 32 + t) * 2;
+        float* dst = p.partials + (((size_t)b * p.nchunks_stats + blockIdx.x) * 32 + t) * 2;
         dst[0] = a;
         dst[1] = q;
     }
@@ -416,6 +417,7 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
         MSD_FAIL(MSD_E_WORKSPACE, "group_norm: partials scratch too small (%lld < %lld floats)",
                  (long long)q->partials_floats, (long long)q->batch * nchunks * 64);
     dim3 grid(nchunks, q->batch);
+    a.nchunks_stats = nchunks;
     const size_t lds = ((size_t)a.pl * C * 2 + (size_t)C * 2) * sizeof(float);
     if (wide) {
         static bool attr_done = false;
@@ -433,6 +435,7 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
             GNArgs as = a;
             as.ppb = ppb * 4 < q->hw ? ppb * 4 : q->hw;
             const int nchunks_s = (q->hw + as.ppb - 1) / as.ppb;
+            as.nchunks_stats = nchunks_s;
             hipLaunchKernelGGL((gn_stats_kernel<1, 1024>), dim3(nchunks_s, q->batch), dim3(1024), lds, stream, as);
             MSD_CHECK_LAUNCH();
             hipLaunchKernelGGL((gn_apply_kernel<1, true, 1024>), grid, dim3(1024), 0, stream, a, nchunks_s);
