@@ -95,7 +95,10 @@ constexpr int LN_MAX_SLOTS = 20;   // row-moment partials per row (column tiles 
 // `lnred` (with ln_out): LDS scratch of WGN x BM float2, free for reuse (the caller has passed a barrier after
 // its last fragment read); `wn` / `wgn`: this wave's column slab and the number of slabs; `row0`: first row
 // of the wave's tile inside the workgroup tile; `tile_n`: column tile index = the partial's slot.
-template <int MI, int NJ>
+// UB: every row of the workgroup's tile belongs to ONE sample (the spatial tiles of conv_halo), so the time-embedding
+// row is loaded once per column group instead of per (row fragment, column group): 48 fewer live registers on the
+// 64x64-per-wave tile, which otherwise spills.
+template <int MI, int NJ, bool UB = false>
 __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI], const int (&mrow)[MI], int nbase, int r, int g,
                                             float* lnred = nullptr, int wn = 0, int wgn = 1, int row0 = 0, int bm = 0, int tile_n = 0) {
     if (p.nslices > 1) {
@@ -210,7 +213,8 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
     }
     const bool plain_res = p.split_mode == 0 && p.residual != nullptr;
     uint2 rr[MI][NJ];
-    float4 rv[MI][NJ];
+    constexpr int RI = UB ? 1 : MI;
+    float4 rv[RI][NJ];
     int bidx[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) bidx[i] = (p.rowvec || p.split_mode) ? udiv_magic(min(mrow[i] + r, p.M - 1), p.hw_out, p.mg_hw) : 0;
@@ -230,14 +234,14 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
     }
     if (p.rowvec) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < RI; ++i) {
             const float* rvp = p.rowvec + (size_t)step * p.rv_step_stride + (size_t)bidx[i] * p.rv_batch_stride;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) rv[i][j] = *reinterpret_cast<const float4*>(rvp + min(nbase + j * 16 + 4 * g, p.N - 4));
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < RI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -261,10 +265,10 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
             for (int j = 0; j < NJ; ++j) {
                 const int n = nbase + j * 16 + 4 * g;
                 if (m >= p.M || n >= p.N) continue;
-                const float v0 = acc[j][i][0] + bv[j].x + rv[i][j].x + bf_lo(rr[i][j].x);
-                const float v1 = acc[j][i][1] + bv[j].y + rv[i][j].y + bf_hi(rr[i][j].x);
-                const float v2 = acc[j][i][2] + bv[j].z + rv[i][j].z + bf_lo(rr[i][j].y);
-                const float v3 = acc[j][i][3] + bv[j].w + rv[i][j].w + bf_hi(rr[i][j].y);
+                const float v0 = acc[j][i][0] + bv[j].x + rv[UB ? 0 : i][j].x + bf_lo(rr[i][j].x);
+                const float v1 = acc[j][i][1] + bv[j].y + rv[UB ? 0 : i][j].y + bf_hi(rr[i][j].x);
+                const float v2 = acc[j][i][2] + bv[j].z + rv[UB ? 0 : i][j].z + bf_lo(rr[i][j].y);
+                const float v3 = acc[j][i][3] + bv[j].w + rv[UB ? 0 : i][j].w + bf_hi(rr[i][j].y);
                 uint2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
                 if (p.ln_out) {   // moments of the ROUNDED values: what a LayerNorm reading `out` would see
@@ -284,8 +288,8 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
         for (int j = 0; j < NJ; ++j) {
             const int n = nbase + j * 16 + 4 * g;
             if (n >= p.N) continue;
-            float v[4] = {acc[j][i][0] + bv[j].x + rv[i][j].x, acc[j][i][1] + bv[j].y + rv[i][j].y,
-                          acc[j][i][2] + bv[j].z + rv[i][j].z, acc[j][i][3] + bv[j].w + rv[i][j].w};
+            float v[4] = {acc[j][i][0] + bv[j].x + rv[UB ? 0 : i][j].x, acc[j][i][1] + bv[j].y + rv[UB ? 0 : i][j].y,
+                          acc[j][i][2] + bv[j].z + rv[UB ? 0 : i][j].z, acc[j][i][3] + bv[j].w + rv[UB ? 0 : i][j].w};
             if (p.act == MSD_ACT_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);

@@ -83,48 +83,52 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     // ---- loader coordinates -----------------------------------------------------------------------
     const int cpos = tid & 7, lrow = tid >> 3;
     const char* zero = reinterpret_cast<const char*>(g_zero_page) + cpos * 16;
-    int hpix[HR], hsrc[HR];
+    // An out-of-image halo row reads the zero page: the select is mask arithmetic on the 64-bit address (32-bit offset
+    // from the tensor base), and the weight rows use scalar base + 32-bit offset with out-of-range rows clamped (their
+    // columns are never stored): no divergent branches in the loader (the ternary form made hipcc wrap every piece
+    // in an exec-mask branch).
+    int hpix[HR], hsrc[HR];   // pixel index of the staged halo row (-1: outside the image), swizzled source chunk (elements)
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
         const int hrow = lrow + RPP * i;
+        const int hy = hrow / HW_, hx = hrow - hy * HW_;
+        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+        const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+        // (coordinates clamped into the image instead of a conditional: no branch; `ok` only selects the sentinel)
+        const int pix = (b * p.h_in + min(max(iy, 0), p.h_in - 1)) * p.w_in + min(max(ix, 0), p.w_in - 1);
+        hpix[i] = ok ? pix : -1;
         hsrc[i] = (cpos ^ ((hrow >> 1) & 7)) * 8;
-        hpix[i] = -1;
-        if (hrow < HROWS) {
-            const int hy = hrow / HW_, hx = hrow - hy * HW_;
-            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-            if ((unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in) hpix[i] = (b * p.h_in + iy) * p.w_in + ix;
-        }
     }
-    const bf16_t* wsrc[BR];
+    uint32_t woff[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int row = lrow + RPP * i;
-        const int n = n0 + row;
-        wsrc[i] = (row < BN && n < p.N) ? (p.w + (size_t)n * p.K + (cpos ^ ((row >> 1) & 7)) * 8) : nullptr;
+        woff[i] = ((uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.K + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 8)) * 2u;
     }
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;   // this wave's 8 rows inside a DMA round
     const int cin = p.c0 + p.c1;
+    const uint64_t zaddr = (uint64_t)(reinterpret_cast<const char*>(g_zero_page) + cpos * 16);
 
     auto issue_halo = [&](int c, int buf) {
         const int ch = c * 64;
-        const bf16_t* src; int csrc, coff;
-        if (ch < p.c0) { src = p.a0; csrc = p.c0; coff = ch; } else { src = p.a1; csrc = p.c1; coff = ch - p.c0; }
+        const bool first = ch < p.c0;                                  // wave-uniform: which tensor of the concat
+        const uint64_t sb = (uint64_t)(first ? p.a0 : p.a1);
+        const int csrc = first ? p.c0 : p.c1, coff = first ? ch : ch - p.c0;
         const uint32_t base = lds_wave + (uint32_t)buf * H_BYTES;
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
-            const void* gp = (hpix[i] >= 0) ? static_cast<const void*>(src + (size_t)hpix[i] * csrc + coff + hsrc[i])
-                                            : static_cast<const void*>(zero);
-            dma16(gp, base + (uint32_t)(RPP * i) * 128u);
+            const uint32_t m32 = (uint32_t)(~hpix[i] >> 31);             // all ones for a pixel inside the image (hpix >= 0)
+            const uint64_t m64 = ((uint64_t)m32 << 32) | m32;
+            const uint32_t off = (uint32_t)(hpix[i] * csrc + coff + hsrc[i]) * 2u;
+            const uint64_t a = ((sb + off) & m64) | (zaddr & ~m64);
+            dma16(reinterpret_cast<const void*>(a), base + (uint32_t)(RPP * i) * 128u);
         }
     };
     auto issue_w = [&](int c, int tap, int stage) {
-        const size_t koff = (size_t)tap * cin + (size_t)c * 64;
+        const uint32_t koff = (uint32_t)(tap * cin + c * 64) * 2u;
         const uint32_t base = lds_wave + 2u * H_BYTES + (uint32_t)stage * W_BYTES;
 #pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const void* gp = wsrc[i] ? static_cast<const void*>(wsrc[i] + koff) : static_cast<const void*>(zero);
-            dma16(gp, base + (uint32_t)(RPP * i) * 128u);
-        }
+        for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + koff, base + (uint32_t)(RPP * i) * 128u);
     };
 
     f32x4 acc[NJ][MI];
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) mrow[i] = (b * p.h_in + ty0 + wm * MI + i) * p.w_in + tx0;
-    cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WNT, r, g);
+    cg_epilogue<MI, NJ, true>(p, acc, mrow, n0 + wn * WNT, r, g);   // (a spatial tile lies inside one sample)
 #ifdef MSD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MSD_STAMP(4);
