@@ -137,27 +137,30 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
             for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * 128u, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
             return;
         }
-        const int tap = kt / p.nkc;
+        // general form, branch-free: coordinates clamped into the image, an out-of-image tap selects the zero page by
+        // mask arithmetic on the 64-bit address; (tap, channel chunk) by a magic-number division; ky = tap / 3 as
+        // (tap * 11) >> 5 (exact for tap < 9; ksize 1 has tap 0)
+        const int tap = udiv_magic(kt, p.nkc, p.mg_nkc);
         const int c = (kt - tap * p.nkc) * 64;
-        const int ky = tap / p.ksize;
-        const int kx = tap - ky * p.ksize;
-        const bf16_t* src; int csrc, coff;
-        if (c < p.c0) { src = p.a0; csrc = p.c0; coff = c; } else { src = p.a1; csrc = p.c1; coff = c - p.c0; }
+        const int ky = (tap * 11) >> 5;
+        const int kx = tap - ky * 3;
+        const bool first = c < p.c0;
+        const uint64_t sb = (uint64_t)(first ? p.a0 : p.a1);
+        const int csrc = first ? p.c0 : p.c1, coff = first ? c : c - p.c0;
         const uint32_t sbase = lds_wave + (uint32_t)stage * ST_BYTES;
+        const uint64_t zaddr = (uint64_t)zero;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             int iy = ay[i] + ky, ix = ax[i] + kx;
-            const bool ok = ((unsigned)iy < (unsigned)Hl) && ((unsigned)ix < (unsigned)Wl);
+            const uint32_t m32 = (((unsigned)iy < (unsigned)Hl) && ((unsigned)ix < (unsigned)Wl)) ? 0xFFFFFFFFu : 0u;
+            iy = min(max(iy, 0), Hl - 1); ix = min(max(ix, 0), Wl - 1);
             if (p.upsample) { iy >>= 1; ix >>= 1; }
-            const void* gp = ok ? static_cast<const void*>(src + (size_t)(ab[i] + iy * p.w_in + ix) * csrc + coff + asrc[i])
-                                : static_cast<const void*>(zero);
-            dma16(gp, sbase + (uint32_t)(RPP * i) * 128u);
+            const uint32_t off = (uint32_t)((ab[i] + iy * p.w_in + ix) * csrc + coff + asrc[i]) * 2u;
+            const uint64_t m64 = ((uint64_t)m32 << 32) | m32;
+            dma16(reinterpret_cast<const void*>(((sb + off) & m64) | (zaddr & ~m64)), sbase + (uint32_t)(RPP * i) * 128u);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) {
-            const void* gp = wsrc[i] ? static_cast<const void*>(wsrc[i] + (size_t)kt * 64) : static_cast<const void*>(zero);
-            dma16(gp, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
-        }
+        for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * 128u, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
     };
 
     f32x4 acc[NJ][MI];
@@ -396,6 +399,11 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     const int cin = q->c0 + q->c1;
     a.K = q->ksize * q->ksize * cin;
     a.nkc = cin / 64;
+    a.mg_nkc = udiv_magic_of(a.nkc);
+    // the loaders address activations and weights with 32-bit byte offsets from the tensor bases
+    if ((long long)q->batch * q->h_in * q->w_in * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 >= (1ll << 32) - 4096 ||
+        (long long)q->N * q->ksize * q->ksize * cin * 2 >= (1ll << 32) - 4096)
+        MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: an operand of 4 GB or more");
     a.nk = q->ksize * q->ksize * a.nkc;
     a.act = q->act; a.out_f32 = (q->out_dtype == MSD_OUT_F32);
     a.out_ld = q->out_ld; a.res_ld = q->res_ld;

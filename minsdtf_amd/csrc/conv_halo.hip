@@ -82,7 +82,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
 
     // ---- loader coordinates -----------------------------------------------------------------------
     const int cpos = tid & 7, lrow = tid >> 3;
-    const char* zero = reinterpret_cast<const char*>(g_zero_page) + cpos * 16;
     // An out-of-image halo row reads the zero page: the select is mask arithmetic on the 64-bit address (32-bit offset
     // from the tensor base), and the weight rows use scalar base + 32-bit offset with out-of-range rows clamped (their
     // columns are never stored): no divergent branches in the loader (the ternary form made hipcc wrap every piece
