@@ -234,12 +234,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
 }
 
 // split-K: sum the fp32 slabs in slice order, then the same epilogue (plain mode only)
-__global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, int slices) {
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, int slices, uint32_t mg_nq) {
     const int nq = p.N >> 2;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)p.M * nq) return;
-    const int m = (int)(idx / nq);
-    const int n = (int)(idx - (long long)m * nq) * 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // (M * N / 4 < 2^31: checked on the host)
+    if (idx >= p.M * nq) return;
+    const int m = udiv_magic(idx, nq, mg_nq);         // (was a 64-bit division by a runtime value: ~100 instructions)
+    const int n = (idx - m * nq) * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     // 8 slab loads in flight per thread (a one-load-per-iteration loop pays a full memory round trip per slice:
     // 6 us for 12 slices of a 128 x 1280 layer); the adds keep the slice order, so the result is unchanged
@@ -451,6 +451,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.nslices = slices;
     if (slices > 1) {
         if (q->split_mode || q->act == MSD_ACT_GEGLU) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: split-K needs plain mode");
+        if ((long long)a.M * a.N / 4 >= (1ll << 31)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: split-K output too large");
         if (!q->workspace || q->workspace_floats < (long long)slices * a.M * a.N)
             MSD_FAIL(MSD_E_WORKSPACE, "conv_gemm: split-K workspace too small (%lld < %lld floats)",
                      (long long)q->workspace_floats, (long long)slices * a.M * a.N);
@@ -471,7 +472,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         MSD_CHECK_LAUNCH();
         if (slices > 1) {
             const long long quads = (long long)a.M * (a.N / 4);
-            hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices);
+            hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices, udiv_magic_of(a.N / 4));
             MSD_CHECK_LAUNCH();
         }
         return MSD_OK;
@@ -512,7 +513,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     MSD_CHECK_LAUNCH();
     if (slices > 1) {
         const long long quads = (long long)a.M * (a.N / 4);
-        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices);
+        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices, udiv_magic_of(a.N / 4));
         MSD_CHECK_LAUNCH();
     }
     return MSD_OK;
