@@ -15,19 +15,22 @@ struct CDArgs {
     int batch, in_batch_mod, h_in, w_in, c_in, h_out, w_out, c_out, ksize, stride, pad;
     int in_f32, out_dtype, act, act_in, ncg;
     long long total;
+    uint32_t mg_ncg, mg_hw, mg_w, mg_bmod;   // floor(2^32 / d) for ncg, h_out*w_out, w_out, in_batch_mod (udiv_magic; total < 2^31 checked)
     float in_scale;
 };
 
 template <int CG, bool IN_F32>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const CDArgs p) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= p.total) return;
-    const int cg = (int)(gid % p.ncg);
-    const long long pix = gid / p.ncg;
+    // (32-bit index math with host-prepared magic numbers: the 64-bit divisions by runtime values this replaced were
+    //  several hundred instructions per thread)
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int)p.total) return;
+    const int pix = udiv_magic(gid, p.ncg, p.mg_ncg);
+    const int cg = gid - pix * p.ncg;
     const int hw = p.h_out * p.w_out;
-    const int b = (int)(pix / hw);
-    const int rem = (int)(pix - (long long)b * hw);
-    const int y = rem / p.w_out, x = rem - y * p.w_out;
+    const int b = udiv_magic(pix, hw, p.mg_hw);
+    const int rem = pix - b * hw;
+    const int y = udiv_magic(rem, p.w_out, p.mg_w), x = rem - y * p.w_out;
     const int co = cg * CG;
     const bool full = (co + CG <= p.c_out);
 
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const CDArgs p) {
 #pragma unroll
     for (int k = 0; k < CG; ++k) acc[k] = (p.bias && co + k < p.c_out) ? p.bias[co + k] : 0.f;
 
-    const int bi = b % p.in_batch_mod;
+    const int bi = b - udiv_magic(b, p.in_batch_mod, p.mg_bmod) * p.in_batch_mod;
     for (int ky = 0; ky < p.ksize; ++ky) {
         const int iy = y * p.stride + ky - p.pad;
         if ((unsigned)iy >= (unsigned)p.h_in) continue;
@@ -100,15 +103,15 @@ __global__ __launch_bounds__(256) void conv_pix4_kernel(const CDArgs p) {
     }
     __syncthreads();
     const int sub = threadIdx.x & 3;
-    const long long pix = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
-    const long long npix = (long long)p.batch * p.h_out * p.w_out;
+    const int pix = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int npix = p.batch * p.h_out * p.w_out;
     const bool live = pix < npix;
-    const long long pc = live ? pix : npix - 1;  // keep all lanes in the shuffles
+    const int pc = live ? pix : npix - 1;  // keep all lanes in the shuffles
     const int hw = p.h_out * p.w_out;
-    const int b = (int)(pc / hw);
-    const int rem = (int)(pc - (long long)b * hw);
-    const int y = rem / p.w_out, x = rem - y * p.w_out;
-    const int bi = b % p.in_batch_mod;
+    const int b = udiv_magic(pc, hw, p.mg_hw);
+    const int rem = pc - b * hw;
+    const int y = udiv_magic(rem, p.w_out, p.mg_w), x = rem - y * p.w_out;
+    const int bi = b - udiv_magic(b, p.in_batch_mod, p.mg_bmod) * p.in_batch_mod;
     const int ncv = p.c_in >> 3;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int ky = 0; ky < p.ksize; ++ky) {
@@ -170,6 +173,10 @@ extern "C" int msd_conv_direct(const MsdConvDirect* q, msd_stream_t stream_) {
     a.h_out = q->h_out; a.w_out = q->w_out; a.c_out = q->c_out; a.ksize = q->ksize; a.stride = q->stride; a.pad = q->pad;
     a.in_f32 = q->in_dtype == MSD_OUT_F32; a.out_dtype = q->out_dtype; a.act = q->act; a.act_in = q->act_in ? 1 : 0;
     a.in_scale = q->in_scale;
+    a.mg_hw = udiv_magic_of(q->h_out * q->w_out); a.mg_w = udiv_magic_of(q->w_out); a.mg_bmod = udiv_magic_of(q->in_batch_mod);
+    a.mg_ncg = 0;
+    if ((long long)q->batch * q->h_out * q->w_out * ((q->c_out + 3) / 4) >= (1ll << 31))
+        MSD_FAIL(MSD_E_UNSUPPORTED, "conv_direct: more than 2^31 work items");
     const int cg = q->c_out <= 4 ? 4 : 8;
     {
         const long long nk = (long long)q->ksize * q->ksize * q->c_in;
@@ -182,6 +189,7 @@ extern "C" int msd_conv_direct(const MsdConvDirect* q, msd_stream_t stream_) {
         }
     }
     a.ncg = (q->c_out + cg - 1) / cg;
+    a.mg_ncg = udiv_magic_of(a.ncg);
     a.total = (long long)q->batch * q->h_out * q->w_out * a.ncg;
     const unsigned blocks = (unsigned)((a.total + 255) / 256);
     if (cg == 4) {
