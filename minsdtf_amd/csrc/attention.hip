@@ -82,13 +82,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         }
     }
 
-    // Retire the Q loads HERE: otherwise hipcc's wait for them lands on their first use inside the
-    // tile loop as vmcnt(0), which also drains the K/V prefetch issued just before it every iteration.
-#pragma unroll
-    for (int f = 0; f < QF; ++f)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[f][ks]));
-
     f32x4 oacc[DF][QF];
 #pragma unroll
     for (int df = 0; df < DF; ++df)
@@ -185,6 +178,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         gload(0);
         lstore(smem, smem + 64 * KROW, 0);
     }
+    // Retire the Q loads HERE, before the tile loop (otherwise hipcc's wait for them lands on their first use inside
+    // the loop as vmcnt(0), which also drains the K/V prefetch issued just before it every iteration) — but after the
+    // loads of K/V tile 0 were issued, so the two round trips overlap.
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[f][ks]));
     for (int tile = 0; tile < ntiles; ++tile) {
         const int t0 = tile * 64;
         const int buf = PIPE ? (tile & 1) : 0;
