@@ -68,20 +68,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         }
     }
 
-    bf16x8 qf[QF][KS];
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-        int qrow = q0 + f * 16 + r;
-        if (qrow > p.s - 1) qrow = p.s - 1;
-        const bf16_t* qp = p.q + ((size_t)b * p.s + qrow) * p.q_ld + h * D;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int d0 = ks * 32 + 8 * g;
-            if (d0 < D) qf[f][ks] = *reinterpret_cast<const bf16x8*>(qp + d0);
-            else qf[f][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    }
-
     f32x4 oacc[DF][QF];
 #pragma unroll
     for (int df = 0; df < DF; ++df)
@@ -173,8 +159,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         }
     };
 
+    if (PIPE) __syncthreads();  // zero fill done (a __syncthreads also waits for every outstanding load: keep it AHEAD of them)
+    // Q fragments and K/V tile 0: issued together, one memory round trip
+    bf16x8 qf[QF][KS];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        int qrow = q0 + f * 16 + r;
+        if (qrow > p.s - 1) qrow = p.s - 1;
+        const bf16_t* qp = p.q + ((size_t)b * p.s + qrow) * p.q_ld + h * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 32 + 8 * g;
+            if (d0 < D) qf[f][ks] = *reinterpret_cast<const bf16x8*>(qp + d0);
+            else qf[f][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
     if (PIPE) {
-        __syncthreads();  // zero fill done
         gload(0);
         lstore(smem, smem + 64 * KROW, 0);
     }
