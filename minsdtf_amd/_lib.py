@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 LIB_NAME = "libminsdtf_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
+LIB_PATH = os.environ.get("MSD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 ABI_VERSION = 4
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
