@@ -121,6 +121,13 @@ typedef struct MsdConvGemm {
     int32_t ln_in_slots;     /* 1..20 */
     int32_t ln_out_slots;    /* must equal ceil(N / tile_n) of this launch (msd_conv_gemm_ln_slots) */
     float ln_eps;
+    /* Shortcut operand (ResBlock, diffusion_model.py:36-38,50: conv2(h) + conv_shortcut(x) as ONE contraction): after the
+     * ksize*ksize*(c0+c1) taps of a0|a1, K continues with the channels of a2|a3 read at the OUTPUT pixel (a 1x1 tap);
+     * W rows are [taps of a0|a1 ... | channels of a2|a3], K = ksize*ksize*(c0+c1) + c2 + c3.  Needs stride 1, same-size
+     * output, c2 % 64 == 0, c3 % 64 == 0; runs on the general tile kernel (no halo tiles). */
+    const void* a2;          /* bf16 [batch][h_out][w_out][c2] or NULL */
+    const void* a3;          /* bf16 [batch][h_out][w_out][c3] or NULL (channel concat a2|a3) */
+    int32_t c2, c3;
 } MsdConvGemm;
 
 /* Number of row-moment partials per row a launch with these parameters writes to `ln_out`

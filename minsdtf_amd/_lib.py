@@ -35,6 +35,7 @@ class MsdConvGemm(C.Structure):
         ("out2_ld", C.c_int32), ("splitk", C.c_int32), ("tile_n", C.c_int32), ("tile_m", C.c_int32), ("stages", C.c_int32),
         ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_out", C.c_void_p),
         ("ln_in_slots", C.c_int32), ("ln_out_slots", C.c_int32), ("ln_eps", C.c_float),
+        ("a2", C.c_void_p), ("a3", C.c_void_p), ("c2", C.c_int32), ("c3", C.c_int32),
     ]
 
 

@@ -15,6 +15,7 @@ struct CGArgs {
     int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
     int split_mode, ns0, ns1, out1_ld, out2_ld;
     uint32_t mg_tdiv, mg_hw, mg_w, mg_tps, mg_tx, mg_nkc;   // floor(2^32 / d) for d = tile-mapping divisor, hw_out, w_out, tiles per sample, tiles per row (udiv_magic)
+    const bf16_t* a2; const bf16_t* a3; int c2, nk_main;         // shortcut operand: K tiles >= nk_main read a2|a3 at the output pixel
     const float* ln_in; const float* ln_colsum; float* ln_out;   // LayerNorm fold (minsdtf_hip.h)
     int ln_in_slots, ln_out_slots;
     float ln_eps, ln_inv_k;

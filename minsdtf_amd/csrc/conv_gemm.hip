@@ -140,13 +140,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         // general form, branch-free: coordinates clamped into the image, an out-of-image tap selects the zero page by
         // mask arithmetic on the 64-bit address; (tap, channel chunk) by a magic-number division; ky = tap / 3 as
         // (tap * 11) >> 5 (exact for tap < 9; ksize 1 has tap 0)
-        const int tap = udiv_magic(kt, p.nkc, p.mg_nkc);
-        const int c = (kt - tap * p.nkc) * 64;
-        const int ky = (tap * 11) >> 5;
-        const int kx = tap - ky * 3;
-        const bool first = c < p.c0;
-        const uint64_t sb = (uint64_t)(first ? p.a0 : p.a1);
-        const int csrc = first ? p.c0 : p.c1, coff = first ? c : c - p.c0;
+        // K tiles past the taps of a0|a1 (ResBlock shortcut folded into conv2): channels of a2|a3 at the output pixel,
+        // i.e. the centre tap (pad 1, stride 1) or the only tap (1x1)
+        const bool extra = kt >= p.nk_main;
+        const int tap = extra ? 0 : udiv_magic(kt, p.nkc, p.mg_nkc);
+        const int c = extra ? (kt - p.nk_main) * 64 : (kt - tap * p.nkc) * 64;
+        const int ky = extra ? p.pad : (tap * 11) >> 5;
+        const int kx = extra ? p.pad : tap - ky * 3;
+        const int cA = extra ? p.c2 : p.c0;
+        const bool first = c < cA;
+        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? p.a0 : p.a1));
+        const int csrc = first ? cA : (extra ? p.K - p.nk_main * 64 - p.c2 : p.c1), coff = first ? c : c - cA;
         const uint32_t sbase = lds_wave + (uint32_t)stage * ST_BYTES;
         const uint64_t zaddr = (uint64_t)zero;
 #pragma unroll
@@ -410,6 +414,17 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.rv_step_stride = q->rv_step_stride; a.rv_batch_stride = q->rv_batch_stride;
     a.split_mode = q->split_mode; a.ns0 = q->ns0; a.ns1 = q->ns1; a.out1_ld = q->out1_ld; a.out2_ld = q->out2_ld;
 
+    a.a2 = (const bf16_t*)q->a2; a.a3 = (const bf16_t*)q->a3; a.c2 = q->c2; a.nk_main = a.nk;
+    if (q->a2) {
+        if (q->c2 <= 0 || (q->c2 % 64) || q->c3 < 0 || (q->c3 % 64) || (q->c3 > 0 && !q->a3) || q->stride != 1 || q->upsample ||
+            q->h_out != q->h_in || q->w_out != q->w_in || !msd_aligned16(q->a2) || !msd_aligned16(q->a3))
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: shortcut operand needs stride 1, a same-size output and channel counts that are multiples of 64");
+        if ((long long)a.M * (q->c2 > q->c3 ? q->c2 : q->c3) * 2 >= (1ll << 32) - 4096) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: an operand of 4 GB or more");
+        a.K += q->c2 + q->c3;
+        a.nk += (q->c2 + q->c3) / 64;
+    } else if (q->c2 || q->c3 || q->a3) {
+        MSD_FAIL(MSD_E_ARG, "conv_gemm: c2 / c3 / a3 without a2");
+    }
     a.ln_in = q->ln_in; a.ln_colsum = q->ln_colsum; a.ln_out = q->ln_out;
     a.ln_in_slots = q->ln_in_slots; a.ln_out_slots = q->ln_out_slots; a.ln_eps = q->ln_eps;
     a.ln_inv_k = 1.0f / (float)a.K;
@@ -433,7 +448,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     int halo_th = 0;
     if (q->tile_m >= 1000) {
         const int th = (q->tile_m % 1000) / 16;   // 1128 / 1256: 8x16 / 16x16 pixels; 2128: 8x16 on 8 waves
-        const bool ok = q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
+        const bool ok = !q->a2 && q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
                         q->w_out == q->w_in && !q->upsample && (q->w_in % 16) == 0 &&
                         (long long)q->N * a.K * 2 < (1ll << 32) - 4096 &&   // 32-bit weight / activation byte offsets
                         (long long)a.M * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 < (1ll << 32) - 4096 &&
@@ -494,7 +509,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.mg_tps = a.mg_tx = 0;
     dim3 grid(tiles_m * a.tiles_n, slices);
     // 1x1 / Dense form: 32-bit byte offsets from the tensor bases
-    const bool dense = g_conv_dense && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in &&
+    const bool dense = g_conv_dense && !q->a2 && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in &&
                        (long long)a.M * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 < (1ll << 32) - 4096 &&
                        (long long)a.N * a.K * 2 < (1ll << 32) - 4096;
     switch (cfg) {

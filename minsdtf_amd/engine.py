@@ -15,6 +15,7 @@ Topology sources (reference, paths relative to stable_diffusion/):
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -228,6 +229,8 @@ LN_FOLD = True
 FF_PROJ_FOLD = True
 # UNet conv_out (320 -> 4, 3x3) on the MFMA path instead of the vector-FMA kernel
 MFMA_CONV_OUT = True
+# ResBlock with a 1x1 shortcut: conv2 and conv_shortcut as one GEMM (the shortcut's channels are extra K tiles)
+SHORTCUT_FOLD = os.environ.get("MSD_SHORTCUT_FOLD", "1") != "0"   # (env switch: same-box A/B runs)
 
 
 # ----------------------------------------------------------------------------- layer emitters
@@ -241,9 +244,10 @@ class Emitter:
     # conv / dense on the MFMA path; x may be a single Act or a (Act, Act) channel concat
     def conv(self, x, name, N, ksize=1, stride=1, upsample=False, act=ops.ACT_NONE, residual: Optional[Act] = None,
              rowvec=None, out_dtype=ops.OUT_BF16, bias=True, wkey=None, split=None, out: Optional[Act] = None,
-             asym_pad: bool = False, ln_out: bool = False, ln_in: Optional[tuple] = None) -> Act:
+             asym_pad: bool = False, ln_out: bool = False, ln_in: Optional[tuple] = None, extra=None) -> Act:
         """ln_out: also write the row-moment partials of the output (returned Act carries them in .ln);
-        ln_in = (buffer, slots): the input rows are LayerNormalized through the fold (weights <name>.lnw/.lncs/.lnb)."""
+        ln_in = (buffer, slots): the input rows are LayerNormalized through the fold (weights <name>.lnw/.lncs/.lnb).
+        extra: Act or (Act, Act) read at the output pixel as extra K tiles (ResBlock shortcut folded into conv2)."""
         p = self.p
         x0, x1 = (x if isinstance(x, tuple) else (x, None))
         cin = x0.C + (x1.C if x1 is not None else 0)
@@ -255,7 +259,10 @@ class Emitter:
         M = x0.B * ho * wo
         nk = ksize * ksize * (cin // 64)
         can_split = not (split is not None or act == ops.ACT_GEGLU)
-        tile_m, tile_n, sk, stages = tuning.lookup(x0.B, x0.H, x0.W, cin, N, ksize, stride, upsample, M, nk, can_split)
+        e0, e1 = (extra if isinstance(extra, tuple) else (extra, None))
+        cx = 0 if e0 is None else e0.C + (e1.C if e1 is not None else 0)
+        nk += cx // 64
+        tile_m, tile_n, sk, stages = tuning.lookup(x0.B, x0.H, x0.W, cin, N, ksize, stride, upsample, M, nk, can_split, cx)
         if ln_out or ln_in is not None:
             sk = 1   # the fold is plain-K only
         if sk > 1:
@@ -271,6 +278,8 @@ class Emitter:
                   workspace=p.ws if sk > 1 else None, workspace_floats=sk * M * N if sk > 1 else 0, splitk=sk,
                   tile_m=tile_m, tile_n=tile_n, stages=stages, pad=pad_lead, pad_end=pad_end,
                   step_ptr=self.step_ptr if rowvec is not None else None, name=name)
+        if e0 is not None:
+            kw.update(a2=e0.buf, c2=e0.C, a3=None if e1 is None else e1.buf, c3=0 if e1 is None else e1.C)
         if ln_in is not None:
             wn = wkey or name
             kw.update(w=self.W[wn + ".lnw"], bias=self.W[wn + ".lnb"], ln_in=ln_in[0], ln_in_slots=ln_in[1],
@@ -314,15 +323,20 @@ class Emitter:
         p.free(g1)
         g2 = self.group_norm(h, name + ".norm2", silu=True)
         p.free(h)
-        if cin != cout:
-            res = self.conv(x, name + ".conv_shortcut", cout, ksize=1)
+        if cin != cout and SHORTCUT_FOLD and (name + ".conv2sc.w") in self.W:
+            # conv2(h) + conv_shortcut(x) as ONE contraction: K = 9 C_out taps of g2, then the C_in channels of x
+            out = self.conv(g2, name + ".conv2sc", cout, ksize=3, extra=x)
+            p.free(g2)
         else:
-            assert not isinstance(x, tuple)
-            res = x0
-        out = self.conv(g2, name + ".conv2", cout, ksize=3, residual=res)
-        p.free(g2)
-        if res is not x0:
-            p.free(res)
+            if cin != cout:
+                res = self.conv(x, name + ".conv_shortcut", cout, ksize=1)
+            else:
+                assert not isinstance(x, tuple)
+                res = x0
+            out = self.conv(g2, name + ".conv2", cout, ksize=3, residual=res)
+            p.free(g2)
+            if res is not x0:
+                p.free(res)
         if free_input:
             for a in (x if isinstance(x, tuple) else (x,)):
                 p.free(a)

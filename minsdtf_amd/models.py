@@ -190,6 +190,19 @@ class HipModel:
             wcat = np.concatenate([w2d @ wpd, wpd], axis=0)                       # (4C + C, C) as (in, out)
             W[att + ".ffproj.w"] = packing.pack_dense(wcat.astype(np.float32), d)
             W[att + ".ffproj.b"] = packing.dev_f32((np.asarray(b2, np.float64) @ wpd + np.asarray(bp, np.float64)).astype(np.float32), d)
+        # ResBlock conv2 + conv_shortcut (diffusion_model.py:34-38,50) as one contraction: W = [conv2 taps | shortcut], b = b2 + bs
+        for n in names:
+            if not n.endswith(".conv_shortcut"):
+                continue
+            rb = n[: -len(".conv_shortcut")]
+            w2, b2 = get(rb + ".conv2", "conv_w"), get(rb + ".conv2", "bias")
+            ws, bs = get(n, "conv_w"), get(n, "bias")
+            if w2 is None or ws is None or w2.shape[0] != 3 or ws.shape[0] != 1 or ws.shape[2] % 64:
+                continue
+            t2 = torch.from_numpy(np.ascontiguousarray(w2)).permute(3, 0, 1, 2).reshape(w2.shape[3], -1)      # [N][9 C_out]
+            tsc = torch.from_numpy(np.ascontiguousarray(ws)).permute(3, 0, 1, 2).reshape(ws.shape[3], -1)     # [N][C_in]
+            W[rb + ".conv2sc.w"] = torch.cat([t2, tsc], dim=1).to(torch.bfloat16).contiguous().to(d)
+            W[rb + ".conv2sc.b"] = packing.dev_f32(np.asarray(b2, np.float32) + np.asarray(bs, np.float32), d)
         if tproj_w:
             W["time_emb_proj_cat.w"] = packing.dev_f32(np.concatenate(tproj_w, axis=1).reshape(1, 1, 1280, -1), d)
             W["time_emb_proj_cat.b"] = packing.dev_f32(np.concatenate(tproj_b), d)

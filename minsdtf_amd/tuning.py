@@ -26,8 +26,10 @@ HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (125
               (1128, 64, 8), (1128, 128, 6), (1128, 80, 8), (1256, 80, 5), (2128, 64, 0), (2128, 80, 0))
 
 
-def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=True) -> str:
-    return f"{batch}x{h_in}x{w_in}x{cin}->{N}k{ksize}s{stride}u{int(bool(upsample))}{'' if allow_split else 'n'}"
+def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=True, cx=0) -> str:
+    """cx: channels of the shortcut operand (extra K tiles at the output pixel), 0 = none."""
+    return (f"{batch}x{h_in}x{w_in}x{cin}->{N}k{ksize}s{stride}u{int(bool(upsample))}{'' if allow_split else 'n'}"
+            f"{'+x' + str(cx) if cx else ''}")
 
 
 def _load() -> Dict[str, list]:
@@ -54,8 +56,8 @@ def heuristic(M: int, N: int, nk: int, allow_split: bool) -> Tuple[int, int, int
     return bm, bn, sk, 0
 
 
-def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split) -> Tuple[int, int, int, int]:
-    ent = _load().get(shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split))
+def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split, cx=0) -> Tuple[int, int, int, int]:
+    ent = _load().get(shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split, cx))
     if ent is not None:
         bm, bn, sk = int(ent[0]), int(ent[1]), int(ent[2])
         stages = int(ent[3]) if len(ent) > 4 else 0   # [bm, bn, splitk, stages, us] (older tables: [bm, bn, splitk, us])

@@ -129,6 +129,42 @@ def test_conv_gemm(gpu, case):
     close(out.reshape(B, Ho, Wo, N), ref, what=str(case))
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=12, W=20, c=128, cx0=64, cx1=0, N=128, ks=3),                          # ResBlock conv2 + 1x1 shortcut, ragged M
+    dict(B=2, H=8, W=8, c=192, cx0=128, cx1=64, N=192, ks=3, splitk=3),                # shortcut over a concat, split-K across both parts
+    dict(B=1, H=16, W=16, c=64, cx0=64, cx1=0, N=320, ks=3, tile_m=64, tile_n=64),
+    dict(B=2, H=12, W=20, c=64, cx0=128, cx1=0, N=100, ks=1, tile_m=128, tile_n=64, stages=13),   # 1x1 main part
+])
+def test_conv_gemm_shortcut_operand(gpu, case):
+    """conv(h) + conv1x1(x) as one contraction (diffusion_model.py:34-38,50): K = taps of h, then the channels of x."""
+    from minsdtf_amd import ops
+
+    torch.manual_seed(21)
+    B, H, W, c, N, ks = case["B"], case["H"], case["W"], case["c"], case["N"], case["ks"]
+    cx0, cx1 = case["cx0"], case["cx1"]
+    cx = cx0 + cx1
+    h = bf(torch.randn(B, H, W, c))
+    x0 = bf(torch.randn(B, H, W, cx0))
+    x1 = bf(torch.randn(B, H, W, cx1)) if cx1 else None
+    w2 = bf(torch.randn(ks, ks, c, N) / math.sqrt(ks * ks * c))
+    wsc = bf(torch.randn(1, 1, cx, N) / math.sqrt(cx))
+    b2, bs = torch.randn(N), torch.randn(N)
+    xin = torch.cat([x0, x1], dim=-1) if cx1 else x0
+    ref = conv_ref(h, w2, b2, pad=1 if ks == 3 else 0) + conv_ref(xin, wsc, bs, pad=0)
+    d = gpu
+    wcat = torch.cat([w2.permute(3, 0, 1, 2).reshape(N, -1), wsc.permute(3, 0, 1, 2).reshape(N, -1)], dim=1).to(torch.bfloat16).contiguous().to(d)
+    M = B * H * W
+    sk = case.get("splitk", 1)
+    keep = [h.to(torch.bfloat16).to(d), x0.to(torch.bfloat16).to(d), x1.to(torch.bfloat16).to(d) if cx1 else None, (b2 + bs).to(d),
+            torch.empty(max(1, sk * M * N), dtype=torch.float32, device=d)]
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=d)
+    call = ops.conv_gemm(a0=keep[0], w=wcat, out=out, batch=B, h_in=H, w_in=W, c0=c, N=N, ksize=ks, bias=keep[3], a2=keep[1], c2=cx0,
+                         a3=keep[2], c3=cx1, workspace=keep[4], workspace_floats=keep[4].numel(), splitk=sk,
+                         tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0))
+    run_calls(call)
+    close(out.reshape(B, H, W, N), ref, what=str(case))
+
+
 def test_conv_gemm_geglu(gpu):
     from minsdtf_amd import ops, packing
 

@@ -26,8 +26,8 @@ def collect_shapes(quick=False):
     rec = []
     orig = tuning.lookup
 
-    def hook(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split):
-        rec.append((batch, h_in, w_in, cin, N, ksize, stride, bool(upsample), bool(allow_split)))
+    def hook(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split, cx=0):
+        rec.append((batch, h_in, w_in, cin, N, ksize, stride, bool(upsample), bool(allow_split), cx))
         return tuning.heuristic(M, N, nk, allow_split)
 
     tuning.lookup = hook
@@ -97,13 +97,14 @@ def collect_shapes(quick=False):
 def tune_one(shape, iters=10):
     from minsdtf_amd import ops, tuning
 
-    batch, h_in, w_in, cin, N, ks, stride, ups, allow_split = shape
+    batch, h_in, w_in, cin, N, ks, stride, ups, allow_split, cx = shape
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream()
     pad = 1 if ks == 3 else 0
     hl, wl = (2 * h_in, 2 * w_in) if ups else (h_in, w_in)
     ho, wo = (hl + 2 * pad - ks) // stride + 1, (wl + 2 * pad - ks) // stride + 1
-    M, K = batch * ho * wo, ks * ks * cin
+    M, K = batch * ho * wo, ks * ks * cin + cx
+    xx = torch.randn(batch, ho, wo, cx, device=dev).to(torch.bfloat16) if cx else None   # shortcut operand (extra K tiles)
     nk = K // 64
     x = torch.randn(batch, h_in, w_in, cin, device=dev).to(torch.bfloat16)
     wbytes = N * K * 2
@@ -114,7 +115,7 @@ def tune_one(shape, iters=10):
     best = None
     results = []
     cands = list(tuning.TILES)
-    if ks == 3 and stride == 1 and not ups and w_in % 16 == 0:  # halo-tile kernel (tile_m = 1000 + pixels per tile)
+    if ks == 3 and stride == 1 and not ups and w_in % 16 == 0 and not cx:  # halo-tile kernel (tile_m = 1000 + pixels per tile)
         cands += [t for t in tuning.HALO_TILES if h_in % ((t[0] % 1000) // 16) == 0]
     for (bm, bn, stg) in cands:
         if bm == 256 and M < 1024:
@@ -133,7 +134,7 @@ def tune_one(shape, iters=10):
             wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32) if sk > 1 else None
             calls = [ops.conv_gemm(a0=x, w=w, out=out, batch=batch, h_in=h_in, w_in=w_in, c0=cin, N=N, ksize=ks, stride=stride,
                                    upsample=ups, bias=bias, workspace=wsf, workspace_floats=0 if wsf is None else wsf.numel(),
-                                   splitk=sk, tile_m=bm, tile_n=bn, stages=stg) for w in ws_]
+                                   splitk=sk, tile_m=bm, tile_n=bn, stages=stg, a2=xx, c2=cx) for w in ws_]
             for c in calls[:2]:
                 c(st.cuda_stream)
             torch.cuda.synchronize()
