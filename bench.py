@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--controlnet", action="store_true", help="BASELINE config 5: ControlNet residuals every step")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="library A/B switch passed to msd_set_option (same-box comparisons), e.g. --opt attn_swp=0")
     ap.add_argument("--streams", type=int, default=0, help="1: cond+uncond as one batch-2B forward; 2: two HIP streams; 0: automatic")
     args = ap.parse_args()
 
@@ -61,6 +63,12 @@ def main():
     from minsdtf_amd import weights as Wt
     from minsdtf_amd.stable_diffusion import StableDiffusion
 
+    if args.opt:
+        from minsdtf_amd import _lib
+
+        for kv in args.opt:
+            k, v = kv.split("=")
+            _lib.check(_lib.load().msd_set_option(k.encode(), int(v)), f"msd_set_option({kv})")
     rank, local_rank, world = mdist.env_rank()
     if world != args.gpus:
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")

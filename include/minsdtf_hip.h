@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 4
+#define MSD_ABI_VERSION 5
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -222,6 +222,9 @@ typedef struct MsdAttention {
     int32_t q_ld, k_ld, vt_ld, o_ld;
     float scale;
     int32_t causal;
+    int32_t q_prescaled; /* != 0: q already carries the factor scale * log2(e) (folded into the weights of the projection that
+                            produced it, minsdtf_amd/models.py), so the kernel takes exp2 of q k^T directly; `scale` is then
+                            not applied again.  0: softmax(scale * q k^T) as written above. */
 } MsdAttention;
 
 int msd_attention(const MsdAttention* p, msd_stream_t stream);
@@ -279,9 +282,13 @@ typedef struct MsdCfgStep {
 
 int msd_cfg_step(const MsdCfgStep* p, msd_stream_t stream);
 
-/* msd_add_bf16 — out = a + b elementwise on bf16 (ControlNet residual adds,
- * diffusion_model.py:230-234). n % 8 == 0. */
+/* msd_add_bf16 — out = a + b elementwise on bf16. n % 8 == 0. */
 int msd_add_bf16(const void* a, const void* b, void* out, int64_t n, msd_stream_t stream);
+/* msd_add_f32_bf16 — out = bf16(a + b), a / out bf16, b fp32, summed in fp32 (may run in place, out == a).  The ControlNet
+ * residual adds of diffusion_model.py:230-234 when the 13 residuals arrive over the model boundary as fp32 arrays
+ * (DiffusionModel.predict_on_batch); the fused device loop has no such launch: there the adds are the epilogue residual of
+ * the ControlNet's own 1x1 "zero" convs (msd_conv_gemm with residual == out). n % 8 == 0. */
+int msd_add_f32_bf16(const void* a, const float* b, void* out, int64_t n, msd_stream_t stream);
 
 /* msd_cast_f32_to_bf16 / msd_cast_bf16_to_f32 — dtype conversion of a contiguous buffer. */
 int msd_cast_f32_to_bf16(const float* in, void* out, int64_t n, msd_stream_t stream);

@@ -12,7 +12,7 @@ import os
 LIB_NAME = "libminsdtf_hip.so"
 # $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
 LIB_PATH = os.environ.get("MSD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -63,7 +63,7 @@ class MsdAttention(C.Structure):
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
         ("batch", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("s", C.c_int32), ("t", C.c_int32),
         ("q_ld", C.c_int32), ("k_ld", C.c_int32), ("vt_ld", C.c_int32), ("o_ld", C.c_int32), ("scale", C.c_float),
-        ("causal", C.c_int32),
+        ("causal", C.c_int32), ("q_prescaled", C.c_int32),
     ]
 
 
@@ -97,6 +97,7 @@ SYMBOLS = {
                                     C.c_int32, C.c_void_p, C.c_void_p]),
     "msd_cfg_step": (C.c_int, [C.POINTER(MsdCfgStep), C.c_void_p]),
     "msd_add_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "msd_add_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "msd_cast_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "msd_cast_bf16_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }

@@ -26,14 +26,49 @@ struct AArgs {
     int batch, heads, s, t, q_ld, k_ld, vt_ld, o_ld;
     float sl2;  // scale * log2(e)
     int causal; // key index > query index is masked (CLIP text encoder, text_encoder.py:75-78)
-    int prio;   // raise the wave's priority inside the MFMA sections (pays when a SIMD holds 3+ waves)
+    int presc;  // q already carries scale * log2(e) (folded into the projection that produced it)
     uint32_t mg_qtiles, mg_heads;   // floor(2^32 / d) for the workgroup-id decomposition (udiv_magic)
 };
 
+// Maximum over the 4 lanes {l, l^16, l^32, l^48} (the four 16-lane rows of the wave), result on every lane: two
+// VALU row swaps (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips through the LDS crossbar
+// (each ~100+ cycles of latency in the middle of the softmax's dependency chain).  v_max via asm: fmaxf() on these
+// bit-cast values makes hipcc canonicalise both inputs first (two more VALU ops per step).
+__device__ __forceinline__ float rows_max4(float v) {
+    const uint32_t u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // a[0]: rows {0,0,2,2}, a[1]: rows {1,1,3,3}
+    float y;
+    asm("v_max_f32 %0, %1, %2\n\ts_nop 1" : "=v"(y) : "v"(a[0]), "v"(a[1]));   // (s_nop: VALU write -> v_permlane read)
+    const uint32_t w = __float_as_uint(y);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // b[0]: lower half everywhere, b[1]: upper half
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(b[0]), "v"(b[1]));
+    return y;
+}
+
+// Lazy rescaling (defer-max): the exponentials of a tile are taken against a REFERENCE maximum m_ref that is only moved
+// when a tile's maximum exceeds it by more than ATTN_THR (in exp2 units), so p <= 2^ATTN_THR instead of p <= 1.  bf16 / fp32
+// are floating point, so the relative precision of P, of the row sum and of O does not depend on that factor; what it
+// buys is that after the first tile the O-wide rescale (and its exp2) almost never runs, and that the per-tile code has
+// ONE rarely-taken wave-uniform branch instead of one taken-half-the-time branch per query block.  Tile 0 always takes
+// the branch (m_ref := the tile's maximum), which also guarantees a row sum >= 1.
+#define ATTN_THR 8.0f
+
 // QF = 16-query MFMA column blocks per wave: 2 (128 queries per workgroup) or 1 (64 queries per workgroup: twice the
 // workgroups — for launches whose 128-query grid leaves CUs idle or a SIMD with fewer than 3 waves).
-template <int D, bool PIPE, int QF = 2>
+// PRESC: q already carries scale * log2(e) (folded into the weights of the projection that produced it, see
+// MsdAttention.q_prescaled): the S^T accumulator chain then STARTS from -m_ref (MFMA C operand) and ends as the exp2
+// argument itself — no per-score fma.
+// NBUF = K/V tile buffers in LDS and with them the loop form:
+//   1  load tile -> store -> compute, two barriers per tile (d = 160: no registers left for a prefetch);
+//   2  tile t+1 is loaded to registers while tile t is computed and stored behind it, one barrier per tile;
+// (A software-pipelined form — the S^T MFMAs of tile t+1 issued between the exponentials of tile t, third LDS buffer, two
+//  accumulator sets — measured SLOWER: 102.8 vs 98.6 us at S = 4096 d = 40 batch 2, 434 vs 338 us at batch 8.  The loop is
+//  bound by the SIMD's instruction ISSUE, which both co-resident waves share and which an MFMA also occupies for 8 of its
+//  16 cycles: ~750 issue cycles per tile and wave, measured ~1600 per tile for the two waves of a SIMD; overlapping inside
+//  one wave adds registers (190 vs 152: one wave per SIMD fewer) and removes no instruction.)
+template <int D, int NBUF, int QF = 2, bool PRESC = false>
 __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
+    constexpr bool PIPE = NBUF == 2;
     constexpr int QT = 64 * QF;          // queries per workgroup
     constexpr int DPAD = ((D + 31) / 32) * 32;
     constexpr int KS = DPAD / 32;        // k-steps of QK^T
@@ -56,14 +91,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     const int q0 = (wi - bh * qtiles) * QT + wave * (16 * QF);
 
     // zero the whole LDS image once: pad columns / pad rows are never written afterwards
-    for (int off = tid * 16; off < (PIPE ? 2 : 1) * BUF_BYTES; off += 256 * 16)
+    for (int off = tid * 16; off < NBUF * BUF_BYTES; off += 256 * 16)
         *reinterpret_cast<uint4*>(smem + off) = make_uint4(0, 0, 0, 0);
 
     if (ONES_ROW) {
         __syncthreads();
         if (tid < 16) {  // 64 keys x bf16(1.0) in row D of each V^T buffer (never overwritten: tiles write rows < D)
 #pragma unroll
-            for (int bufi = 0; bufi < (PIPE ? 2 : 1); ++bufi)
+            for (int bufi = 0; bufi < NBUF; ++bufi)
                 *reinterpret_cast<uint2*>(smem + bufi * BUF_BYTES + 64 * KROW + D * VROW + tid * 8) = make_uint2(0x3F803F80u, 0x3F803F80u);
         }
     }
@@ -73,15 +108,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     for (int df = 0; df < DF; ++df)
 #pragma unroll
         for (int f = 0; f < QF; ++f) oacc[df][f] = (f32x4){0, 0, 0, 0};
-    float mrun[QF], lrun[QF];
+    float mref[QF], lrun[QF];   // reference maximum of the exponentials (raw-score units; PRESC: exp2 units), row sums
+    f32x4 negm[QF];             // PRESC: {-m_ref x 4}, the C operand that starts every S^T accumulator chain
 #pragma unroll
-    for (int f = 0; f < QF; ++f) { mrun[f] = -1e30f; lrun[f] = 0.f; }
+    for (int f = 0; f < QF; ++f) { mref[f] = 0.f; lrun[f] = 0.f; negm[f] = (f32x4){0, 0, 0, 0}; }
 
     const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
     const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
     const int ntiles = (p.t + 63) / 64;
 
-    // K / V^T tile staging: global -> registers (issued one tile ahead when PIPE) -> LDS.
+    // K / V^T tile staging: global -> registers (issued ahead when PIPE) -> LDS.
     // Per-thread source pointers / LDS offsets are fixed for the whole kernel; a full tile
     // (t0 + 64 <= t, i.e. every self-attention tile) takes a branch-free path, only a ragged last
     // tile (text context) pays for bounds checks and for zeroing the V^T padding columns.
@@ -132,7 +168,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
             }
         }
     };
-    auto lstore = [&](char* dK, char* dV, int t0) {
+    auto lstore = [&](char* dK, int t0) {
+        char* dV = dK + 64 * KROW;
 #pragma unroll
         for (int i = 0; i < KCH; ++i)
             if (kin[i]) *reinterpret_cast<uint4*>(dK + klds[i]) = rk[i];
@@ -177,7 +214,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 
     if (PIPE) {
         gload(0);
-        lstore(smem, smem + 64 * KROW, 0);
+        lstore(smem, 0);
     }
     // Retire the Q loads HERE, before the tile loop (otherwise hipcc's wait for them lands on their first use inside
     // the loop as vmcnt(0), which also drains the K/V prefetch issued just before it every iteration) — but after the
@@ -186,45 +223,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     for (int f = 0; f < QF; ++f)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[f][ks]));
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int t0 = tile * 64;
-        const int buf = PIPE ? (tile & 1) : 0;
-        char* sK = smem + buf * BUF_BYTES;
-        char* sV = sK + 64 * KROW;
-        if (PIPE) {
-            __syncthreads();  // tile `tile` staged by every wave; buffer buf^1 no longer read by anyone
-            if (tile + 1 < ntiles) gload(t0 + 64);  // next tile's loads fly while this tile is computed
-        } else {
-            __syncthreads();  // previous tile fully consumed (also orders the zero fill on the first pass)
-            gload(t0);
-            lstore(sK, sV, t0);
-            __syncthreads();
-        }
 
-        // ---- S^T = K Q^T ------------------------------------------------------------------
-        // (s_setprio: two waves share a SIMD; the one in an MFMA section goes first so the matrix core is fed while
-        //  the other wave's softmax VALU work fills the issue slots in between)
-        if (p.prio) __builtin_amdgcn_s_setprio(1);
-        f32x4 sacc[4][QF];
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-            for (int f = 0; f < QF; ++f) sacc[kf][f] = (f32x4){0, 0, 0, 0};
+    // ---- pieces of one 64-key tile --------------------------------------------------------------
+    // S^T block kf (16 keys x all queries of the wave) = K Q^T [- m_ref]
+    auto qk_block = [&](f32x4 (&s)[4][QF], const char* sK, int kf) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sK + (kf * 16 + r) * KROW + ks * 64 + g * 16);
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf) {
-                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sK + (kf * 16 + r) * KROW + ks * 64 + g * 16);
-#pragma unroll
-                for (int f = 0; f < QF; ++f)
-                    sacc[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[f][ks], sacc[kf][f], 0, 0, 0);
-            }
+            for (int f = 0; f < QF; ++f)
+                s[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    kfrag, qf[f][ks], ks == 0 ? (PRESC ? negm[f] : (f32x4){0, 0, 0, 0}) : s[kf][f], 0, 0, 0);
         }
-        if (p.prio) __builtin_amdgcn_s_setprio(0);
-        // ---- online softmax: lane holds keys t0 + kf*16 + 4g + e of query f*16 + r ----------
-        // Scores stay RAW (unscaled) in the accumulators: the running max is tracked on raw scores
-        // (scale > 0, so the max commutes with it) and the scale is folded into the exponent with
-        // one fma:  p = exp2(s*c - m*c),  c = scale*log2(e).  Per score: 1 fma + 1 exp + 1/2 max + 1/2 cvt.
+    };
+    // masks, tile maximum, and the (rare) move of the reference maximum.  Lane holds keys t0 + kf*16 + 4g + e of query
+    // f*16 + r.  generic: scores stay RAW in the accumulators, p = exp2(s*c - m_ref*c), c = scale*log2(e), one fma per
+    // score; PRESC: the accumulators already hold s*c - m_ref, p = exp2(acc).
+    auto tile_prepare = [&](f32x4 (&s)[4][QF], int tile) {
+        const int t0 = tile * 64;
         if (t0 + 64 > p.t) {  // ragged key tail (text context): only this tile pays for the masking
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                 for (int e = 0; e < 4; ++e)
                     if (t0 + kf * 16 + 4 * g + e >= p.t) {
 #pragma unroll
-                        for (int f = 0; f < QF; ++f) sacc[kf][f][e] = -1e30f;
+                        for (int f = 0; f < QF; ++f) s[kf][f][e] = -1e30f;
                     }
         }
         if (p.causal) {       // every query keeps key 0, so no row is ever fully masked
@@ -243,76 +259,112 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (t0 + kf * 16 + 4 * g + e > qi) sacc[kf][f][e] = -1e30f;
+                        if (t0 + kf * 16 + 4 * g + e > qi) s[kf][f][e] = -1e30f;
             }
         }
-        bf16x8 pb[2][QF];
+        // tile maximum per query: a v_max3 chain over the lane's 16 scores, then across the four 16-lane rows
+        float mx[QF];
+        bool need = tile == 0;
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
-            // linear max chain: every pair of scores folds into one v_max3_f32
-            float mx = fmaxf(sacc[0][f][0], sacc[0][f][1]);
-            mx = fmaxf(fmaxf(mx, sacc[0][f][2]), sacc[0][f][3]);
+            float m = fmaxf(s[0][f][0], s[0][f][1]);
+            m = fmaxf(fmaxf(m, s[0][f][2]), s[0][f][3]);
 #pragma unroll
             for (int kf = 1; kf < 4; ++kf) {
-                mx = fmaxf(fmaxf(mx, sacc[kf][f][0]), sacc[kf][f][1]);
-                mx = fmaxf(fmaxf(mx, sacc[kf][f][2]), sacc[kf][f][3]);
+                m = fmaxf(fmaxf(m, s[kf][f][0]), s[kf][f][1]);
+                m = fmaxf(fmaxf(m, s[kf][f][2]), s[kf][f][3]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[f], mx);
-            // After the first tiles the running maximum rarely moves: when it did not move for ANY query of the
-            // wave the rescale factor is exactly 1, so skip its exp2 and the DF x 4 multiplies of O.
-            const bool moved = __builtin_amdgcn_ballot_w64(mnew > mrun[f]) != 0;
-            float alpha = 1.0f;
-            if (moved) alpha = __builtin_amdgcn_exp2f((mrun[f] - mnew) * p.sl2);
-            mrun[f] = mnew;
-            const float nm = -mnew * p.sl2;
+            mx[f] = rows_max4(m);
+            need = need || (PRESC ? (mx[f] > ATTN_THR) : ((mx[f] - mref[f]) * p.sl2 > ATTN_THR));
+        }
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {   // wave-uniform; after the first tile: rare (see ATTN_THR)
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                float alpha;
+                if (PRESC) {
+                    const float delta = tile == 0 ? mx[f] : fmaxf(mx[f], 0.f);   // m_ref only grows after tile 0
+                    alpha = __builtin_amdgcn_exp2f(-delta);
+                    mref[f] += delta;
+                    negm[f] = (f32x4){-mref[f], -mref[f], -mref[f], -mref[f]};
+#pragma unroll
+                    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s[kf][f][e] -= delta;
+                } else {
+                    const float mnew = tile == 0 ? mx[f] : fmaxf(mref[f], mx[f]);
+                    alpha = __builtin_amdgcn_exp2f((mref[f] - mnew) * p.sl2);
+                    mref[f] = mnew;
+                }
+                if (tile != 0) {   // (tile 0: O and the row sum are still zero)
+                    lrun[f] *= alpha;
+#pragma unroll
+                    for (int df = 0; df < DF; ++df) {
+                        oacc[df][f][0] *= alpha; oacc[df][f][1] *= alpha; oacc[df][f][2] *= alpha; oacc[df][f][3] *= alpha;
+                    }
+                }
+            }
+        }
+    };
+    // exponentials of S^T block kf, in place
+    auto exp_block = [&](f32x4 (&s)[4][QF], int kf) {
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            const float nm = -mref[f] * p.sl2;
             float ls = 0.f;
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kf][f][e], p.sl2, nm));
-                    sacc[kf][f][e] = pv;
-                    if (!ONES_ROW) ls += pv;
-                }
-            if (!ONES_ROW) lrun[f] = lrun[f] * alpha + ls;
-            if (moved) {
-#pragma unroll
-                for (int df = 0; df < DF; ++df) {
-                    oacc[df][f][0] *= alpha; oacc[df][f][1] *= alpha; oacc[df][f][2] *= alpha; oacc[df][f][3] *= alpha;
-                }
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(PRESC ? s[kf][f][e] : fmaf(s[kf][f][e], p.sl2, nm));
+                s[kf][f][e] = pv;
+                if (!ONES_ROW) ls += pv;
             }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                union { bf16x8 v; uint32_t u[4]; } pk;
-                pk.u[0] = pack_bf2(sacc[2 * kk][f][0], sacc[2 * kk][f][1]);
-                pk.u[1] = pack_bf2(sacc[2 * kk][f][2], sacc[2 * kk][f][3]);
-                pk.u[2] = pack_bf2(sacc[2 * kk + 1][f][0], sacc[2 * kk + 1][f][1]);
-                pk.u[3] = pack_bf2(sacc[2 * kk + 1][f][2], sacc[2 * kk + 1][f][3]);
-                pb[kk][f] = pk.v;
-            }
+            if (!ONES_ROW) lrun[f] += ls;
         }
-        // ---- O^T += V^T P^T -----------------------------------------------------------------
-        if (p.prio) __builtin_amdgcn_s_setprio(1);
+    };
+    // O^T += V^T P^T over the 32 keys of S^T blocks 2kk, 2kk+1 (P packed to bf16 = the MFMA's B fragment)
+    auto pv_half = [&](f32x4 (&s)[4][QF], const char* sV, int kk) {
+        bf16x8 pb[QF];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            union { bf16x8 v; uint32_t u[4]; } pk;
+            pk.u[0] = pack_bf2(s[2 * kk][f][0], s[2 * kk][f][1]);
+            pk.u[1] = pack_bf2(s[2 * kk][f][2], s[2 * kk][f][3]);
+            pk.u[2] = pack_bf2(s[2 * kk + 1][f][0], s[2 * kk + 1][f][1]);
+            pk.u[3] = pack_bf2(s[2 * kk + 1][f][2], s[2 * kk + 1][f][3]);
+            pb[f] = pk.v;
+        }
 #pragma unroll
         for (int df = 0; df < DF; ++df) {
+            union { bf16x8 v; uint2 h2[2]; } vf;
+            const char* vp = sV + (df * 16 + r) * VROW + kk * 64 + g * 8;
+            vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
+            vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 32);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                union { bf16x8 v; uint2 h2[2]; } vf;
-                const char* vp = sV + (df * 16 + r) * VROW + kk * 64 + g * 8;
-                vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
-                vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 32);
+            for (int f = 0; f < QF; ++f)
+                oacc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[f], oacc[df][f], 0, 0, 0);
+        }
+    };
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int t0 = tile * 64;
+        char* sK = smem + (PIPE ? (tile & 1) : 0) * BUF_BYTES;
+        if (PIPE) {
+            __syncthreads();  // tile `tile` staged by every wave; the other buffer no longer read by anyone
+            if (tile + 1 < ntiles) gload(t0 + 64);  // next tile's loads fly while this tile is computed
+        } else {
+            __syncthreads();  // previous tile fully consumed (also orders the zero fill on the first pass)
+            gload(t0);
+            lstore(sK, t0);
+            __syncthreads();
+        }
+        f32x4 sacc[4][QF];
 #pragma unroll
-                for (int f = 0; f < QF; ++f)
-                    oacc[df][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[kk][f], oacc[df][f], 0, 0, 0);
-            }
-        }
-        if (p.prio) __builtin_amdgcn_s_setprio(0);
-        if (PIPE && tile + 1 < ntiles) {
-            char* nK = smem + (buf ^ 1) * BUF_BYTES;
-            lstore(nK, nK + 64 * KROW, t0 + 64);
-        }
+        for (int kf = 0; kf < 4; ++kf) qk_block(sacc, sK, kf);
+        tile_prepare(sacc, tile);
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) exp_block(sacc, kf);
+        pv_half(sacc, sK + 64 * KROW, 0);
+        pv_half(sacc, sK + 64 * KROW, 1);
+        if (PIPE && tile + 1 < ntiles) lstore(smem + ((tile & 1) ^ 1) * BUF_BYTES, t0 + 64);
     }
 
 #pragma unroll
@@ -346,45 +398,55 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     }
 }
 
+// ---- launch configuration ---------------------------------------------------------------------
 template <int D>
-static constexpr bool attn_pipe() { return D <= 80; }  // D=160 has no registers left for the prefetch
-template <int D>
+static constexpr int attn_nbuf() { return D <= 80 ? 2 : 1; }   // D = 160 has no registers left for the prefetch
+template <int D, int NBUF>
 static constexpr int attn_lds_bytes() {
-    return (attn_pipe<D>() ? 2 : 1) * (64 * (((D + 31) / 32) * 32 * 2 + 16) + ((D + 15) / 16) * 16 * (64 * 2 + 16));
+    return NBUF * (64 * (((D + 31) / 32) * 32 * 2 + 16) + ((D + 15) / 16) * 16 * (64 * 2 + 16));
 }
 
 static bool g_attn_attr_done = false;
 static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = queries per wave / 16 forced (A/B runs)
-static int g_attn_prio = -1;  // -1 = automatic, 0 / 1 forced
 void msd_set_attn_qf(int v) { g_attn_qf = v; }
-void msd_set_attn_prio(int v) { g_attn_prio = v; }
 
-template <int D, int QF>
+template <int D, int NBUF, int QF, bool PRESC>
+static hipError_t attn_attr1() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D, NBUF, QF, PRESC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<D, NBUF>());
+}
+template <int D>
 static hipError_t attn_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D, attn_pipe<D>(), QF>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<D>());
+    constexpr int NB = attn_nbuf<D>();
+    hipError_t e = attn_attr1<D, NB, 1, false>();
+    if (e == hipSuccess) e = attn_attr1<D, NB, 2, false>();
+    if (e == hipSuccess) e = attn_attr1<D, NB, 1, true>();
+    if (e == hipSuccess) e = attn_attr1<D, NB, 2, true>();
+    return e;
 }
 int msd_attention_init() {
     if (g_attn_attr_done) return MSD_OK;
-    hipError_t e = attn_attr<40, 2>();
-    if (e == hipSuccess) e = attn_attr<40, 1>();
-    if (e == hipSuccess) e = attn_attr<80, 2>();
-    if (e == hipSuccess) e = attn_attr<80, 1>();
-    if (e == hipSuccess) e = attn_attr<160, 2>();
-    if (e == hipSuccess) e = attn_attr<160, 1>();
-    if (e == hipSuccess) e = attn_attr<64, 2>();
-    if (e == hipSuccess) e = attn_attr<64, 1>();
+    hipError_t e = attn_attr<40>();
+    if (e == hipSuccess) e = attn_attr<80>();
+    if (e == hipSuccess) e = attn_attr<160>();
+    if (e == hipSuccess) e = attn_attr<64>();
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
     g_attn_attr_done = true;
     return MSD_OK;
 }
 
+template <int D, int NBUF, int QF>
+static void attn_launch2(const AArgs& a, dim3 grid, hipStream_t stream) {
+    constexpr int lds = attn_lds_bytes<D, NBUF>();
+    if (a.presc) hipLaunchKernelGGL((attention_kernel<D, NBUF, QF, true>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((attention_kernel<D, NBUF, QF, false>), grid, dim3(256), lds, stream, a);
+}
 template <int D>
 static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
     const int qt = 64 * qf;
-    dim3 grid(((a.s + qt - 1) / qt) * a.heads * a.batch);
-    if (qf == 1) hipLaunchKernelGGL((attention_kernel<D, attn_pipe<D>(), 1>), grid, dim3(256), attn_lds_bytes<D>(), stream, a);
-    else hipLaunchKernelGGL((attention_kernel<D, attn_pipe<D>(), 2>), grid, dim3(256), attn_lds_bytes<D>(), stream, a);
+    const dim3 grid(((a.s + qt - 1) / qt) * a.heads * a.batch);
+    if (qf == 1) attn_launch2<D, attn_nbuf<D>(), 1>(a, grid, stream);
+    else attn_launch2<D, attn_nbuf<D>(), 2>(a, grid, stream);
 }
 
 extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
@@ -406,15 +468,14 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     a.q_ld = q->q_ld; a.k_ld = q->k_ld; a.vt_ld = q->vt_ld; a.o_ld = q->o_ld;
     a.sl2 = q->scale * 1.4426950408889634f;
     a.causal = q->causal ? 1 : 0;
+    a.presc = q->q_prescaled ? 1 : 0;
     if (a.causal && q->s != q->t) MSD_FAIL(MSD_E_ARG, "attention: causal masking needs s == t");
     // Workgroup size in queries: 128, or 64 when the 128-query grid has fewer workgroups than ~1.5 x the CUs (S = 1024
     // and below at batch 2: 128 / 32 / 8 workgroups).  Measured on one box (us, 128 vs 64 queries per workgroup): S=4096
     // d=40 116 / 125; S=1024 d=80 35 / 28; S=256 d=160 17 / 13; S=4096 T=77 8.8 / 9.8; S=9216 525 / 584.
-    // s_setprio in the MFMA sections: 0-4 % either way; on (116 vs 121 us at S=4096, 389 vs 397 at batch 8).
     const long long wgs128 = (long long)((q->s + 127) / 128) * q->heads * q->batch;
     int qf = g_attn_qf ? g_attn_qf : (wgs128 < 384 ? 1 : 2);
     if (qf != 1) qf = 2;
-    a.prio = g_attn_prio >= 0 ? g_attn_prio : 1;
     a.mg_qtiles = udiv_magic_of((q->s + 64 * qf - 1) / (64 * qf));
     a.mg_heads = udiv_magic_of(q->heads);
     switch (q->head_dim) {

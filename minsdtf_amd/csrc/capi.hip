@@ -27,7 +27,6 @@ void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
 void msd_set_attn_qf(int v);
-void msd_set_attn_prio(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "gn_impl" (1 = single-launch per-group
  * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
 extern "C" int msd_set_option(const char* key, int value) {
@@ -37,10 +36,6 @@ extern "C" int msd_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "attn_qf") == 0) {     // 0 = automatic [default], 1 / 2 = 64 / 128 queries per workgroup
         msd_set_attn_qf(value);
-        return MSD_OK;
-    }
-    if (key && strcmp(key, "attn_prio") == 0) {   // -1 = automatic [default], 0 / 1 = s_setprio in the MFMA sections off / on
-        msd_set_attn_prio(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "gn_wide") == 0) {   // 1 = 1024-thread GroupNorm workgroups for mid-sized tensors [default]

@@ -425,6 +425,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     } else if (q->c2 || q->c3 || q->a3) {
         MSD_FAIL(MSD_E_ARG, "conv_gemm: c2 / c3 / a3 without a2");
     }
+    // (again, with the shortcut channels in K: the weight loader's 32-bit byte offsets are n * K * 2 + ...)
+    if ((long long)a.N * a.K * 2 >= (1ll << 32) - 4096) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: an operand of 4 GB or more");
     a.ln_in = q->ln_in; a.ln_colsum = q->ln_colsum; a.ln_out = q->ln_out;
     a.ln_in_slots = q->ln_in_slots; a.ln_out_slots = q->ln_out_slots; a.ln_eps = q->ln_eps;
     a.ln_inv_k = 1.0f / (float)a.K;

@@ -131,6 +131,17 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* a, const uin
         o[i] = pack8(fa);
     }
 }
+// out = bf16(a + b), a bf16, b fp32, summed in fp32 (8 elements per thread: one 16-byte and two 16-byte loads)
+__global__ __launch_bounds__(256) void add_f32_bf16_kernel(const uint4* a, const float4* b, uint4* o, long long nvec) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        float fa[8];
+        unpack8(a[i], fa);
+        const float4 b0 = b[2 * i], b1 = b[2 * i + 1];
+        fa[0] += b0.x; fa[1] += b0.y; fa[2] += b0.z; fa[3] += b0.w;
+        fa[4] += b1.x; fa[5] += b1.y; fa[6] += b1.z; fa[7] += b1.w;
+        o[i] = pack8(fa);
+    }
+}
 __global__ __launch_bounds__(256) void cast_f2b_kernel(const float* in, bf16_t* out, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = f2bf(in[i]);
 }
@@ -148,6 +159,14 @@ extern "C" int msd_add_bf16(const void* a, const void* b, void* out, int64_t n, 
     if (!msd_aligned16(a) || !msd_aligned16(b) || !msd_aligned16(out)) MSD_FAIL(MSD_E_ALIGN, "add_bf16: alignment");
     hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream_, (const uint4*)a,
                        (const uint4*)b, (uint4*)out, (long long)(n / 8));
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}
+extern "C" int msd_add_f32_bf16(const void* a, const float* b, void* out, int64_t n, msd_stream_t stream_) {
+    if (!a || !b || !out || n <= 0 || (n % 8)) MSD_FAIL(MSD_E_ARG, "add_f32_bf16: bad arguments");
+    if (!msd_aligned16(a) || !msd_aligned16(b) || !msd_aligned16(out)) MSD_FAIL(MSD_E_ALIGN, "add_f32_bf16: alignment");
+    hipLaunchKernelGGL(add_f32_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream_, (const uint4*)a,
+                       (const float4*)b, (uint4*)out, (long long)(n / 8));
     MSD_CHECK_LAUNCH();
     return MSD_OK;
 }

@@ -240,6 +240,7 @@ class Emitter:
 
     def __init__(self, plan: Plan, W: Dict[str, torch.Tensor], step_ptr=None):
         self.p, self.W, self.step_ptr = plan, W, step_ptr
+        plan.keep.append(W)   # the calls hold raw addresses of these tensors: the plan owns a reference to them
 
     # conv / dense on the MFMA path; x may be a single Act or a (Act, Act) channel concat
     def conv(self, x, name, N, ksize=1, stride=1, upsample=False, act=ops.ACT_NONE, residual: Optional[Act] = None,
@@ -366,7 +367,7 @@ class Emitter:
             p.free(n1)
         a1 = p.act(B, H, Wd, C)
         p.rec(ops.attention, q=q.buf, k=k.buf, vt=vt, out=a1.buf, batch=B, heads=heads, head_dim=d, s=S, t=S, q_ld=C,
-              k_ld=C, vt_ld=sp, o_ld=C, scale=d ** -0.5, name=tb + ".attn1")
+              k_ld=C, vt_ld=sp, o_ld=C, scale=d ** -0.5, q_prescaled=True, name=tb + ".attn1")
         p.free(q, k, vt)
         t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0, ln_out=fold)
         p.free(a1, t0)
@@ -381,7 +382,7 @@ class Emitter:
         kc, vtc, tp = ctx_kv[tb + ".attn2"]
         a2 = p.act(B, H, Wd, C)
         p.rec(ops.attention, q=q2.buf, k=kc, vt=vtc, out=a2.buf, batch=B, heads=heads, head_dim=d, s=S, t=ctx_len, q_ld=C,
-              k_ld=C, vt_ld=tp, o_ld=C, scale=d ** -0.5, name=tb + ".attn2")
+              k_ld=C, vt_ld=tp, o_ld=C, scale=d ** -0.5, q_prescaled=True, name=tb + ".attn2")
         p.free(q2)
         t2 = self.conv(a2, tb + ".attn2.to_out.0", C, residual=t1, ln_out=fold)
         p.free(a2, t1)
@@ -492,11 +493,19 @@ def _emit_encoder(e: Emitter, x: Act, temb_of, ctx_kv, ctx_len, outputs: List[Ac
 
 
 def emit_unet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w: int, temb, ctx_kv, ctx_len: int,
-              eps_out_f32, controls: Optional[List[Act]] = None) -> None:
+              eps_out_f32, controls=None, control_taps=None) -> None:
     """DiffusionModel graph (diffusion_model.py:184-279).
 
     latent_f32: fp32 [latent_batch_mod][h][w][4] (sample b reads row b % latent_batch_mod);
-    temb = (table, step_stride, batch_stride, {resblock: column}); eps_out_f32: fp32 [NB][h][w][4]."""
+    temb = (table, step_stride, batch_stride, {resblock: column}); eps_out_f32: fp32 [NB][h][w][4].
+    ControlNet residuals (diffusion_model.py:230-234: added to the 12 skips and to the mid-block output AFTER the down
+    path), two forms:
+      control_taps = (ControlNet emitter, its 13 feature maps from emit_controlnet_features): the fused device loop.  Each
+        residual is a 1x1 "zero conv" of a ControlNet feature map (control_net.py:92-106), so that conv runs HERE with the
+        skip as its epilogue residual and the skip's buffer as its output: skip += zero_conv(feature) in one launch, summed
+        in fp32 — the 13 elementwise adds do not exist;
+      controls = 13 fp32 buffers [NB][h_i][w_i][c_i] handed over the model boundary (predict_on_batch): one
+        add-and-round launch each."""
     p = e.p
     table, sstride, bstride, cols = temb
 
@@ -509,12 +518,17 @@ def emit_unet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w:
           out_dtype=ops.OUT_BF16, name="conv_in")
     outputs: List[Act] = [x]
     x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs)
-    if controls is not None:  # diffusion_model.py:230-234, after the down path is complete
+    if control_taps is not None:
+        e_c, feats = control_taps
+        assert len(outputs) == 12 and len(feats) == 13
+        for i, (o, f) in enumerate(zip(outputs + [x], feats)):
+            assert (o.B, o.H, o.W, o.C) == (f.B, f.H, f.W, f.C)
+            e_c.conv(f, f"zero_convs.{i}", o.C, ksize=1, residual=o, out=o)
+            p.free(f)
+    elif controls is not None:
         assert len(outputs) == 12 and len(controls) == 13
-        p.rec(ops.add_bf16, a=x.buf, b=controls[12].buf, out=x.buf, n=x.M * x.C, name="control.12")
-        for i, (o, c) in enumerate(zip(outputs, controls[:12])):
-            assert (o.B, o.H, o.W, o.C) == (c.B, c.H, c.W, c.C)
-            p.rec(ops.add_bf16, a=o.buf, b=c.buf, out=o.buf, n=o.M * o.C, name=f"control.{i}")
+        for i, (o, c) in enumerate(zip(outputs + [x], controls)):
+            p.rec(ops.add_f32_bf16, a=o.buf, b=c, out=o.buf, n=o.M * o.C, name=f"control.{i}")
     for ui, lvl in enumerate((3, 2, 1, 0)):
         ch = wtab.UNET_CH[lvl]
         for r in range(3):
@@ -539,9 +553,10 @@ def emit_unet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w:
     p.free(g)
 
 
-def emit_controlnet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w: int, temb, ctx_kv, ctx_len: int,
-                    hint: Act, outs: List[Act]) -> None:
-    """ControlNet (control_net.py:45-107): conv_in(latent)+hint, encoder, 13 1x1 'zero' convs."""
+def emit_controlnet_features(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w: int, temb, ctx_kv, ctx_len: int,
+                             hint: Act) -> List[Act]:
+    """ControlNet (control_net.py:45-90) up to its 13 taps: conv_in(latent)+hint and the encoder.  The taps' 1x1 zero
+    convs are emitted by the consumer (emit_unet: fused with the residual adds) or by emit_controlnet."""
     p = e.p
     table, sstride, bstride, cols = temb
 
@@ -555,7 +570,16 @@ def emit_controlnet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: i
     outputs: List[Act] = [x]
     x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs)
     outputs.append(x)
-    assert len(outputs) == 13 and len(outs) == 13
+    assert len(outputs) == 13
+    return outputs
+
+
+def emit_controlnet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w: int, temb, ctx_kv, ctx_len: int,
+                    hint: Act, outs: List[Act]) -> None:
+    """ControlNet (control_net.py:45-107): conv_in(latent)+hint, encoder, 13 1x1 'zero' convs."""
+    p = e.p
+    outputs = emit_controlnet_features(e, latent_f32, latent_batch_mod, NB, h, w, temb, ctx_kv, ctx_len, hint)
+    assert len(outs) == 13
     for i, (o, dst) in enumerate(zip(outputs, outs)):
         e.conv(o, f"zero_convs.{i}", o.C, ksize=1, out=dst)
     for o in outputs:

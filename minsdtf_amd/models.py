@@ -55,6 +55,16 @@ _DIRECT = {
 } | {f"input_hint_block.{i}" for i in range(7)}
 
 
+UNET_HEADS = 8   # CrossAttention(num_heads=8) everywhere in the UNet / ControlNet (diffusion_model.py:60-65)
+
+
+def _q_prescale(c_out: int) -> np.float32:
+    """Factor folded into the UNet's query projections (attn1.to_q, attn2.to_q) at pack time: the attention scale
+    head_size**-0.5 (diffusion_model.py:105,123) times log2(e), so the attention kernel takes exp2 of q k^T directly
+    (MsdAttention.q_prescaled).  Exact up to the bf16 rounding of the weights, which happens once either way."""
+    return np.float32((c_out // UNET_HEADS) ** -0.5 * 1.4426950408889634)
+
+
 class HipModel:
     kind = ""  # weight-table kind
 
@@ -69,6 +79,9 @@ class HipModel:
         self._W: Optional[Dict[str, torch.Tensor]] = None
         self._plans: Dict[tuple, "_BoundPlan"] = {}
         self._use_graph = False
+        # bumped by every set_weights(): launch plans hold raw device addresses of the packed weights, so whatever caches
+        # a plan built on this model (its own _plans, StableDiffusion._engines) keys on it
+        self.weights_version = 0
 
     def _table_kw(self) -> dict:
         return {}
@@ -93,6 +106,16 @@ class HipModel:
                 raise ValueError(f"{self.name}: {s.name} has shape {a.shape}, expected {s.shape}")
             named[(s.name, s.kind)] = a
         self._W = self._pack(named)
+        self.weights_version += 1
+        self._plans.clear()
+
+    def share_weights(self, other: "HipModel") -> None:
+        """Use `other`'s packed device weights (same network kind, e.g. one checkpoint served at two image sizes):
+        no second copy in HBM, no second packing pass."""
+        if type(other) is not type(self) or other._W is None:
+            raise ValueError(f"{self.name}: share_weights needs a loaded model of the same kind")
+        self._W = other._W
+        self.weights_version += 1
         self._plans.clear()
 
     def load_synthetic(self, seed=0, bias_scale=0.0) -> List[np.ndarray]:
@@ -149,8 +172,12 @@ class HipModel:
         for n in names:
             if n.endswith(".attn1.to_q"):
                 base = n[: -len(".to_q")]
+                wq = get(base + ".to_q", "dense_w")
                 W[base + ".qkv.w"] = packing.pack_dense_stack(
-                    [get(base + ".to_q", "dense_w"), get(base + ".to_k", "dense_w"), get(base + ".to_v", "dense_w")], d)
+                    [wq * _q_prescale(wq.shape[1]), get(base + ".to_k", "dense_w"), get(base + ".to_v", "dense_w")], d)
+            elif n.endswith(".attn2.to_q"):   # (the generic branch above packed it unscaled)
+                wq = get(n, "dense_w")
+                W[n + ".w"] = packing.pack_dense(wq * _q_prescale(wq.shape[1]), d)
             elif n.endswith(".attn2.to_k"):
                 base = n[: -len(".to_k")]
                 W[base + ".kv.w"] = packing.pack_dense_stack([get(base + ".to_k", "dense_w"), get(base + ".to_v", "dense_w")], d)
@@ -166,11 +193,13 @@ class HipModel:
                 continue
             tb = n[: -len(".norm1")]
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).t().contiguous()  # noqa: E731  (in,out) -> [out][in]
-            qkv = torch.cat([t(get(tb + ".attn1." + k, "dense_w")) for k in ("to_q", "to_k", "to_v")], dim=0)
+            cq = _q_prescale(get(tb + ".attn1.to_q", "dense_w").shape[1])
+            qkv = torch.cat([t(get(tb + ".attn1." + k, "dense_w")) * (cq if k == "to_q" else 1.0) for k in ("to_q", "to_k", "to_v")],
+                            dim=0)
             W[tb + ".attn1.qkv.lnw"], W[tb + ".attn1.qkv.lncs"], W[tb + ".attn1.qkv.lnb"] = packing.fold_layer_norm(
                 qkv, None, get(tb + ".norm1", "gamma"), get(tb + ".norm1", "beta"), d)
             W[tb + ".attn2.to_q.lnw"], W[tb + ".attn2.to_q.lncs"], W[tb + ".attn2.to_q.lnb"] = packing.fold_layer_norm(
-                t(get(tb + ".attn2.to_q", "dense_w")), None, get(tb + ".norm2", "gamma"), get(tb + ".norm2", "beta"), d)
+                t(get(tb + ".attn2.to_q", "dense_w")) * cq, None, get(tb + ".norm2", "gamma"), get(tb + ".norm2", "beta"), d)
             gw, gb = get(tb + ".ff.net.0.proj", "dense_w"), get(tb + ".ff.net.0.proj", "bias")
             order = packing.geglu_row_order(gw.shape[1] // 2)
             W[tb + ".ff.net.0.proj.lnw"], W[tb + ".ff.net.0.proj.lncs"], W[tb + ".ff.net.0.proj.lnb"] = packing.fold_layer_norm(
@@ -286,15 +315,13 @@ class DiffusionModel(HipModel):
         table = plan.alloc(B * total * 4)
         engine.emit_time_embedding(e, ins["t_emb"], B, table, encoder_only=False)
         controls, cstage = None, []
-        if with_controls:
+        if with_controls:   # fp32 staging buffers; emit_unet adds them to the skips in fp32 (one add-and-round launch each)
             controls = []
             for i, ch in enumerate(wtab.UNET_SKIP_CH + (1280,)):
                 hh, ww = _skip_hw(i, h, w)
                 st = plan.alloc(B * hh * ww * ch * 4)
-                a = plan.act(B, hh, ww, ch)
-                plan.rec(ops.cast_f32_to_bf16, x=st, out=a.buf, n=B * hh * ww * ch, name=f"control.{i}.bf16")
                 cstage.append((st, (B, hh, ww, ch)))
-                controls.append(a)
+                controls.append(st)
         eps = plan.alloc(B * h * w * 4 * 4)
         engine.emit_unet(e, ins["latent"], B, B, h, w, (table, 0, total, cols), ctx_kv, T, eps, controls)
         plan.finalize()

@@ -129,13 +129,14 @@ def layer_norm(*, x, gamma, beta, out, rows, c, eps=1e-5, name="layer_norm") -> 
 
 
 def attention(*, q, k, vt, out, batch, heads, head_dim, s, t, q_ld, k_ld, vt_ld, o_ld, scale, causal=False,
-              name="attention") -> Call:
+              q_prescaled=False, name="attention") -> Call:
     lib = _lib.load()
     a = _lib.MsdAttention()
     a.q, a.k, a.vt, a.out = _p(q), _p(k), _p(vt), _p(out)
     a.batch, a.heads, a.head_dim, a.s, a.t = batch, heads, head_dim, s, t
     a.q_ld, a.k_ld, a.vt_ld, a.o_ld, a.scale = q_ld, k_ld, vt_ld, o_ld, float(scale)
     a.causal = int(bool(causal))
+    a.q_prescaled = int(bool(q_prescaled))
     return Call(lib.msd_attention, (C.byref(a),), name, keep=a)
 
 
@@ -160,6 +161,11 @@ def cfg_step(*, eps, latent, coef, step_ptr, batch, n, num_steps, guidance, guid
 def add_bf16(*, a, b, out, n, name="add_bf16") -> Call:
     lib = _lib.load()
     return Call(lib.msd_add_bf16, (_p(a), _p(b), _p(out), n), name)
+
+
+def add_f32_bf16(*, a, b, out, n, name="add_f32_bf16") -> Call:
+    lib = _lib.load()
+    return Call(lib.msd_add_f32_bf16, (_p(a), _p(b), _p(out), n), name)
 
 
 def cast_f32_to_bf16(*, x, out, n, name="cast_f2b") -> Call:

@@ -146,16 +146,16 @@ class DenoiseEngine:
                 self.branches.append(step)
                 s_u = engine.Emitter(step, unet._W, step_ptr=self.step_ptr)
                 s_c = engine.Emitter(step, control_net._W, step_ptr=self.step_ptr) if self.has_control else None
-            controls = None
+            taps = None
             if self.has_control:
-                controls = [step.act(nb, *_skip_hw(i, h, w), ch) for i, ch in enumerate(wtab.UNET_SKIP_CH + (1280,))]
+                # ControlNet encoder first; its 13 zero convs run inside the UNet plan, fused with the residual adds
                 hint_nb = engine.Act(hint_act.buf, nb, h, w, 320)  # first nb rows of the tiled hint
-                engine.emit_controlnet(s_c, self.latent, B, nb, h, w, (table_c, total_c, 0, cols_c), ctx_kv_c[tag], t,
-                                       hint_nb, controls)
+                feats = engine.emit_controlnet_features(s_c, self.latent, B, nb, h, w, (table_c, total_c, 0, cols_c), ctx_kv_c[tag], t,
+                                                        hint_nb)
+                taps = (s_c, feats)
             eps_view = _Ptr(self.eps.data_ptr() + row0 * n * 4)
-            engine.emit_unet(s_u, self.latent, B, nb, h, w, (table_u, total_u, 0, cols_u), ctx_kv_u[tag], t, eps_view, controls)
-            if controls is not None:
-                step.free(*controls)
+            engine.emit_unet(s_u, self.latent, B, nb, h, w, (table_u, total_u, 0, cols_u), ctx_kv_u[tag], t, eps_view,
+                             control_taps=taps)
         tail = engine.Plan(dev) if self.dual else step
         # inpainting (reference :469-475): the blend with the re-noised encoded image is part of the sampler kernel
         self.inpaint = None
@@ -239,6 +239,7 @@ class DenoiseEngine:
             for i in range(count):
                 self._one_step(st)
                 if callback is not None:
+                    st.synchronize()   # callback(iteration) fires after the step has finished, like the reference's
                     callback(i + 1)
             return
         if callback is None:
@@ -254,8 +255,13 @@ class DenoiseEngine:
         if self._step_graph is None:
             self._warm()
             self._step_graph = self._capture(self._one_step)
+        # the reference calls callback(iteration) after the step has FINISHED (stable_diffusion.py:476-479): progress
+        # bars and cancellation rely on that, so wait for each replay before reporting it
+        done = torch.cuda.Event()
         for i in range(count):
             self._step_graph.replay()
+            done.record()
+            done.synchronize()
             callback(i + 1)
 
     def prepare(self, contexts: Dict[str, np.ndarray], noise: np.ndarray, scheduler: Scheduler, timesteps,
@@ -266,7 +272,13 @@ class DenoiseEngine:
             init, ip_noise, mask = inpaint
             self.inpaint["init"].copy_(torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32).reshape(-1)))
             self.inpaint["noise"].copy_(torch.from_numpy(np.ascontiguousarray(ip_noise, dtype=np.float32).reshape(self.B, -1)))
-            m = np.asarray(mask, dtype=np.float32).reshape(self.h, self.w, 1)
+            m = np.asarray(mask, dtype=np.float32)
+            # preprocessed_mask keeps the reference's (width//8, height//8) resize (:301), which is only the latent's
+            # (h, w) for square images; the reference's blend then fails to broadcast — fail the same way, loudly
+            if m.shape[:2] != (self.h, self.w):
+                raise ValueError(f"latent mask has shape {m.shape[:2]}, the latent is {(self.h, self.w)} "
+                                 "(the reference's mask resize swaps width and height: non-square inpainting is unsupported)")
+            m = m.reshape(self.h, self.w, 1)
             self.inpaint["mask"].copy_(torch.from_numpy(np.ascontiguousarray(np.broadcast_to(m, (self.h, self.w, 4))).reshape(-1)))
         for tag, arr in contexts.items():
             self.ctx_in[tag].copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)))
@@ -605,7 +617,11 @@ class StableDiffusionBase:
         return self.image_decoder.decode_to_uint8(eng.latent).cpu().numpy()
 
     def _engine(self, B, tc, tu, steps, g, phi, control, inpaint=False) -> DenoiseEngine:
-        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams, inpaint, self.active_tcd)
+        # the engine's plans (and captured hipGraphs) hold raw addresses of the packed weights: a set_weights() /
+        # load_synthetic() / LoRA reload on any of the models it was built from must retire it
+        wver = (self.diffusion_model.weights_version,) + ((self.control_net.weights_version, self.hint_net.weights_version)
+                                                           if control else ())
+        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams, inpaint, self.active_tcd, wver)
         eng = self._engines.get(key)
         if eng is None:
             eng = DenoiseEngine(self.diffusion_model, B, tc, tu, steps, g, phi,

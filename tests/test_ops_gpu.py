@@ -420,9 +420,15 @@ def test_layer_norm(gpu, rows, c):
     dict(B=2, H=8, d=160, S=256, T=154),     # long prompt (2 x 77)
     dict(B=1, H=2, d=40, S=72, T=72),        # ragged queries
     dict(B=1, H=8, d=80, S=256, T=256, spike=True),  # forces online-softmax rescales
+    dict(B=1, H=4, d=40, S=200, T=520, spike=True),  # ... with a ragged last tile, d = 40 (ones-row denominator)
+    dict(B=1, H=2, d=160, S=64, T=320, spike=True, ramp=True),  # reference maximum creeps up below the threshold, then jumps
 ])
 @pytest.mark.parametrize("qf", [2, 1])   # 128 / 64 queries per workgroup (the library picks by grid size; both forced here)
-def test_attention(gpu, case, qf):
+@pytest.mark.parametrize("presc", [False, True])   # q carrying scale*log2(e) already (the UNet's projections) or not
+def test_attention(gpu, case, qf, presc):
+    """The lazy rescale (attention.hip ATTN_THR) is a rare data-dependent branch: the `spike` cases force it at chosen
+    tiles (one key row scaled so the tile maximum jumps far past the threshold), `ramp` makes the maximum grow by
+    less than the threshold over several tiles first (the deferred path), and the reference is the full fp32 softmax."""
     from minsdtf_amd import _lib, ops
 
     torch.manual_seed(7)
@@ -430,15 +436,23 @@ def test_attention(gpu, case, qf):
     C = H * d
     Tp = (T + 7) // 8 * 8
     q, k, v = bf(torch.randn(B, S, C)), bf(torch.randn(B, T, C)), bf(torch.randn(B, T, C))
+    if case.get("ramp"):
+        k *= (1.0 + 0.5 * torch.arange(T).float() / T)[None, :, None]
     if case.get("spike"):
         # later keys score far higher than earlier ones for some queries -> the running max jumps
         k[:, T // 2 + 3] *= 6.0
         k[:, T - 5] *= 12.0
+        k = bf(k)
     scale = d ** -0.5
+    if presc:   # what the prescaled projection delivers: bf16(q * scale * log2 e); the kernel computes exp2(q' k^T)
+        q = bf(q * (scale * 1.4426950408889634))
+        score_scale = math.log(2.0)
+    else:
+        score_scale = scale
     qh = q.view(B, S, H, d).permute(0, 2, 1, 3)
     kh = k.view(B, T, H, d).permute(0, 2, 1, 3)
     vh = v.view(B, T, H, d).permute(0, 2, 1, 3)
-    ref = (torch.softmax((qh @ kh.transpose(-1, -2)) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, S, C)
+    ref = (torch.softmax((qh @ kh.transpose(-1, -2)) * score_scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, S, C)
     # q lives inside a wider fused buffer (leading dimension 3C) like the QKV GEMM output would
     qbuf = torch.zeros(B, S, 3 * C, dtype=torch.bfloat16, device=gpu)
     qbuf[:, :, C:2 * C] = q.to(torch.bfloat16).to(gpu)
@@ -447,7 +461,7 @@ def test_attention(gpu, case, qf):
     out = torch.full((B, S, C), float("nan"), dtype=torch.bfloat16, device=gpu)
     kd = k.to(torch.bfloat16).to(gpu)
     call = ops.attention(q=qbuf.data_ptr() + 2 * C, k=kd, vt=vt, out=out, batch=B, heads=H,
-                         head_dim=d, s=S, t=T, q_ld=3 * C, k_ld=C, vt_ld=Tp, o_ld=C, scale=scale)
+                         head_dim=d, s=S, t=T, q_ld=3 * C, k_ld=C, vt_ld=Tp, o_ld=C, scale=scale, q_prescaled=presc)
     _lib.load().msd_set_option(b"attn_qf", qf)
     try:
         run_calls(call)
@@ -455,7 +469,7 @@ def test_attention(gpu, case, qf):
         _lib.load().msd_set_option(b"attn_qf", 0)
     # P is rounded to bf16 before the PV product (relative 2^-9 per term): the error scales with the
     # magnitude of the summed terms, so the absolute floor is 1.5e-2 of max(1, max|O|)
-    close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"{case} qf={qf}")
+    close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"{case} qf={qf} presc={presc}")
 
 
 def test_softmax_rows(gpu):

@@ -25,14 +25,13 @@ def main():
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--qf", type=int, default=0, help="0 = automatic, 1 / 2 = 64 / 128 queries per workgroup")
-    ap.add_argument("--prio", type=int, default=-1, help="-1 = automatic, 0 / 1 = s_setprio in the MFMA sections")
+    ap.add_argument("--presc", type=int, default=1, help="1 = q carries scale*log2(e) (the UNet's projections), 0 = generic")
     args = ap.parse_args()
     from minsdtf_amd import _lib, ops
 
     lib = _lib.load()
     lib.msd_init()
     lib.msd_set_option(b"attn_qf", args.qf)
-    lib.msd_set_option(b"attn_prio", args.prio)
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream()
     for idx, (name, B, H, d, S, T) in enumerate(SHAPES):
@@ -45,7 +44,7 @@ def main():
         vt = torch.randn(B, C, Tp, device=dev).to(torch.bfloat16)
         out = torch.empty(B, S, C, device=dev, dtype=torch.bfloat16)
         call = ops.attention(q=q, k=k, vt=vt, out=out, batch=B, heads=H, head_dim=d, s=S, t=T, q_ld=C, k_ld=C, vt_ld=Tp, o_ld=C,
-                             scale=d ** -0.5)
+                             scale=d ** -0.5, q_prescaled=bool(args.presc))
         for _ in range(3):
             call(st.cuda_stream)
         torch.cuda.synchronize()
