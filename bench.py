@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 
 UNET_TFLOP = 0.8033   # per UNet forward, 512x512, ctx 77, per sample
 VAE_TFLOP = 2.5145    # per decode
+UNET_SELF_ATTN_TFLOP = 0.1225   # of which self-attention QK^T + AV: grows with the SQUARE of the image area
+VAE_ATTN_TFLOP = 0.0344         # (17.2 GMAC single-head attention of the decoder's mid block)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0      # HBM3E, MI355X_MICROARCH.md
 
@@ -51,6 +53,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--controlnet", action="store_true", help="BASELINE config 5: ControlNet residuals every step")
+    ap.add_argument("--sync-phases", action="store_true", help="drain the device at the end of every roctx phase range (profiling)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="library A/B switch passed to msd_set_option (same-box comparisons), e.g. --opt attn_swp=0")
     ap.add_argument("--streams", type=int, default=0, help="1: cond+uncond as one batch-2B forward; 2: two HIP streams; 0: automatic")
@@ -98,40 +101,27 @@ def main():
     unc = rng.standard_normal((gb, 77, 768)).astype(np.float32)
     noise = np.random.default_rng(0).standard_normal((gb, h, h, 4)).astype(np.float32)
 
-    def one_job():
-        """contexts/noise broadcast -> local denoise loop + decode -> all-gather of uint8 images"""
-        def local(c, u, z):
+    def local(c, u, z):
+        """This rank's slice: prepare -> 25-step loop -> decode.  c / u / z arrive as device tensors (N > 1: views of the
+        one broadcast buffer) or host arrays (N = 1)."""
+        with phase("prepare", args.sync_phases):   # uploads + context K/V, time-embedding tables (+ HintNet)
             eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, args.controlnet)
             eng.prepare(eng.contexts(u, c), z, sd.scheduler, None, 0, hint_img)
+        with phase("denoise_loop", args.sync_phases):
             eng.run_steps(nsteps, None)
+        with phase("vae_decode", args.sync_phases):
             return sd.image_decoder.decode_to_uint8(eng.latent)
+
+    def one_job():
         sd.scheduler.set_timesteps(nsteps)
-        return mdist.generate_sharded(local, ctx, unc, noise, dev)
+        return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, 1)):
-        img = one_job()
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        img = one_job()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert tuple(img.shape) == (gb, size, size, 3) and img.dtype == torch.uint8
+    elapsed, img = timed_jobs(one_job, args.steps, args.warmup, dev)
+    assert tuple(img.shape) == (gb, size, size, 3) and img.dtype == torch.uint8 and (rank != 0 or img.device.type == "cpu")
 
     images = gb * args.steps
     value = images / elapsed
-    tflop_per_image = 2 * nsteps * UNET_TFLOP * (size / 512) ** 2 + VAE_TFLOP * (size / 512) ** 2
-    if args.controlnet:
-        tflop_per_image += (2 * nsteps * 0.2686 + 0.015) * (size / 512) ** 2  # ControlNet per UNet call + HintNet once
+    tflop_per_image = algorithmic_tflop_per_image(size, nsteps, args.controlnet)
     out = {
         "metric": "512x512 images/sec (whole node), SD1.5 25-step txt2img",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,6 +161,85 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class phase:
+    """roctx range around one phase of a job (rocprofv3 --marker-trace); with `sync` the device is drained at the range
+    end so that tools/phase_summary.py can attribute the kernel trace to phases by time (profiling runs only)."""
+
+    def __init__(self, name, sync=False):
+        self.name, self.sync = name, sync
+
+    def __enter__(self):
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        import torch
+
+        if torch.cuda.is_available():
+            if self.sync:
+                torch.cuda.synchronize()
+            torch.cuda.nvtx.range_pop()
+
+
+def sharded_job(local, ctx, unc, noise, dev, sync_phases=False):
+    """One whole job on this rank: ONE packed broadcast of the global contexts + noise (RCCL, device resident), the local
+    generator on this rank's slice, all-gather of the uint8 images, and the copy of the gathered batch to host memory on
+    rank 0 (the timed job ends with the uint8 images on the host)."""
+    import torch.distributed as dist
+
+    from minsdtf_amd import dist as mdist
+
+    img = mdist.generate_sharded(local, ctx, unc, noise, dev)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    with phase("d2h", sync_phases):
+        return img.cpu() if rank == 0 else img
+
+
+def timed_jobs(one_job, steps, warmup, dev):
+    """The bench contract's timing: `warmup` untimed jobs, then exactly `steps` jobs bracketed by a barrier + device
+    synchronise on both sides; returns (MAX over ranks of the elapsed seconds, last job's result)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    img = None
+    for _ in range(max(warmup, 1)):
+        img = one_job()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(steps):
+        img = one_job()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, img
+
+
+def algorithmic_tflop_per_image(size, nsteps, controlnet=False):
+    """Algorithmic FLOP of the reference graph for one image (42.68 TFLOP at 512x512 x 25 steps, 220.6 at
+    768x768 x 50).  Convolutions, dense layers and cross-attention grow with the image area a = (size/512)^2, the
+    self-attention products (UNet: 0.1225 of 0.8033 TFLOP per forward; VAE: 0.0344 of 2.5145) with a^2."""
+    a = (size / 512.0) ** 2
+    unet = (UNET_TFLOP - UNET_SELF_ATTN_TFLOP) * a + UNET_SELF_ATTN_TFLOP * a * a
+    vae = (VAE_TFLOP - VAE_ATTN_TFLOP) * a + VAE_ATTN_TFLOP * a * a
+    t = 2 * nsteps * unet + vae
+    if controlnet:   # ControlNet = the UNet's down + mid path per call (0.2686 TFLOP at 512^2, 0.0490 of it self-attention) + HintNet once
+        t += 2 * nsteps * ((0.2686 - 0.0490) * a + 0.0490 * a * a) + 0.015 * a
+    return t
 
 
 def kernel_roofline(sd, b, nsteps, control=False):
@@ -270,15 +339,19 @@ def kernel_roofline(sd, b, nsteps, control=False):
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
     # HBM-side bytes per launch come from the PMC pass committed under profiles/ (rocprofv3 --pmc cannot run
     # inside this process); null when the file is missing
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-            traffic = json.load(f).get("conv_gemm", {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    traffic, traffic_src = None, None
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):   # newest committed PMC pass (tools/measure_round.sh)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pm = json.load(f)
+            traffic = pm.get("conv_gemm", {}).get("hbm_bytes_per_launch")
+            traffic_src = f"profiles/{name}" + (f" (commit {pm['commit']})" if pm.get("commit") else "")
+            break
+        except (OSError, ValueError):
+            continue
     roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
+            "traffic": traffic, "traffic_source": traffic_src, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
             "gflop_per_launch": round(flop_per_launch / 1e9, 3)}
     # per kernel class of one denoise step (event-per-launch pass: each duration includes ~1-2 us of event gap):
     # MFMA utilisation of the contractions, achieved algorithmic HBM rate of everything

@@ -14,4 +14,7 @@ def __getattr__(name):
     if name in ("DiffusionModel", "ImageDecoder", "ImageEncoder", "ControlNet", "HintNet", "TextEncoder", "TextClipEmbedding"):
         from . import models as m
         return getattr(m, name)
+    if name == "shutdown":   # destroy every captured hipGraph and drain the device (also runs at interpreter exit)
+        from ._lib import shutdown
+        return shutdown
     raise AttributeError(name)

@@ -6,8 +6,11 @@ missing or does not export the ABI the header declares, importing any op raises
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 LIB_NAME = "libminsdtf_hip.so"
 # $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
@@ -104,6 +107,36 @@ SYMBOLS = {
 
 _lib = None
 
+# ---- orderly shutdown ---------------------------------------------------------------------------------------------------
+# Captured hipGraphs hold kernel nodes of this library's code object.  At process exit the C runtime unregisters the code
+# object (an atexit handler installed when the .so was loaded, i.e. AFTER torch's: it runs BEFORE torch's static
+# destructors), and only then would torch destroy whatever CUDAGraph objects are still alive — a graph whose kernels'
+# module is already gone.  So everything that owns a graph registers here, and `shutdown()` (also run by Python's own
+# atexit, which precedes the C-level handlers) releases the graphs first, then drains the device.
+_graph_owners = weakref.WeakSet()
+_shutdown_registered = False
+
+
+def track_graph_owner(owner) -> None:
+    """`owner.release_graphs()` will be called by shutdown()."""
+    _graph_owners.add(owner)
+
+
+def shutdown() -> None:
+    """Destroy every captured hipGraph of this package and wait for the device (idempotent; engines and models stay
+    usable: their graphs are re-captured on the next use)."""
+    import gc
+
+    for o in list(_graph_owners):
+        try:
+            o.release_graphs()
+        except Exception:   # pragma: no cover - best effort at exit
+            pass
+    gc.collect()
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+
 
 def load() -> C.CDLL:
     """Load (once) and type the shared library.  Raises HipExtensionError when it is unusable."""
@@ -130,6 +163,10 @@ def load() -> C.CDLL:
     if lib.msd_abi_version() != ABI_VERSION:
         raise HipExtensionError(f"ABI version mismatch: library {lib.msd_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
+    global _shutdown_registered
+    if not _shutdown_registered:
+        atexit.register(shutdown)
+        _shutdown_registered = True
     return lib
 
 

@@ -241,17 +241,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     // score; PRESC: the accumulators already hold s*c - m_ref, p = exp2(acc).
     auto tile_prepare = [&](f32x4 (&s)[4][QF], int tile) {
         const int t0 = tile * 64;
+        // (the key index is made opaque INSIDE each branch: otherwise hipcc hoists its 16 adds out of both branches into
+        //  every tile's straight-line path — 64 issue cycles of ~750 — although self-attention tiles take neither branch)
         if (t0 + 64 > p.t) {  // ragged key tail (text context): only this tile pays for the masking
+            int key0 = t0 + 4 * g;
+            asm volatile("" : "+v"(key0));
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (t0 + kf * 16 + 4 * g + e >= p.t) {
+                    if (key0 + kf * 16 + e >= p.t) {
 #pragma unroll
                         for (int f = 0; f < QF; ++f) s[kf][f][e] = -1e30f;
                     }
         }
         if (p.causal) {       // every query keeps key 0, so no row is ever fully masked
+            int key0 = t0 + 4 * g;
+            asm volatile("" : "+v"(key0));
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
                 const int qi = q0 + f * 16 + r;
@@ -259,12 +265,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (t0 + kf * 16 + 4 * g + e > qi) s[kf][f][e] = -1e30f;
+                        if (key0 + kf * 16 + e > qi) s[kf][f][e] = -1e30f;
             }
         }
         // tile maximum per query: a v_max3 chain over the lane's 16 scores, then across the four 16-lane rows
         float mx[QF];
-        bool need = tile == 0;
+        bool need[QF], any = false;
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
             float m = fmaxf(s[0][f][0], s[0][f][1]);
@@ -275,14 +281,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
                 m = fmaxf(fmaxf(m, s[kf][f][2]), s[kf][f][3]);
             }
             mx[f] = rows_max4(m);
-            need = need || (PRESC ? (mx[f] > ATTN_THR) : ((mx[f] - mref[f]) * p.sl2 > ATTN_THR));
+            need[f] = tile == 0 || (PRESC ? (mx[f] > ATTN_THR) : ((mx[f] - mref[f]) * p.sl2 > ATTN_THR));
+            any = any || need[f];
         }
-        if (__builtin_amdgcn_ballot_w64(need) != 0) {   // wave-uniform; after the first tile: rare (see ATTN_THR)
+        if (__builtin_amdgcn_ballot_w64(any) != 0) {   // wave-uniform; after the first tile: rare (see ATTN_THR)
+            // Only the queries that need it move their reference: for the others delta = 0 / alpha = 1 exactly, so what a
+            // query's result is does not depend on which other queries share its wave (64- vs 128-query workgroups are
+            // picked by grid size, i.e. by batch: results must not depend on how a batch is sharded).
 #pragma unroll
             for (int f = 0; f < QF; ++f) {
                 float alpha;
                 if (PRESC) {
-                    const float delta = tile == 0 ? mx[f] : fmaxf(mx[f], 0.f);   // m_ref only grows after tile 0
+                    const float delta = need[f] ? mx[f] : 0.f;   // (after tile 0: > ATTN_THR, so m_ref only grows)
                     alpha = __builtin_amdgcn_exp2f(-delta);
                     mref[f] += delta;
                     negm[f] = (f32x4){-mref[f], -mref[f], -mref[f], -mref[f]};
@@ -291,11 +301,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) s[kf][f][e] -= delta;
                 } else {
-                    const float mnew = tile == 0 ? mx[f] : fmaxf(mref[f], mx[f]);
+                    const float mnew = need[f] ? mx[f] : mref[f];   // (need: mx > m_ref + THR / scale, or tile 0)
                     alpha = __builtin_amdgcn_exp2f((mref[f] - mnew) * p.sl2);
                     mref[f] = mnew;
                 }
-                if (tile != 0) {   // (tile 0: O and the row sum are still zero)
+                if (tile != 0) {   // (tile 0: O and the row sum are still zero; alpha would be exp2(-first maximum))
                     lrun[f] *= alpha;
 #pragma unroll
                     for (int df = 0; df < DF; ++df) {
@@ -398,6 +408,157 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     }
 }
 
+// ---- d = 512: the VAE's single-head AttentionBlock (layers.py:28-59) ----------------------------------------------
+// The head does not fit the kernel above (O^T of 32 queries x 512 channels alone is 256 registers per lane), and the
+// reference's route — materialise softmax(q k^T / sqrt(C)) — is 64 MB of fp32 scores + 32 MB of probabilities per image
+// at 512x512 (340 MB at 768x768) through HBM.  Here: one workgroup = 4 waves x 16 queries; a wave keeps its 16 x 512
+// query fragments (64 registers) and its O^T accumulator (32 MFMA row blocks = 128 registers) for the whole kernel and
+// walks the keys in 32-key tiles.  A tile is 32 KB of K rows + 32 KB of V^T rows, moved L2 -> LDS by LDS-DMA (no
+// registers to stage through) into a two-stage ring, the next tile in flight while this one is multiplied:
+//   * K image [32 keys][1 KB]: one DMA instruction = one key row; the 16-byte chunk index is XOR-swizzled with the key's
+//     low 4 bits on the SOURCE address (LDS-DMA writes lane-linear), undone in the ds_read_b128 fragment reads, which are
+//     then conflict-free (rows are a multiple of the 256-byte bank row apart);
+//   * V^T image [512 channels][64 B]: one DMA instruction = 16 channel rows; chunk index XOR ((channel >> 2) & 3), so the
+//     8-byte fragment reads of 16 consecutive channels at one key offset spread over all 64 banks.
+// Same transposed products, in-register softmax and lazy reference maximum as above; the row sum is a VALU sum (no
+// spare V^T row when d is a multiple of 16).  Per tile and wave: 64 MFMAs (1024 cycles) against 64 KB of LDS-DMA per
+// workgroup, so at one workgroup per CU the tile loop runs at the L2 -> LDS rate (~1 us per tile), about the time of the
+// three launches it replaces at batch 1, and it scales with the batch where those ran sample by sample.
+__global__ __launch_bounds__(256) void attention512_kernel(const AArgs p) {
+    constexpr int D = 512, KT = 32, KS = D / 32, DF = D / 16;
+    constexpr int K_BYTES = KT * D * 2, V_BYTES = D * KT * 2, ST_BYTES = K_BYTES + V_BYTES;   // 32 KB + 32 KB per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int qtiles = (p.s + 63) / 64;
+    const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);
+    const int bh = udiv_magic(wi, qtiles, p.mg_qtiles);
+    const int b = udiv_magic(bh, p.heads, p.mg_heads), h = bh - b * p.heads;
+    const int q0 = (wi - bh * qtiles) * 64 + wave * 16;
+    const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
+    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
+    const int ntiles = p.t / KT;   // (host: t % 32 == 0)
+
+    // this wave's share of a tile: key rows 8 wave .. 8 wave + 7 and channel rows 128 wave .. 128 wave + 127
+    auto issue_tile = [&](int tile, int stage) {
+        const uint32_t sb = lds0 + (uint32_t)stage * ST_BYTES;
+        const int t0 = tile * KT;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = wave * 8 + i;
+            const int chunk = (lane & 48) | ((lane & 15) ^ (row & 15));
+            dma16(kbase + (size_t)(t0 + row) * p.k_ld + chunk * 8, sb + (uint32_t)row * 1024u);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = (wave * 8 + j) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((d >> 2) & 3);
+            dma16(vbase + (size_t)d * p.vt_ld + t0 + chunk * 8, sb + K_BYTES + (uint32_t)(wave * 8 + j) * 1024u);
+        }
+    };
+    issue_tile(0, 0);
+
+    bf16x8 qf[KS];
+    {
+        int qrow = q0 + r;
+        if (qrow > p.s - 1) qrow = p.s - 1;
+        const bf16_t* qp = p.q + ((size_t)b * p.s + qrow) * p.q_ld + h * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + 8 * g);
+    }
+    f32x4 oacc[DF];
+#pragma unroll
+    for (int df = 0; df < DF; ++df) oacc[df] = (f32x4){0, 0, 0, 0};
+    float mref = 0.f, lrun = 0.f;
+    wait_vmcnt<0>();   // tile 0 and the query fragments have landed
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int stage = tile & 1;
+        __builtin_amdgcn_s_barrier();   // every wave's share of tile `tile` is in LDS; the other stage is no longer read
+        if (tile + 1 < ntiles) issue_tile(tile + 1, stage ^ 1);
+        const char* sK = smem + stage * ST_BYTES;
+        const char* sV = sK + K_BYTES;
+        // ---- S^T = K Q^T: 2 key blocks x 16 k-steps
+        f32x4 sacc[2];
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf) sacc[kf] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int chunk = ks * 4 + g;
+            const int pos = (chunk & 48) | ((chunk & 15) ^ r);   // (key row & 15 = r for both key blocks)
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf) {
+                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sK + (kf * 16 + r) * 1024 + pos * 16);
+                sacc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[ks], sacc[kf], 0, 0, 0);
+            }
+        }
+        // ---- softmax with the lazy reference maximum (lane: keys tile*32 + kf*16 + 4g + e of query r)
+        float m = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3]));
+        m = fmaxf(m, fmaxf(fmaxf(sacc[1][0], sacc[1][1]), fmaxf(sacc[1][2], sacc[1][3])));
+        const float mx = rows_max4(m);
+        const bool need = tile == 0 || (mx - mref) * p.sl2 > ATTN_THR;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            const float mnew = need ? mx : mref;
+            const float alpha = __builtin_amdgcn_exp2f((mref - mnew) * p.sl2);
+            mref = mnew;
+            if (tile != 0) {
+                lrun *= alpha;
+#pragma unroll
+                for (int df = 0; df < DF; ++df) { oacc[df][0] *= alpha; oacc[df][1] *= alpha; oacc[df][2] *= alpha; oacc[df][3] *= alpha; }
+            }
+        }
+        const float nm = -mref * p.sl2;
+        float ls = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kf][e], p.sl2, nm));
+                sacc[kf][e] = pv;
+                ls += pv;
+            }
+        lrun += ls;
+        union { bf16x8 v; uint32_t u[4]; } pk;
+        pk.u[0] = pack_bf2(sacc[0][0], sacc[0][1]);
+        pk.u[1] = pack_bf2(sacc[0][2], sacc[0][3]);
+        pk.u[2] = pack_bf2(sacc[1][0], sacc[1][1]);
+        pk.u[3] = pack_bf2(sacc[1][2], sacc[1][3]);
+        // ---- O^T += V^T P^T: 32 channel blocks, one 32-key k-step each
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const int d = df * 16 + r;
+            const int sw = (d >> 2) & 3;
+            const char* vrow = sV + d * 64 + (g & 1) * 8;
+            union { bf16x8 v; uint2 h2[2]; } vf;
+            vf.h2[0] = *reinterpret_cast<const uint2*>(vrow + (((g >> 1)) ^ sw) * 16);        // keys 4g .. 4g+3
+            vf.h2[1] = *reinterpret_cast<const uint2*>(vrow + ((2 + (g >> 1)) ^ sw) * 16);    // keys 16+4g .. 16+4g+3
+            oacc[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, oacc[df], 0, 0, 0);
+        }
+        wait_vmcnt<0>();   // this wave's share of tile + 1 has landed (before the barrier that publishes it)
+    }
+
+    float lt = lrun;
+    lt += __shfl_xor(lt, 16);
+    lt += __shfl_xor(lt, 32);
+    const float inv = 1.0f / lt;
+    const int qrow = q0 + r;
+    if (qrow < p.s) {
+        bf16_t* op = p.out + ((size_t)b * p.s + qrow) * p.o_ld + h * D;
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            uint2 o;
+            o.x = pack_bf2(oacc[df][0] * inv, oacc[df][1] * inv);
+            o.y = pack_bf2(oacc[df][2] * inv, oacc[df][3] * inv);
+            *reinterpret_cast<uint2*>(op + df * 16 + 4 * g) = o;
+        }
+    }
+}
+constexpr int ATTN512_LDS = 2 * (32 * 512 * 2 + 512 * 32 * 2);
+
 // ---- launch configuration ---------------------------------------------------------------------
 template <int D>
 static constexpr int attn_nbuf() { return D <= 80 ? 2 : 1; }   // D = 160 has no registers left for the prefetch
@@ -430,6 +591,8 @@ int msd_attention_init() {
     if (e == hipSuccess) e = attn_attr<80>();
     if (e == hipSuccess) e = attn_attr<160>();
     if (e == hipSuccess) e = attn_attr<64>();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN512_LDS);
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
     g_attn_attr_done = true;
     return MSD_OK;
@@ -483,7 +646,13 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
         case 80: attn_launch<80>(a, qf, stream); break;
         case 160: attn_launch<160>(a, qf, stream); break;
         case 64: attn_launch<64>(a, qf, stream); break;
-        default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 64, 80, 160)", q->head_dim);
+        case 512: {
+            if ((q->t % 32) || a.causal || a.presc) MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim 512 needs t %% 32 == 0, no causal mask, no prescaled q");
+            a.mg_qtiles = udiv_magic_of((q->s + 63) / 64);
+            hipLaunchKernelGGL(attention512_kernel, dim3(((q->s + 63) / 64) * q->heads * q->batch), dim3(256), ATTN512_LDS, stream, a);
+            break;
+        }
+        default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 64, 80, 160, 512)", q->head_dim);
     }
     MSD_CHECK_LAUNCH();
     return MSD_OK;

@@ -44,15 +44,34 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// Wave-wide sum / max, result on every lane, without the LDS crossbar: four DPP steps inside each 16-lane row (quad
+// permutes, row rotates: fused into the v_add / v_max) and two row swaps (v_permlane16_swap / v_permlane32_swap).
+// __shfl_xor compiles to ds_bpermute_b32, ~100+ cycles of latency per step in the middle of a dependency chain (six steps
+// per reduction: these small normalisation kernels are latency chains).  Fixed order -> bit-reproducible.
+#define MSD_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += MSD_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+    v += MSD_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+    v += MSD_DPP(v, 0x124);   // row_ror:4
+    v += MSD_DPP(v, 0x128);   // row_ror:8
+    const uint32_t u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const uint32_t w = __float_as_uint(v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, MSD_DPP(v, 0xB1));
+    v = fmaxf(v, MSD_DPP(v, 0x4E));
+    v = fmaxf(v, MSD_DPP(v, 0x124));
+    v = fmaxf(v, MSD_DPP(v, 0x128));
+    const uint32_t u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const uint32_t w = __float_as_uint(v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // Bijective XCD-aware remap of a linear workgroup id (cdna_hip_programming.md T1): ids b and b+8
@@ -72,6 +91,49 @@ __device__ __forceinline__ int udiv_magic(int x, int d, uint32_t magic) {
     return q;
 }
 static inline uint32_t udiv_magic_of(int d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint64_t)d); }
+
+// ---- LDS-DMA helpers (compiler-invisible on purpose: see cdna_hip_programming.md §5.7) ---------
+// One wave instruction copies 64 x 16 B from per-lane global addresses to LDS bytes
+// [lds_dst, lds_dst + 1024) in lane order.  M0 carries the LDS base and is restored.
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+// same, source = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
+__device__ __forceinline__ void dma16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most min(later, MAXT) tiles of L DMA instructions each are still in flight
+template <int L, int MAXT>
+__device__ __forceinline__ void wait_vmcnt_tiles(int later) {
+    if constexpr (MAXT <= 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (later >= MAXT) wait_vmcnt<(MAXT * L < 63 ? MAXT * L : 63)>();
+        else wait_vmcnt_tiles<L, MAXT - 1>(later);
+    }
+}
 
 // ---- host side ---------------------------------------------------------------------------
 void msd_set_error(const char* fmt, ...);

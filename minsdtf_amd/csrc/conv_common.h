@@ -362,47 +362,3 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
         }
     }
 }
-
-// ---- LDS-DMA helpers (compiler-invisible on purpose: see cdna_hip_programming.md §5.7) ---------
-// One wave instruction copies 64 x 16 B from per-lane global addresses to LDS bytes
-// [lds_dst, lds_dst + 1024) in lane order.  M0 carries the LDS base and is restored.
-__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-// same, source = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
-__device__ __forceinline__ void dma16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// wait until at most min(later, MAXT) tiles of L DMA instructions each are still in flight
-template <int L, int MAXT>
-__device__ __forceinline__ void wait_vmcnt_tiles(int later) {
-    if constexpr (MAXT <= 0) {
-        wait_vmcnt<0>();
-    } else {
-        if (later >= MAXT) wait_vmcnt<(MAXT * L < 63 ? MAXT * L : 63)>();
-        else wait_vmcnt_tiles<L, MAXT - 1>(later);
-    }
-}
-

@@ -404,8 +404,9 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     // 512^2) are byte-bound: ~1024 workgroups chip-wide and a separate ordered finalize (3 launches).
     const bool small = (long long)q->hw * C <= (4ll << 20);
     // (wide: 128 chunks per sample — 256 workgroups at batch 2, one per CU; 64 leave half the chip idle)
-    long long target_blocks = small ? (wide ? 128 : 64) : 1024 / q->batch;
-    if (target_blocks < 1) target_blocks = 1;
+    // (chunks per SAMPLE, whatever the batch: the partial moments are summed chunk by chunk, so the chunking is part of the
+    //  arithmetic, and a sample's result must not depend on the batch it is computed in)
+    const long long target_blocks = small ? (wide ? 128 : 64) : 1024;
     int ppb = (int)((q->hw + target_blocks - 1) / target_blocks);
     const int min_ppb = wide ? a.pl : a.pl * 4;
     if (ppb < min_ppb) ppb = min_ppb;

@@ -5,8 +5,8 @@ are per sample, the CFG-rescale std is per sample, reference ``stable_diffusion.
 rank r owns the contiguous slice ``[r*B/G, (r+1)*B/G)`` of the global batch and NOTHING crosses
 GPUs inside a step.  The only exchanges are the inputs and the outputs:
 
-* one broadcast from rank 0 of the text contexts and of the initial noise drawn for the GLOBAL
-  batch (so results do not depend on the number of ranks),
+* ONE broadcast from rank 0 of the text contexts and of the initial noise drawn for the GLOBAL
+  batch (so results do not depend on the number of ranks), packed into a single device buffer,
 * one all-gather of the finished uint8 images.
 
 Both are a few MB at most (latency-bound), so they are plain RCCL collectives
@@ -49,16 +49,23 @@ def shard_bounds(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def broadcast_inputs(arrays, device, src: int = 0):
-    """Broadcast a list of equally-shaped-on-all-ranks fp32 arrays from `src`; returns numpy arrays.
-
-    Every rank passes arrays of the right shape (contents only matter on `src`)."""
+    """ONE broadcast from `src` of a list of fp32 arrays (same shapes on every rank; contents only matter on `src`),
+    packed into a single flat device buffer; returns device-resident views of it, one per array — nothing comes back to
+    the host (the denoise engine copies device -> device).  Single process: the arrays are returned as they are."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return [np.asarray(a, dtype=np.float32) for a in arrays]
-    out = []
-    for a in arrays:
-        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
-        dist.broadcast(t, src=src)
-        out.append(t.cpu().numpy())
+        return list(arrays)
+    shapes = [tuple(np.shape(a)) for a in arrays]
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    if dist.get_rank() == src:
+        flat = np.concatenate([np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in arrays])
+        buf = torch.from_numpy(flat).to(device)
+    else:
+        buf = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    dist.broadcast(buf, src=src)
+    out, off = [], 0
+    for sh, n in zip(shapes, sizes):
+        out.append(buf[off:off + n].view(*sh))
+        off += n
     return out
 
 
@@ -81,7 +88,7 @@ def generate_sharded(generate_local: Callable[[np.ndarray, np.ndarray, np.ndarra
     rank 0, right shape elsewhere)."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    context, uncond_context, noise = broadcast_inputs([context, uncond_context, noise], device)
+    context, uncond_context, noise = broadcast_inputs([context, uncond_context, noise], device)   # device tensors when world > 1
     lo, hi = shard_bounds(noise.shape[0], rank, world)
     img = generate_local(context[lo:hi], uncond_context[lo:hi], noise[lo:hi])
     return all_gather_images(img)

@@ -609,10 +609,14 @@ def emit_hintnet(e: Emitter, image_f32, B: int, H: int, W: int, out: Act) -> Non
         h, w = ho, wo
 
 
+# VAE attention: the fused d = 512 kernel (scores stay on chip), or the three-launch route that materialises them
+VAE_FUSED_ATTN = os.environ.get("MSD_VAE_FUSED_ATTN", "1") != "0"   # (env switch: same-box A/B runs)
+
+
 def emit_vae_attention(e: Emitter, x: Act, name: str) -> Act:
-    """AttentionBlock (layers.py:28-59): single head, d = C = 512, scale 1/sqrt(C); q/k/v/proj
-    Dense with bias.  d=512 does not fit the fused kernel's register budget, so the scores of this
-    one layer are materialised (fp32) per sample: S = Q K^T on MFMA, row softmax, O = P V on MFMA."""
+    """AttentionBlock (layers.py:28-59): single head, d = C = 512, scale 1/sqrt(C); q/k/v/proj Dense with bias.
+    softmax(q k^T / sqrt(C)) v is one msd_attention launch (the d = 512 kernel: scores never leave the chip; the reference
+    materialises S x S fp32 scores, 64 MB per image at 512x512, 340 MB at 768x768)."""
     p = e.p
     B, H, Wd, C = x.B, x.H, x.W, x.C
     S = H * Wd
@@ -622,6 +626,14 @@ def emit_vae_attention(e: Emitter, x: Act, name: str) -> Act:
     e.conv(g, name + ".qkv", 3 * C, split=(C, C, q.buf, k.buf, vt, S))
     p.free(g)
     o = p.act(B, H, Wd, C)
+    if VAE_FUSED_ATTN and C == 512 and S % 32 == 0:
+        p.rec(ops.attention, q=q.buf, k=k.buf, vt=vt, out=o.buf, batch=B, heads=1, head_dim=C, s=S, t=S, q_ld=C, k_ld=C, vt_ld=S,
+              o_ld=C, scale=1.0 / float(np.sqrt(C)), name=name + ".attention")
+        p.free(q, k, vt)
+        out = e.conv(o, name + ".proj_attn", C, residual=x)
+        p.free(o, x)
+        return out
+    # (any other geometry: scores materialised per sample — S = Q K^T on MFMA, row softmax, O = P V on MFMA)
     scores = p.alloc(S * S * 4)
     probs = p.alloc(S * S * 2)
     for b in range(B):

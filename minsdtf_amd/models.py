@@ -259,6 +259,10 @@ class _BoundPlan:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = use_graph
         self.io: Dict[str, torch.Tensor] = {}
+        _lib.track_graph_owner(self)
+
+    def release_graphs(self) -> None:
+        self.graph = None
 
     def run(self):
         if not self.use_graph:

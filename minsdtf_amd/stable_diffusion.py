@@ -26,7 +26,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
-from . import engine, ops
+from . import _lib, engine, ops
 from . import weights as wtab
 from .models import (ControlNet, DiffusionModel, HintNet, ImageDecoder, ImageEncoder, TextClipEmbedding, TextEncoder, _BoundPlan,
                      _skip_hw, default_device)
@@ -181,6 +181,12 @@ class DenoiseEngine:
         self._loop_graph: Optional[torch.cuda.CUDAGraph] = None
         self._loop_graph_steps = 0
         self._warmed = False
+        _lib.track_graph_owner(self)
+
+    def release_graphs(self) -> None:
+        """Destroy the captured step / loop graphs (re-captured on the next run_steps)."""
+        self._step_graph = self._loop_graph = None
+        self._loop_graph_steps = 0
 
     @property
     def calls(self):
@@ -188,11 +194,13 @@ class DenoiseEngine:
         out = [c for pl in self.branches for c in pl.calls]
         return out + (self.tail.calls if self.tail is not None else [])
 
-    def contexts(self, unconditional_context, context) -> Dict[str, np.ndarray]:
-        """The `prepare` input for this engine's pass layout."""
+    def contexts(self, unconditional_context, context) -> dict:
+        """The `prepare` input for this engine's pass layout (host arrays or device tensors)."""
         if not self.cfg:
             return {"cond": context}
         if len(self.passes) == 1:
+            if isinstance(context, torch.Tensor):
+                return {"both": torch.cat([unconditional_context, context], dim=0)}
             return {"both": np.concatenate([unconditional_context, context], axis=0)}
         return {"uncond": unconditional_context, "cond": context}
 
@@ -281,8 +289,8 @@ class DenoiseEngine:
             m = m.reshape(self.h, self.w, 1)
             self.inpaint["mask"].copy_(torch.from_numpy(np.ascontiguousarray(np.broadcast_to(m, (self.h, self.w, 4))).reshape(-1)))
         for tag, arr in contexts.items():
-            self.ctx_in[tag].copy_(torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)))
-        self.latent.copy_(torch.from_numpy(np.ascontiguousarray(noise, dtype=np.float32)))
+            self.ctx_in[tag].copy_(_f32_tensor(arr))
+        self.latent.copy_(_f32_tensor(noise))
         self.coef.copy_(torch.from_numpy(scheduler.coefficient_table()))
         temb = np.concatenate([get_timestep_embedding(int(t), 1) for t in scheduler.timesteps], axis=0)
         self.temb_in.copy_(torch.from_numpy(np.ascontiguousarray(temb, dtype=np.float32)))
@@ -299,6 +307,13 @@ class DenoiseEngine:
             reps = self.hint_img.shape[0] // hi.shape[0]
             self.hint_img.copy_(torch.from_numpy(np.tile(hi, (reps, 1, 1, 1))))
         self.prep.run(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32_tensor(x) -> torch.Tensor:
+    """Host array or (device) tensor -> fp32 tensor for a copy_ into an engine buffer (no host round trip for tensors)."""
+    if isinstance(x, torch.Tensor):
+        return x.to(torch.float32)
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
 
 
 class _Ptr:

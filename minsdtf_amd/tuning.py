@@ -15,6 +15,7 @@ from typing import Dict, Optional, Tuple
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning.json")
 _table: Optional[Dict[str, list]] = None
+_families: Optional[Dict[str, Dict[int, list]]] = None   # batch-agnostic key -> {batch: entry}
 
 # (tile_m, tile_n, stages): stages 0 = the tile's default ring depth.  tile_m 1128 / 1256 = halo-tile
 # 3x3 kernel with 8x16 / 16x16 pixel tiles.
@@ -33,18 +34,23 @@ def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=Tr
 
 
 def _load() -> Dict[str, list]:
-    global _table
+    global _table, _families
     if _table is None:
         try:
             with open(_PATH) as f:
                 _table = json.load(f)
         except (OSError, ValueError):
             _table = {}
+        _families = {}
+        for key, ent in _table.items():
+            b, rest = key.split("x", 1)
+            _families.setdefault(rest, {})[int(b)] = ent
     return _table
 
 
 def heuristic(M: int, N: int, nk: int, allow_split: bool) -> Tuple[int, int, int, int]:
-    """(tile_m, tile_n, splitk, stages) when the shape has not been measured."""
+    """(tile_m, tile_n, splitk, stages) when the shape has not been measured.  M = rows of ONE sample: split-K and the
+    column tile are part of a layer's arithmetic (order of the fp32 sums) and must not depend on the batch."""
     bn = 128 if (N % 128 == 0 or N > 1024) else 64
     bm = 128
     if M <= 64:
@@ -57,11 +63,27 @@ def heuristic(M: int, N: int, nk: int, allow_split: bool) -> Tuple[int, int, int
 
 
 def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split, cx=0) -> Tuple[int, int, int, int]:
-    ent = _load().get(shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split, cx))
+    key = shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split, cx)
+    ent = _load().get(key)
+    if ent is None:
+        # a batch that was not measured takes the entry of the nearest measured batch of the same layer: every entry of
+        # a layer is in the layer's one numerics class (tools/tune_conv.py), so the sample's bits stay the same
+        fam = _families.get(key.split("x", 1)[1])
+        if fam:
+            ent = fam[min(fam, key=lambda b: (abs(b - batch) / (b + batch), b))]
+            if int(ent[0]) == 256 and M < 1024:   # (the 256-row tile needs >= 1024 rows)
+                ent = [128] + list(ent[1:])
     if ent is not None:
         bm, bn, sk = int(ent[0]), int(ent[1]), int(ent[2])
         stages = int(ent[3]) if len(ent) > 4 else 0   # [bm, bn, splitk, stages, us] (older tables: [bm, bn, splitk, us])
         if not allow_split:
             sk = 1
         return bm, bn, sk, stages
-    return heuristic(M, N, nk, allow_split)
+    return heuristic(M // max(1, batch), N, nk, allow_split)
+
+
+def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int) -> Tuple[bool, int, int]:
+    """The part of a launch configuration that decides the ORDER of the layer's fp32 sums: kernel family (halo-tile 3x3
+    kernel: chunk-major K walk), split-K slices, and for 1x1 / dense layers the column tile (grouping of the LayerNorm
+    fold's row-moment partials).  The table holds ONE class per layer shape for all batch sizes (tools/tune_conv.py)."""
+    return (tile_m >= 1000, splitk, tile_n if ksize == 1 else 0)

@@ -69,10 +69,10 @@ def test_batch_equals_independent_samples(gpu, nets):
     both = sd.generate_image(ctx, batch_size=3, diffusion_noise=noise, **kw)
     for i in range(3):
         one = sd.generate_image(ctx[i], batch_size=1, diffusion_noise=noise[i], **kw)
-        # Same arithmetic up to the choices that depend on M: split-K slices and, with the LayerNorm fold, the
-        # column-tile grouping of the row-moment partials (fp32 reassociation, amplified by bf16 rounding over
-        # 3 steps x 16 blocks: measured 49 dB; both runs sit 48-49 dB from the oracle).  Bar: the parity bar + 5 dB.
-        assert O.psnr(both[i:i + 1], one) >= 45.0
+        # BIT-identical: everything that orders a layer's fp32 sums (kernel family, split-K slices, column tile of the
+        # LayerNorm partials, GroupNorm chunking, the attention's reference-maximum moves) is fixed per layer, not per
+        # batch (minsdtf_amd/tuning.py numerics_class) — so a sample does not depend on how a global batch is sharded
+        np.testing.assert_array_equal(both[i:i + 1], one)
 
 
 @pytest.mark.parametrize("jit", [True, False])
@@ -96,7 +96,7 @@ def test_two_stream_step_equals_fused_batch(gpu, nets, jit):
         assert sd._engine(2, 77, 77, 4, 7.5, 0.7, False).dual == (streams == 2)
         again = sd.generate_image(ctx, **kw)                      # replay (graph or eager): same bits
         np.testing.assert_array_equal(out[streams], again)
-    assert O.psnr(out[2], out[1]) >= 50.0   # batch-1 vs batch-2 launches pick different tiles / split-K
+    np.testing.assert_array_equal(out[2], out[1])   # batch-2 forwards vs the batch-4 fused one: same bits per sample
 
 
 def test_non_power_of_two_latent(gpu):

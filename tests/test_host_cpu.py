@@ -352,6 +352,30 @@ def test_splitk_policy():
     assert pick_splitk(128, 1280, 4) == 1           # short K: never split
 
 
+def test_tuning_table_pins_one_numerics_class_per_layer():
+    """A sample's bits must not depend on the batch it runs in: the launch parameters that order a layer's fp32 sums
+    (kernel family, split-K slices, column tile of 1x1 / dense layers) are the same for every batch of a layer shape."""
+    import json
+
+    from minsdtf_amd import tuning
+
+    table = json.load(open(os.path.join(ROOT, "minsdtf_amd", "conv_tuning.json")))
+    fams = {}
+    for key, ent in table.items():
+        b, rest = key.split("x", 1)
+        ks = int(re.search(r"k(\d)s", rest).group(1))
+        fams.setdefault(rest, set()).add(tuning.numerics_class(ks, int(ent[0]), int(ent[1]), int(ent[2])))
+    bad = {k: v for k, v in fams.items() if len(v) != 1}
+    assert not bad, bad
+    # an unmeasured batch lands in the same class as the measured ones; an unknown layer falls back per SAMPLE
+    a = tuning.lookup(2, 8, 8, 1280, 1280, 3, 1, False, 128, 180, True)
+    b = tuning.lookup(6, 8, 8, 1280, 1280, 3, 1, False, 384, 180, True)
+    assert tuning.numerics_class(3, a[0], a[1], a[2]) == tuning.numerics_class(3, b[0], b[1], b[2])
+    h1 = tuning.lookup(1, 40, 40, 704, 704, 3, 1, False, 1600, 99, True)
+    h5 = tuning.lookup(5, 40, 40, 704, 704, 3, 1, False, 8000, 99, True)
+    assert h1[1:3] == h5[1:3]
+
+
 # ------------------------------------------------------------------ the C ABI
 def test_library_exports_every_declared_symbol():
     """libminsdtf_hip.so loads and exports exactly what include/minsdtf_hip.h declares."""

@@ -297,6 +297,10 @@ def test_conv_gemm_qkv_split(gpu, nq):
     dict(B=1, mod=1, H=8, W=8, cin=4, cout=4, in_f32=True, ks=1, scale=1 / 0.18215, out="f32"),  # post_quant
     dict(B=5, mod=5, H=1, W=1, cin=320, cout=1280, in_f32=True, ks=1, act=True, out="f32"),      # time-embedding dense
     dict(B=1, mod=1, H=8, W=8, cin=4, cout=320, in_f32=True, resid=True),        # ControlNet conv_in + hint
+    dict(B=2, mod=1, H=64, W=64, cin=4, cout=320, in_f32=True, resid=True),      # ... at the real size: 32-pixel row segments
+    dict(B=3, mod=3, H=24, W=48, cin=4, cout=512, in_f32=True, scale=1 / 0.18215),  # VAE decoder.conv_in: 16-pixel segments, 2 px groups
+    dict(B=1, mod=1, H=5, W=8, cin=4, cout=64, in_f32=True),                     # 8-pixel segments, 16 pixel groups
+    dict(B=1, mod=1, H=6, W=6, cin=4, cout=320, in_f32=True),                    # width not a multiple of 8: generic kernel
 ])
 def test_conv_direct(gpu, case):
     from minsdtf_amd import ops
@@ -397,6 +401,30 @@ def test_group_norm(gpu, case):
     run_calls(call2)
     if case.get("impl", 1) == 1:
         assert torch.equal(out.view(torch.int16), out2.view(torch.int16))   # bit-reproducible run to run
+
+
+@pytest.mark.parametrize("B,S,spike", [(1, 4096, False), (2, 320, True), (1, 9216, False), (1, 64, False), (3, 200, False)])
+def test_attention_d512(gpu, B, S, spike):
+    """VAE AttentionBlock (layers.py:28-59): single head, d = 512, softmax(q k^T / sqrt(512)) v with the scores kept on
+    chip (msd_attention head_dim 512), at the decoder's real sizes (S = 4096 at 512x512, 9216 at 768x768), a query count
+    that is not a multiple of the 64-query workgroup, and forced reference-maximum moves (`spike`)."""
+    from minsdtf_amd import ops
+
+    torch.manual_seed(12)
+    d = 512
+    T = (S + 31) // 32 * 32 if S % 32 else S
+    q, k, v = bf(torch.randn(B, S, d)), bf(torch.randn(B, T, d)), bf(torch.randn(B, T, d))
+    if spike:
+        k[:, T // 2 + 3] *= 5.0
+        k[:, T - 5] *= 9.0
+        k = bf(k)
+    scale = 1.0 / math.sqrt(d)
+    ref = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) @ v
+    vt = v.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(gpu)
+    out = torch.full((B, S, d), float("nan"), dtype=torch.bfloat16, device=gpu)
+    run_calls(ops.attention(q=q.to(torch.bfloat16).to(gpu), k=k.to(torch.bfloat16).to(gpu), vt=vt, out=out, batch=B, heads=1, head_dim=d,
+                            s=S, t=T, q_ld=d, k_ld=d, vt_ld=T, o_ld=d, scale=scale))
+    close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"d512 B={B} S={S}")
 
 
 @pytest.mark.parametrize("rows,c", [(256, 320), (100, 640), (64, 1280), (7, 2048)])
