@@ -114,7 +114,9 @@ typedef struct MsdConvGemm {
     int32_t stages;      /* 0 = default LDS ring depth of the tile; deeper rings built: 128x128:4 64x64:8 64x128:5 128x64:5
                             128x80:4; halo tiles 1128x64:8 1128x128:6 1128x80:8 1256x80:5 (an unknown depth = the default);
                             10 + depth = the tile on 8 waves (two per SIMD): 64x64:14 128x64:13 64x128:13;
-                            20 + depth = 64x64 per wave: 128x128:23/24 128x64:24 64x128:24 */
+                            20 + depth = 64x64 per wave: 128x128:23/24 128x64:24 64x128:24;
+                            30 + depth = halo tiles with 3 filter taps (one filter row) per K step: 1128x64:33/34 1128x80:33
+                            2128x64:33 */
     const float* ln_in;      /* float2 [M][ln_in_slots] row-moment partials of the input rows, or NULL */
     const float* ln_colsum;  /* [N]: sum_k W[n][k] of the gamma-folded bf16 weights (with ln_in) */
     float* ln_out;           /* float2 [M][ln_out_slots] row-moment partials of the stored output, or NULL */

@@ -38,7 +38,12 @@ __device__ __forceinline__ void halo_wait(int later, bool halo) {
     }
 }
 
-template <int TH, int BN, int WGM, int WGN, int S>
+// TAPS = filter taps per K step (1, or 3 = one filter row): with 3 the weight ring moves a whole filter row per stage and
+// there is one wait + barrier per 3 taps; inside a step the fragment reads of the next tap have no barrier between them
+// and the previous tap's MFMAs (a 1-tap step measured 0.59 us for 0.16 us of MFMA work on the 8x16x80 tile: 0.32 us
+// issuing fragment reads + DMAs, 0.16 us wait + barrier).  The taps of a chunk are still walked in the order 0..8, so the
+// bits do not change.
+template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGArgs p) {
     constexpr int TW = 16, BM = TH * TW;
     constexpr int NW = WGM * WGN, NT = NW * 64;
@@ -50,8 +55,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     constexpr int HR = (HROWS + RPP - 1) / RPP;            // DMA rounds (= instructions per thread) per halo
     constexpr int H_BYTES = HR * RPP * 128;
     constexpr int BNP = (BN + RPP - 1) / RPP * RPP;        // weight rows as staged (BN = 80: padded to the DMA round)
-    constexpr int BR = BNP * 8 / NT;                       // weight DMA instructions per thread per K step
-    constexpr int W_BYTES = BNP * 128;
+    constexpr int BR1 = BNP * 8 / NT;                      // weight DMA instructions per thread per tap
+    constexpr int BR = BR1 * TAPS;                         // ... per K step
+    constexpr int W1_BYTES = BNP * 128, W_BYTES = W1_BYTES * TAPS;
+    constexpr int SPC = 9 / TAPS;                          // K steps per 64-channel chunk
+    static_assert(TAPS == 1 || TAPS == 3, "taps per step");
     static_assert(WNT % 16 == 0 && WMT % 16 == 0, "config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     const int nchunks = p.nkc;                             // 64-channel chunks of the (concatenated) input
     const int c_begin = blockIdx.y * p.nk_per;             // split-K is over chunks here
     const int c_end = min(nchunks, c_begin + p.nk_per);
-    const int nkt = (c_end - c_begin) * 9;
+    const int nkt = (c_end - c_begin) * SPC;
 
     // ---- loader coordinates -----------------------------------------------------------------------
     const int cpos = tid & 7, lrow = tid >> 3;
@@ -98,9 +106,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         hpix[i] = ok ? pix : -1;
         hsrc[i] = (cpos ^ ((hrow >> 1) & 7)) * 8;
     }
-    uint32_t woff[BR];
+    uint32_t woff[BR1];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
+    for (int i = 0; i < BR1; ++i) {
         const int row = lrow + RPP * i;
         woff[i] = ((uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.K + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 8)) * 2u;
     }
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         const bool first = ch < p.c0;                                  // wave-uniform: which tensor of the concat
         const uint64_t sb = (uint64_t)(first ? p.a0 : p.a1);
         const int csrc = first ? p.c0 : p.c1, coff = first ? ch : ch - p.c0;
-        const uint32_t base = lds_wave + (uint32_t)buf * H_BYTES;
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)buf * H_BYTES);
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const uint32_t m32 = (uint32_t)(~hpix[i] >> 31);             // all ones for a pixel inside the image (hpix >= 0)
@@ -123,11 +131,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
             dma16(reinterpret_cast<const void*>(a), base + (uint32_t)(RPP * i) * 128u);
         }
     };
-    auto issue_w = [&](int c, int tap, int stage) {
-        const uint32_t koff = (uint32_t)(tap * cin + c * 64) * 2u;
-        const uint32_t base = lds_wave + 2u * H_BYTES + (uint32_t)stage * W_BYTES;
+    auto issue_w = [&](int c, int tg, int stage) {   // tg = tap (TAPS = 1) or filter row (TAPS = 3)
 #pragma unroll
-        for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + koff, base + (uint32_t)(RPP * i) * 128u);
+        for (int t = 0; t < TAPS; ++t) {
+            const uint32_t koff = (uint32_t)((tg * TAPS + t) * cin + c * 64) * 2u;
+            // (readfirstlane: with the tap loop unrolled hipcc no longer proves this sum wave-uniform and M0 needs an SGPR)
+            const uint32_t base = __builtin_amdgcn_readfirstlane(lds_wave + 2u * H_BYTES + (uint32_t)stage * W_BYTES + (uint32_t)t * W1_BYTES);
+#pragma unroll
+            for (int i = 0; i < BR1; ++i) dma16s(p.w, woff[i] + koff, base + (uint32_t)(RPP * i) * 128u);
+        }
     };
 
     f32x4 acc[NJ][MI];
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     // Program order of the DMA queue: H(c_begin), W(0) .. W(S-2) | iteration it: [H(next chunk) at tap 0],
     // W(it+S-1).  With one workgroup per CU (batch 1-2) a K step costs (L2 latency) / (tiles in flight):
     // S = 3 measured ~0.7 us per step against ~0.13 us of MFMA work, hence the deeper rings.
-    static_assert(S >= 3 && S - 1 <= 9, "ring depth");
+    static_assert(S >= 3 && S - 1 <= SPC, "ring depth");
     if (nkt > 0) {
         issue_halo(c_begin, 0);
 #pragma unroll
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     MSD_STAMP(1);
     int c = c_begin, tap = 0, stage = 0, hbuf = 0;
     int cw = c_begin, tw = S - 1, sw = S - 1;   // (chunk, tap, stage) of the next weight tile to issue
-    if (tw >= 9) { tw -= 9; ++cw; }
+    if (tw >= SPC) { tw -= SPC; ++cw; }
     int since_halo = 1 << 20;                   // iterations since a halo was issued
     for (int it = 0; it < nkt; ++it) {
         // Retire W(it) (and, being older in the queue, the halo of this chunk).  Younger than W(it):
@@ -169,27 +181,41 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         if (it == (nkt >> 1)) MSD_STAMP(5);
         if (probe) MSD_STAMP(12);
 #endif
-        // fragments of this K step first, then the DMA issue of the tiles ahead (it runs under the LDS latency), then the MFMAs
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const char* bW = smem + 2 * H_BYTES + stage * W_BYTES + (wn * WNT + r) * 128;
+        // fragments of this K step's first tap, then the DMA issue of the tiles ahead (it runs under the LDS latency), then
+        // per tap: MFMAs (the next tap's fragment reads are independent of them: no barrier inside a step)
         const char* bH = smem + hbuf * H_BYTES;
-        int hrow[MI];
+        auto read_tap = [&](int t, bf16x8 (&af)[2][MI], bf16x8 (&wf)[2][NJ]) {
+            const int tp = tap * TAPS + t;
+            const int ky = TAPS == 3 ? tap : tp / 3, kx = TAPS == 3 ? t : tp - ky * 3;
+            const char* bW = smem + 2 * H_BYTES + stage * W_BYTES + t * W1_BYTES + (wn * WNT + r) * 128;
+            int hrow[MI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) hrow[i] = (wm * MI + i + ky) * HW_ + kx + r;
+            for (int i = 0; i < MI; ++i) hrow[i] = (wm * MI + i + ky) * HW_ + kx + r;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int wc = ((ks * 4 + g) ^ (r >> 1)) << 4;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[ks][i] = *reinterpret_cast<const bf16x8*>(bH + hrow[i] * 128 + (((ks * 4 + g) ^ ((hrow[i] >> 1) & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bW + j * 16 * 128 + wc);
+            }
+        };
+        auto mfma_tap = [&](const bf16x8 (&af)[2][MI], const bf16x8 (&wf)[2][NJ]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+        };
         bf16x8 af[2][MI], wf[2][NJ];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int wc = ((ks * 4 + g) ^ (r >> 1)) << 4;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[ks][i] = *reinterpret_cast<const bf16x8*>(bH + hrow[i] * 128 + (((ks * 4 + g) ^ ((hrow[i] >> 1) & 7)) << 4));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bW + j * 16 * 128 + wc);
-        }
+        read_tap(0, af, wf);
         if (tap == 0 && c + 1 < c_end) { issue_halo(c + 1, hbuf ^ 1); since_halo = 0; }
         if (it + S - 1 < nkt) {
             issue_w(cw, tw, sw);
-            if (++tw == 9) { tw = 0; ++cw; }
+            if (++tw == SPC) { tw = 0; ++cw; }
             if (++sw == S) sw = 0;
         }
         ++since_halo;
@@ -200,13 +226,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
             MSD_STAMP(14);                                           // fragments in registers
         }
 #endif
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+        if constexpr (TAPS == 1) {
+            mfma_tap(af, wf);
+        } else {
+            bf16x8 af2[2][MI], wf2[2][NJ];
+            read_tap(1, af2, wf2);
+            mfma_tap(af, wf);
+            read_tap(2, af, wf);
+            mfma_tap(af2, wf2);
+            mfma_tap(af, wf);
+        }
 #ifdef MSD_STAMPS
         if (probe) {
             asm volatile("v_mov_b32 %0, %0" : "+v"(acc[NJ - 1][MI - 1][3]));   // last MFMA of the step has retired
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         }
 #endif
         if (++stage == S) stage = 0;
-        if (++tap == 9) { tap = 0; ++c; hbuf ^= 1; }
+        if (++tap == SPC) { tap = 0; ++c; hbuf ^= 1; }
     }
     MSD_STAMP(3);
     int mrow[MI];
@@ -236,24 +265,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
 //  per MFMA — and a deeper ring for 16x16 x 128: none beat the tiles below on any UNet / VAE shape.)
 // Variant 1 (tile_m 2128): the same tile on 8 waves — two waves per SIMD even when the launch puts a
 // single workgroup on a CU, so one wave's LDS-DMA issue stalls and LDS latency hide under the other's MFMAs.
-#define MSD_HALO_CFGS(X)   \
-    X(8, 64, 2, 2, 3, 0)   \
-    X(8, 128, 2, 4, 3, 0)  \
-    X(16, 128, 4, 2, 3, 0) \
-    X(8, 80, 4, 1, 3, 0)   \
-    X(16, 80, 4, 1, 3, 0)  \
-    X(8, 64, 2, 2, 8, 0)   \
-    X(8, 128, 2, 4, 6, 0)  \
-    X(8, 80, 4, 1, 8, 0)   \
-    X(16, 80, 4, 1, 5, 0)  \
-    X(8, 64, 4, 2, 3, 1)   \
-    X(8, 80, 8, 1, 3, 1)
+// `stages` 30 + depth: 3 taps (one filter row) per K step with a ring of `depth` rows (8x16 tiles x 64 / 80 channels: the
+// ring holds depth x 3 weight tiles).
+#define MSD_HALO_CFGS(X)      \
+    X(8, 64, 2, 2, 3, 0, 1)   \
+    X(8, 128, 2, 4, 3, 0, 1)  \
+    X(16, 128, 4, 2, 3, 0, 1) \
+    X(8, 80, 4, 1, 3, 0, 1)   \
+    X(16, 80, 4, 1, 3, 0, 1)  \
+    X(8, 64, 2, 2, 8, 0, 1)   \
+    X(8, 128, 2, 4, 6, 0, 1)  \
+    X(8, 80, 4, 1, 8, 0, 1)   \
+    X(16, 80, 4, 1, 5, 0, 1)  \
+    X(8, 64, 4, 2, 3, 1, 1)   \
+    X(8, 80, 8, 1, 3, 1, 1)   \
+    X(8, 64, 2, 2, 33, 0, 3)  \
+    X(8, 64, 2, 2, 34, 0, 3)  \
+    X(8, 80, 4, 1, 33, 0, 3)  \
+    X(8, 64, 4, 2, 33, 1, 3)
 
-template <int TH, int BN, int WGM, int WGN, int S>
+template <int TH, int BN, int WGM, int WGN, int SC, int TAPS>
 static constexpr int halo_lds() {
+    constexpr int S = SC % 30;   // (SC = stages code: 30 + depth for the 3-taps-per-step form)
     constexpr int NT = WGM * WGN * 64, RPP = NT / 8, HROWS = (TH + 2) * 18, HR = (HROWS + RPP - 1) / RPP;
     constexpr int BNP = (BN + RPP - 1) / RPP * RPP;
-    constexpr int bytes = 2 * HR * RPP * 128 + S * BNP * 128;
+    constexpr int bytes = 2 * HR * RPP * 128 + S * TAPS * BNP * 128;
     static_assert(bytes <= 160 * 1024, "LDS budget");
     return bytes;
 }
@@ -262,10 +298,10 @@ static bool g_halo_attr_done = false;
 int msd_conv_halo_init() {
     if (g_halo_attr_done) return MSD_OK;
     hipError_t e = hipSuccess;
-#define X(th, bn, wgm, wgn, st, var)                                                                            \
-    if (e == hipSuccess)                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st>),   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st>());
+#define X(th, bn, wgm, wgn, st, var, taps)                                                                             \
+    if (e == hipSuccess)                                                                                              \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st % 30, taps>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st, taps>());
     MSD_HALO_CFGS(X)
 #undef X
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_halo): %s", hipGetErrorString(e));
@@ -281,21 +317,21 @@ int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int varian
     dim3 grid(tiles, slices);
     // `stages` picks the ring depth if that variant is built, otherwise the tile's default (3)
     bool have = false;
-#define X(th_, bn_, wgm, wgn, st, var) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
+#define X(th_, bn_, wgm, wgn, st, var, taps) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
     MSD_HALO_CFGS(X)
 #undef X
     if (!have) {   // unknown ring depth -> the tile's default; unknown 8-wave variant -> the 4-wave tile
         stages = 3;
         have = false;
-#define X(th_, bn_, wgm, wgn, st, var) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
+#define X(th_, bn_, wgm, wgn, st, var, taps) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
         MSD_HALO_CFGS(X)
 #undef X
         if (!have) variant = 0;
     }
-#define X(th_, bn_, wgm, wgn, st, var)                                                                                    \
-    if (th == th_ && bn == bn_ && stages == st && variant == var) {                                                                      \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st>), grid, dim3(wgm * wgn * 64),                      \
-                           (halo_lds<th_, bn_, wgm, wgn, st>()), stream, a);                                              \
+#define X(th_, bn_, wgm, wgn, st, var, taps)                                                                              \
+    if (th == th_ && bn == bn_ && stages == st && variant == var) {                                                       \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps>), grid, dim3(wgm * wgn * 64),          \
+                           (halo_lds<th_, bn_, wgm, wgn, st, taps>()), stream, a);                                        \
         return MSD_OK;                                                                                                    \
     }
     MSD_HALO_CFGS(X)

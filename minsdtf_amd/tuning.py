@@ -24,7 +24,8 @@ TILES = ((128, 128, 0), (128, 64, 0), (64, 64, 0), (64, 128, 0), (256, 128, 0),
          (64, 64, 14), (128, 64, 13), (64, 128, 13),   # stages 10 + depth: the tile on 8 waves
          (128, 128, 23), (128, 128, 24), (128, 64, 24), (64, 128, 24))   # 20 + depth: 64x64 per wave (4 / 2 waves)
 HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (1256, 80, 0),
-              (1128, 64, 8), (1128, 128, 6), (1128, 80, 8), (1256, 80, 5), (2128, 64, 0), (2128, 80, 0))
+              (1128, 64, 8), (1128, 128, 6), (1128, 80, 8), (1256, 80, 5), (2128, 64, 0), (2128, 80, 0),
+              (1128, 64, 33), (1128, 64, 34), (1128, 80, 33), (2128, 64, 33))   # 30 + depth: 3 taps (a filter row) per K step
 
 
 def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=True, cx=0) -> str:

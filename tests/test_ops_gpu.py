@@ -81,6 +81,12 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=1, H=12, W=20, c0=64, N=100, ks=1, tile_m=64, tile_n=64),                  # DENSE loader: M and N tails inside one tile
     dict(B=2, H=16, W=16, c0=128, N=128, ks=3, stride=2, asym=True),                 # VAE encoder downsampler: pad bottom/right only
     dict(B=1, H=10, W=18, c0=64, N=192, ks=3, stride=2, asym=True, splitk=3, tile_m=64, tile_n=64),
+    # halo kernel, 3 taps (one filter row) per K step: stages 30 + ring depth
+    dict(B=2, H=16, W=16, c0=192, N=128, ks=3, tile_m=1128, tile_n=64, stages=33, same_as=(1128, 64, 0)),
+    dict(B=1, H=16, W=32, c0=64, c1=64, N=100, ks=3, tile_m=1128, tile_n=64, stages=34, same_as=(1128, 64, 0)),
+    dict(B=2, H=8, W=16, c0=320, N=320, ks=3, tile_m=1128, tile_n=80, stages=33, same_as=(1128, 80, 0)),
+    dict(B=2, H=16, W=16, c0=128, N=192, ks=3, tile_m=2128, tile_n=64, stages=33, same_as=(1128, 64, 0)),
+    dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, stages=33, splitk=2),       # + split over chunks
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing
@@ -127,6 +133,14 @@ def test_conv_gemm(gpu, case):
                          **(dict(pad=0, pad_end=1) if asym else {}))
     run_calls(call)
     close(out.reshape(B, Ho, Wo, N), ref, what=str(case))
+    if case.get("same_as"):   # tile shape / kernel form never changes a result's bits (K tiles are summed in the same order)
+        tm, tn, stg = case["same_as"]
+        out2 = torch.full_like(out, float("nan"))
+        run_calls(ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=wp, out=out2, batch=B, h_in=H, w_in=W, c0=c0, N=N, ksize=ks, stride=stride,
+                                upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N, rv_batch_stride=N, step_ptr=step,
+                                residual=resid.to(torch.bfloat16).to(d), act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
+                                out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, tile_n=tn, tile_m=tm, stages=stg))
+        assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "tile shape changed the bits"
 
 
 @pytest.mark.parametrize("case", [
@@ -190,6 +204,8 @@ def test_conv_gemm_geglu(gpu):
     dict(M=128, C=640, tile=(64, 64, 0), mode="geglu"),        # 10 partials per row, GEGLU consumer
     dict(M=130, C=1280, tile=(64, 64, 14), mode="dense"),      # 20 partials per row (the maximum), 8-wave producer
     dict(M=256, C=320, tile=(64, 128, 24), mode="dense"),      # one slab per tile
+    dict(M=200, C=320, tile=(128, 80, 0), mode="geglu", ctile=(128, 128, 0)),     # consumer tiles chosen explicitly
+    dict(M=136, C=640, tile=(64, 64, 0), mode="qkv", ctile=(64, 128, 13)),
 ])
 def test_conv_gemm_layer_norm_fold(gpu, case):
     """LayerNormalization folded into the GEMMs around it (diffusion_model.py:84-88 + Dense): the producer
@@ -200,6 +216,8 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
     torch.manual_seed(11)
     M, C = case["M"], case["C"]
     tm, tn, stg = case["tile"]
+    ctm, ctn, cstg = case.get("ctile", (0, 0, 0))
+    ckw = dict(tile_m=ctm, tile_n=ctn, stages=cstg)
     x = bf(torch.randn(M, C))
     res = bf(torch.randn(M, C) * 2 + 0.5)                      # non-zero row means
     w0 = bf(torch.randn(C, C) / math.sqrt(C))
@@ -226,7 +244,7 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
         wf, cs, cb = packing.fold_layer_norm(w1.t().contiguous()[order], b1.numpy()[order.numpy()], gamma.numpy(), beta.numpy(), d)
         out = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device=d)
         cons = ops.conv_gemm(a0=tdev, w=wf, out=out, batch=1, h_in=M, w_in=1, c0=C, N=8 * C, bias=cb, act=ops.ACT_GEGLU,
-                             ln_in=stats, ln_in_slots=slots, ln_colsum=cs)
+                             ln_in=stats, ln_in_slots=slots, ln_colsum=cs, **ckw)
         run_calls([prod, cons])
         close(out, ref, atol=2e-2 * float(ref.abs().max()), what=str(case))
     elif mode == "qkv":
@@ -238,7 +256,7 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
         sp = (M + 7) // 8 * 8
         vt = torch.zeros((1, C, sp), dtype=torch.bfloat16, device=d)
         cons = ops.conv_gemm(a0=tdev, w=wf, out=q, batch=1, h_in=M, w_in=1, c0=C, N=3 * C, bias=cb, split=(C, C, k, C, vt, sp),
-                             ln_in=stats, ln_in_slots=slots, ln_colsum=cs)
+                             ln_in=stats, ln_in_slots=slots, ln_colsum=cs, **ckw)
         run_calls([prod, cons])
         atol = 2e-2 * float(ref.abs().max())
         close(q, ref[:, :C], atol=atol, what=str(case) + " q")
@@ -251,7 +269,7 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
         wf, cs, cb = packing.fold_layer_norm(w1.t().contiguous(), b1.numpy(), gamma.numpy(), beta.numpy(), d)
         out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
         cons = ops.conv_gemm(a0=tdev, w=wf, out=out, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=cb, ln_in=stats, ln_in_slots=slots,
-                             ln_colsum=cs)
+                             ln_colsum=cs, **ckw)
         run_calls([prod, cons])
         close(out, ref, atol=2e-2 * float(ref.abs().max()), what=str(case))
     close(tdev, t, what=str(case) + " producer output")
