@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 5
+#define MSD_ABI_VERSION 6
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -130,6 +130,11 @@ typedef struct MsdConvGemm {
     const void* a2;          /* bf16 [batch][h_out][w_out][c2] or NULL */
     const void* a3;          /* bf16 [batch][h_out][w_out][c3] or NULL (channel concat a2|a3) */
     int32_t c2, c3;
+    /* Storage order of w.  0: [N][K] rows.  1: chunk-major [K/64][N][64] — the 64-element K chunk kc of ALL output
+     * columns is one contiguous N x 128-byte run, so the weight tile of a K step (any tile_n, any column offset) is a
+     * single contiguous block of HBM instead of tile_n pieces of 128 bytes K*2 bytes apart (the packed form the
+     * models keep; same values, same K order, same results). */
+    int32_t w_layout;
 } MsdConvGemm;
 
 /* Number of row-moment partials per row a launch with these parameters writes to `ln_out`

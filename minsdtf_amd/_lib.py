@@ -15,7 +15,7 @@ import weakref
 LIB_NAME = "libminsdtf_hip.so"
 # $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
 LIB_PATH = os.environ.get("MSD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -38,7 +38,7 @@ class MsdConvGemm(C.Structure):
         ("out2_ld", C.c_int32), ("splitk", C.c_int32), ("tile_n", C.c_int32), ("tile_m", C.c_int32), ("stages", C.c_int32),
         ("ln_in", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_out", C.c_void_p),
         ("ln_in_slots", C.c_int32), ("ln_out_slots", C.c_int32), ("ln_eps", C.c_float),
-        ("a2", C.c_void_p), ("a3", C.c_void_p), ("c2", C.c_int32), ("c3", C.c_int32),
+        ("a2", C.c_void_p), ("a3", C.c_void_p), ("c2", C.c_int32), ("c3", C.c_int32), ("w_layout", C.c_int32),
     ]
 
 

@@ -13,12 +13,14 @@ struct CGArgs {
                            // grid-size arguments: that is a second, dependent scalar-memory round trip at kernel start)
     int tiles_m, m_fast;   // m_fast: consecutive tiles (= same XCD) share the WEIGHT rows instead of the pixel rows
     int act, out_f32, out_ld, res_ld, rv_step_stride, rv_batch_stride;
+    int vec16;             // rows of out / out1 / residual are 16-byte aligned (and split parts multiples of 16 columns): 16-byte epilogue form
     int split_mode, ns0, ns1, out1_ld, out2_ld;
     uint32_t mg_tdiv, mg_hw, mg_w, mg_tps, mg_tx, mg_nkc;   // floor(2^32 / d) for d = tile-mapping divisor, hw_out, w_out, tiles per sample, tiles per row (udiv_magic)
     const bf16_t* a2; const bf16_t* a3; int c2, nk_main;         // shortcut operand: K tiles >= nk_main read a2|a3 at the output pixel
     const float* ln_in; const float* ln_colsum; float* ln_out;   // LayerNorm fold (minsdtf_hip.h)
     int ln_in_slots, ln_out_slots;
     float ln_eps, ln_inv_k;
+    uint32_t w_rs, w_ks;   // weight addressing in bytes: row (output column) stride, K-chunk stride ([N][K]: 2K, 128; chunk-major: 128, 128 N)
 };
 
 static __device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows (one copy per TU)
@@ -88,20 +90,33 @@ __device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, 
     }
 }
 
-// Whole-wave epilogue: lane (r = lane&15, g = lane>>4) holds, per (j, i), output channels
-// n..n+3 (n = nbase + 16j + 4g) of pixel m (= mbase + 16i + r).
+// Whole-wave epilogue.  Fragment map: the weight rows of a 16-column block are read into the MFMA in the order
+// 0-3, 8-11, 4-7, 12-15 (cg_wrow below), so lane (r = lane & 15, g = lane >> 4) holds, per (j, i), the 4 output channels
+// n .. n+3, n = nbase + 16 j + cg_col(g), cg_col = {0, 8, 4, 12}, of pixel m = mrow[i] + r.  Lanes l and l + 32 then hold
+// the two halves of one 8-channel run, and ONE v_permlane32_swap per register turns the accumulators of two row
+// fragments (i, i + 1) into 8 consecutive channels of one pixel per lane — the lower half-wave for fragment i, the upper
+// one for i + 1 — which are stored (and whose residual is loaded) with 16-byte instead of 8-byte vectors: half the
+// store / load instructions of the epilogue, whose tail is bound by store ISSUE, not bandwidth (in-kernel stamps;
+// cdna_hip_programming.md T21).  Which lane holds which channel does not change any value.
 // Rows: fragment i of the wave covers pixels mrow[i] + r (r = 0..15), so a spatially blocked tile
 // (conv_halo) and a linear one (conv_gemm: mrow[i] = mbase + 16 i) share the epilogue.
 constexpr int LN_MAX_SLOTS = 20;   // row-moment partials per row (column tiles of the producing launch)
+__device__ __forceinline__ int cg_wrow(int r) { return (r & 3) | ((r & 4) << 1) | ((r & 8) >> 1); }   // MFMA row -> weight row of the block
+__device__ __forceinline__ int cg_col(int g) { return ((g & 1) << 3) | ((g & 2) << 1); }
 // `lnred` (with ln_out): LDS scratch of WGN x BM float2, free for reuse (the caller has passed a barrier after
 // its last fragment read); `wn` / `wgn`: this wave's column slab and the number of slabs; `row0`: first row
 // of the wave's tile inside the workgroup tile; `tile_n`: column tile index = the partial's slot.
 // UB: every row of the workgroup's tile belongs to ONE sample (the spatial tiles of conv_halo), so the time-embedding
 // row is loaded once per column group instead of per (row fragment, column group): 48 fewer live registers on the
 // 64x64-per-wave tile, which otherwise spills.
-template <int MI, int NJ, bool UB = false>
+// DF (dense form): the 1x1 / Dense kernel's epilogue carries the LayerNorm-fold consumer (ln_in), the GEGLU gate and the
+// q | k | v^T split — none of which a 3x3 / strided / upsampling conv ever has — and no time-embedding row (rowvec: only
+// ever the 3x3 conv1 of a ResBlock); the general and halo kernels' epilogue (DF = false) is the reverse.  Neither form
+// pays registers or instruction-cache lines for the other's cases (the host routes each launch to the form it needs).
+template <int MI, int NJ, bool UB = false, bool DF = true>
 __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI], const int (&mrow)[MI], int nbase, int r, int g,
                                             float* lnred = nullptr, int wn = 0, int wgn = 1, int row0 = 0, int bm = 0, int tile_n = 0) {
+    const int cgo = cg_col(g);
     if (p.nslices > 1) {
         float* ws = p.ws + (size_t)blockIdx.y * p.M * p.N;
 #pragma unroll
@@ -110,7 +125,7 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int n = nbase + j * 16 + 4 * g;
+                const int n = nbase + j * 16 + cgo;
                 if (n >= p.N) continue;
                 *reinterpret_cast<float4*>(ws + (size_t)m * p.N + n) =
                     make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
@@ -119,6 +134,21 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
         return;
     }
     const int step = p.step_ptr ? *p.step_ptr : 0;
+    // 16-byte form: needs fragment pairs and 16-byte aligned rows (host: p.vec16); the lane's row / 8-channel run after the swap
+    constexpr int MP = MI / 2;
+    const bool v16 = (MI % 2 == 0) && p.vec16;
+    const int cg8 = (g & 1) << 3;
+    int msw[MP > 0 ? MP : 1];
+#pragma unroll
+    for (int ip = 0; ip < MP; ++ip) msw[ip] = (g < 2 ? mrow[2 * ip] : mrow[2 * ip + 1]) + r;
+    auto swap8 = [&](const float (&a)[4], const float (&b)[4], float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[e]), __float_as_uint(b[e]), false, false);
+            v[e] = __uint_as_float(sw[0]);       // lower half-wave: own a[e]; upper: b[e] of lane - 32 (channels cgo - 4 + e)
+            v[4 + e] = __uint_as_float(sw[1]);   // lower: a[e] of lane + 32 (channels cgo + 4 + e); upper: own b[e]
+        }
+    };
     // Two passes: every load of the epilogue first, then the arithmetic and the stores.  `out` may alias
     // `residual` as far as the compiler knows, so in a single pass each group's loads wait behind the
     // previous group's store: MI x NJ serial memory round trips (in-kernel stamps: 4.4 us of a 9 us launch
@@ -130,16 +160,17 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
     float4 bv[NJ];
     if (p.bias) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + min(nbase + j * 16 + 4 * g, p.N - 4));
+        for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + min(nbase + j * 16 + cgo, p.N - 4));
     } else {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // LayerNorm fold, consumer side: partial row moments (lane group g takes slots g, g+4, ...) and column sums
     constexpr int LNS = LN_MAX_SLOTS / 4;
-    float2 lnp[MI][LNS];
+    constexpr bool LN = DF, RV = !DF;
+    float2 lnp[LN ? MI : 1][LNS];
     float4 lcs[NJ];
-    if (p.ln_in) {
+    if (LN && p.ln_in) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const float2* src = reinterpret_cast<const float2*>(p.ln_in) + (size_t)min(mrow[i] + r, p.M - 1) * p.ln_in_slots;
@@ -147,10 +178,10 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
             for (int k = 0; k < LNS; ++k) lnp[i][k] = src[min(g + 4 * k, p.ln_in_slots - 1)];   // (clamped: masked below)
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) lcs[j] = *reinterpret_cast<const float4*>(p.ln_colsum + min(nbase + j * 16 + 4 * g, p.N - 4));
+        for (int j = 0; j < NJ; ++j) lcs[j] = *reinterpret_cast<const float4*>(p.ln_colsum + min(nbase + j * 16 + cgo, p.N - 4));
     }
     auto ln_apply = [&]() {   // after the vmcnt(0): acc <- rstd * (acc - mean * colsum)
-        if (!p.ln_in) return;
+        if (!LN || !p.ln_in) return;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             float s1 = 0.f, s2 = 0.f;
@@ -170,8 +201,10 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
             }
         }
     };
-    if (p.act == MSD_ACT_GEGLU) {
-        if constexpr (NJ % 2 == 0) {   // (x|gate pairs: the host never sends GEGLU to an odd-NJ tile)
+    if (DF && p.act == MSD_ACT_GEGLU) {
+        if constexpr (DF && NJ % 2 == 0) {   // (x|gate pairs: the host never sends GEGLU to an odd-NJ tile)
+            // (GEGLU launches carry no residual in this pipeline; one is still honoured on the 8-byte path)
+            const bool g16 = v16 && !p.residual;
             uint2 rr[MI][NJ / 2];
             if (p.residual) {
 #pragma unroll
@@ -179,7 +212,7 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
                     const size_t mo = (size_t)min(mrow[i] + r, p.M - 1) * p.res_ld;
 #pragma unroll
                     for (int j = 0; j < NJ; j += 2)
-                        rr[i][j / 2] = *reinterpret_cast<const uint2*>(p.residual + mo + min(((nbase + j * 16) >> 1) + 4 * g, (p.N >> 1) - 4));
+                        rr[i][j / 2] = *reinterpret_cast<const uint2*>(p.residual + mo + min(((nbase + j * 16) >> 1) + cgo, (p.N >> 1) - 4));
                 }
             } else {
 #pragma unroll
@@ -189,174 +222,298 @@ __device__ __forceinline__ void cg_epilogue(const CGArgs& p, f32x4 (&acc)[NJ][MI
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every epilogue load has landed
             ln_apply();
+            auto gl4 = [&](int i, int j, float (&v)[4]) {   // x columns nb + [0,16), gate nb + 16 + [0,16): same channel map in both
+                v[0] = geglu_f(acc[j][i][0] + bv[j].x, acc[j + 1][i][0] + bv[j + 1].x);
+                v[1] = geglu_f(acc[j][i][1] + bv[j].y, acc[j + 1][i][1] + bv[j + 1].y);
+                v[2] = geglu_f(acc[j][i][2] + bv[j].z, acc[j + 1][i][2] + bv[j + 1].z);
+                v[3] = geglu_f(acc[j][i][3] + bv[j].w, acc[j + 1][i][3] + bv[j + 1].w);
+            };
+            if (g16) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = mrow[i] + r;
-                if (m >= p.M) continue;
+                for (int ip = 0; ip < MP; ++ip)
 #pragma unroll
-                for (int j = 0; j < NJ; j += 2) {
-                    const int nb = nbase + j * 16;  // multiple of 32: x columns nb+[0,16), gate nb+16+[0,16)
-                    if (nb + 4 * g >= p.N) continue;
-                    float v[4];
-                    v[0] = geglu_f(acc[j][i][0] + bv[j].x, acc[j + 1][i][0] + bv[j + 1].x);
-                    v[1] = geglu_f(acc[j][i][1] + bv[j].y, acc[j + 1][i][1] + bv[j + 1].y);
-                    v[2] = geglu_f(acc[j][i][2] + bv[j].z, acc[j + 1][i][2] + bv[j + 1].z);
-                    v[3] = geglu_f(acc[j][i][3] + bv[j].w, acc[j + 1][i][3] + bv[j + 1].w);
-                    const int no = (nb >> 1) + 4 * g;
-                    const uint2 q = rr[i][j / 2];
-                    v[0] += bf_lo(q.x); v[1] += bf_hi(q.x); v[2] += bf_lo(q.y); v[3] += bf_hi(q.y);
-                    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
+                    for (int j = 0; j < NJ; j += 2) {
+                        float a[4], b[4], v[8];
+                        gl4(2 * ip, j, a);
+                        gl4(2 * ip + 1, j, b);
+                        swap8(a, b, v);
+                        const int no = ((nbase + j * 16) >> 1) + cg8;
+                        if (msw[ip] >= p.M || no >= (p.N >> 1)) continue;
+                        bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)msw[ip] * p.out_ld + no;
+                        if (no + 8 <= (p.N >> 1)) *reinterpret_cast<uint4*>(dst) = pack8(v);
+                        else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int m = mrow[i] + r;
+                    if (m >= p.M) continue;
+#pragma unroll
+                    for (int j = 0; j < NJ; j += 2) {
+                        const int nb = nbase + j * 16;  // multiple of 32
+                        if (nb + cgo >= p.N) continue;
+                        float v[4];
+                        gl4(i, j, v);
+                        const int no = (nb >> 1) + cgo;
+                        const uint2 q = rr[i][j / 2];
+                        v[0] += bf_lo(q.x); v[1] += bf_hi(q.x); v[2] += bf_lo(q.y); v[3] += bf_hi(q.y);
+                        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + no) = o;
+                    }
                 }
             }
         }
         return;
     }
-    const bool plain_res = p.split_mode == 0 && p.residual != nullptr;
-    uint2 rr[MI][NJ];
-    constexpr int RI = UB ? 1 : MI;
-    float4 rv[RI][NJ];
+    const int split_mode = DF ? p.split_mode : 0;
+    const bool plain_res = split_mode == 0 && p.residual != nullptr;
+    const bool compact = split_mode == 0 && !p.out_f32 && p.act == MSD_ACT_NONE;
+    const bool c16 = v16 && compact;                                  // plain bf16 output, 16-byte stores
+    const bool s16 = v16 && split_mode != 0 && p.act == MSD_ACT_NONE;   // q | k parts of the split epilogue (ns0, ns1 multiples of 16: host)
+    // Time-embedding row (one per SAMPLE): when all rows of the wave's fragments lie in one sample — always for the spatial
+    // tiles (UB) and for every linear tile except a 128-row one at the 8x8 level — it is ONE float4 per column group,
+    // loaded with the batch below; otherwise (rare) the fragments add theirs one at a time after the batch (rv_slow).
+    // (A per-fragment array costs 64 registers on the 64x64-per-wave tiles, which sit at the register limit.)
     int bidx[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) bidx[i] = (p.rowvec || p.split_mode) ? udiv_magic(min(mrow[i] + r, p.M - 1), p.hw_out, p.mg_hw) : 0;
-    if (plain_res) {
+    for (int i = 0; i < MI; ++i) bidx[i] = ((RV && p.rowvec) || split_mode) ? udiv_magic(min(mrow[i] + r, p.M - 1), p.hw_out, p.mg_hw) : 0;
+    const int b_first = UB ? bidx[0] : udiv_magic(min(mrow[0], p.M - 1), p.hw_out, p.mg_hw);
+    const int b_last = UB ? bidx[0] : udiv_magic(min(mrow[MI - 1] + 15, p.M - 1), p.hw_out, p.mg_hw);
+    const bool rv_one = RV && p.rowvec && b_first == b_last, rv_slow = RV && p.rowvec && !rv_one;   // (wave-uniform)
+    float4 rv[NJ];
+    if (rv_one) {
+        const float* rvp = p.rowvec + (size_t)step * p.rv_step_stride + (size_t)b_first * p.rv_batch_stride;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const size_t mo = (size_t)min(mrow[i] + r, p.M - 1) * p.res_ld;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                rr[i][j] = *reinterpret_cast<const uint2*>(p.residual + mo + min(nbase + j * 16 + 4 * g, p.N - 4));
-        }
+        for (int j = 0; j < NJ; ++j) rv[j] = *reinterpret_cast<const float4*>(rvp + min(nbase + j * 16 + cgo, p.N - 4));
     } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) rv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    MSD_STAMP_DRAIN();
+    MSD_STAMP(6);
+    // ln_out (LayerNorm fold, producer side): moments of the ROUNDED values this launch stores, per row and column tile.
+    // Canonical order, independent of the wave layout and of the 8- / 16-byte form (a sample's bits must not depend on
+    // launch parameters that are tuned per batch): per 16-column block (s[0..3] + s[4..7]) + (s[8..11] + s[12..15]) with
+    // s[c..c+3] = (q0 + q1) + (q2 + q3), written to LDS per (row, block); then the blocks of the column tile in ascending
+    // order (below).  The cross-lane adds are row swaps (VALU), not LDS shuffles.
+    const int nb16 = wgn * NJ;   // 16-column blocks of the workgroup's column tile
+    if (p.ln_out) __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the ring can be reused
+    auto xadd16 = [](float x) {
+        auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    };
+    auto xadd32 = [](float x) {
+        auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+    };
+    auto ln_put = [&](int i, int j, float s1, float s2) {   // s1, s2: the block's sums, complete on the calling lane
+        float* dst = lnred + ((size_t)(row0 + i * 16 + r) * nb16 + wn * NJ + j) * 2;
+        dst[0] = s1; dst[1] = s2;
+    };
+    // bias + time-embedding row go INTO the accumulators as soon as the loads have landed (add_bias_rowvec, called after
+    // the vmcnt(0) of either form): their registers (up to 80 on the 64x64-per-wave tiles) are dead before the swaps,
+    // packs and stores begin
+    auto add_bias_rowvec = [&]() {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) rr[i][j] = make_uint2(0, 0);
-    }
-    if (p.rowvec) {
+            for (int j = 0; j < NJ; ++j) {
+                acc[j][i][0] = (acc[j][i][0] + bv[j].x) + rv[j].x; acc[j][i][1] = (acc[j][i][1] + bv[j].y) + rv[j].y;
+                acc[j][i][2] = (acc[j][i][2] + bv[j].z) + rv[j].z; acc[j][i][3] = (acc[j][i][3] + bv[j].w) + rv[j].w;
+            }
+        if (rv_slow) {   // rows of the wave in more than one sample: per-fragment rows, one round trip each
 #pragma unroll
-        for (int i = 0; i < RI; ++i) {
-            const float* rvp = p.rowvec + (size_t)step * p.rv_step_stride + (size_t)bidx[i] * p.rv_batch_stride;
+            for (int i = 0; i < MI; ++i) {
+                const float* rvp = p.rowvec + (size_t)step * p.rv_step_stride + (size_t)bidx[i] * p.rv_batch_stride;
+                float4 t[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) rv[i][j] = *reinterpret_cast<const float4*>(rvp + min(nbase + j * 16 + 4 * g, p.N - 4));
+                for (int j = 0; j < NJ; ++j) t[j] = *reinterpret_cast<const float4*>(rvp + min(nbase + j * 16 + cgo, p.N - 4));
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { acc[j][i][0] += t[j].x; acc[j][i][1] += t[j].y; acc[j][i][2] += t[j].z; acc[j][i][3] += t[j].w; }
+            }
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < RI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) rv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every epilogue load has landed
-    ln_apply();
-    float ls1[MI], ls2[MI];   // ln_out: this wave's partial row moments of the values it stores
-#pragma unroll
-    for (int i = 0; i < MI; ++i) { ls1[i] = 0.f; ls2[i] = 0.f; }
-    MSD_STAMP_DRAIN();
-    MSD_STAMP(6);
+    };
+    auto pre4 = [&](int i, int j, float (&v)[4]) { v[0] = acc[j][i][0]; v[1] = acc[j][i][1]; v[2] = acc[j][i][2]; v[3] = acc[j][i][3]; };
+    // Two complete forms, chosen by one wave-uniform branch, each with its own residual registers (so the register peak is
+    // the larger of the two, not their sum: the 64x64-per-wave tiles sit at the 256-register limit).
     // The common case (plain mode, bf16 output, no activation: every residual / LayerNorm-producer / shortcut GEMM and
     // the second conv of a ResBlock) takes a compact straight-line path of its own instead of threading through the
-    // branches of every other mode (in-kernel stamps: arithmetic + store issue 0.72 -> 0.48 us on the 64x64 tile, 1.92 ->
-    // 1.68 us on 128x128; a kernel starts with a cold instruction cache and the generic loop touches several times
-    // more instruction lines than this case executes).
-    if (p.split_mode == 0 && !p.out_f32 && p.act == MSD_ACT_NONE) {
+    // branches of every other mode (a kernel starts with a cold instruction cache and the generic loop touches several
+    // times more instruction lines than this case executes).
+    if (c16) {
+        uint4 rr16[MP > 0 ? MP : 1][NJ];
+        if (plain_res) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = mrow[i] + r;
+            for (int ip = 0; ip < MP; ++ip) {
+                const size_t mo = (size_t)min(msw[ip], p.M - 1) * p.res_ld;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    rr16[ip][j] = *reinterpret_cast<const uint4*>(p.residual + mo + min(nbase + j * 16 + cg8, p.N - 8));
+            }
+        } else {
+#pragma unroll
+            for (int ip = 0; ip < MP; ++ip)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) rr16[ip][j] = make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every epilogue load has landed
+        ln_apply();
+        add_bias_rowvec();
+        // the half-wave exchange IN PLACE (acc[j][2 ip] <- channels run .. run+3, acc[j][2 ip + 1] <- run+4 .. run+7 of the
+        // lane's row): no second copy of the tile's values is ever live
+#pragma unroll
+        for (int ip = 0; ip < MP; ++ip)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[j][2 * ip][e]), __float_as_uint(acc[j][2 * ip + 1][e]), false, false);
+                    acc[j][2 * ip][e] = __uint_as_float(sw[0]);
+                    acc[j][2 * ip + 1][e] = __uint_as_float(sw[1]);
+                }
+#pragma unroll
+        for (int ip = 0; ip < MP; ++ip)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int n = nbase + j * 16 + 4 * g;
-                if (m >= p.M || n >= p.N) continue;
-                const float v0 = acc[j][i][0] + bv[j].x + rv[UB ? 0 : i][j].x + bf_lo(rr[i][j].x);
-                const float v1 = acc[j][i][1] + bv[j].y + rv[UB ? 0 : i][j].y + bf_hi(rr[i][j].x);
-                const float v2 = acc[j][i][2] + bv[j].z + rv[UB ? 0 : i][j].z + bf_lo(rr[i][j].y);
-                const float v3 = acc[j][i][3] + bv[j].w + rv[UB ? 0 : i][j].w + bf_hi(rr[i][j].y);
-                uint2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
-                if (p.ln_out) {   // moments of the ROUNDED values: what a LayerNorm reading `out` would see
-                    const float q0 = bf_lo(o.x), q1 = bf_hi(o.x), q2 = bf_lo(o.y), q3 = bf_hi(o.y);
-                    ls1[i] += (q0 + q1) + (q2 + q3);
-                    ls2[i] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                float v[8], q[8];
+                unpack8(rr16[ip][j], q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[j][2 * ip][e] + q[e]; v[4 + e] = acc[j][2 * ip + 1][e] + q[4 + e]; }
+                const uint4 o = pack8(v);
+                const int n8 = nbase + j * 16 + cg8;
+                const bool lo = msw[ip] < p.M && n8 < p.N, hi = lo && n8 + 8 <= p.N;   // (N % 4 == 0: a run cut by the edge keeps its first 4 channels)
+                bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)msw[ip] * p.out_ld + n8;
+                if (hi) *reinterpret_cast<uint4*>(dst) = o;
+                else if (lo) *reinterpret_cast<uint2*>(dst) = make_uint2(o.x, o.y);
+                if (p.ln_out) {   // (every lane takes part in the row swap of xadd16: predicated values, no early exit)
+                    unpack8(o, q);
+                    float s1 = (lo ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f) + (hi ? (q[4] + q[5]) + (q[6] + q[7]) : 0.f);
+                    float s2 = (lo ? (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]) : 0.f) +
+                               (hi ? (q[4] * q[4] + q[5] * q[5]) + (q[6] * q[6] + q[7] * q[7]) : 0.f);
+                    s1 = xadd16(s1); s2 = xadd16(s2);                        // the two 8-channel halves of the block
+                    if ((g & 1) == 0) ln_put(2 * ip + (g >> 1), j, s1, s2);  // lower half-wave: fragment 2 ip, upper: 2 ip + 1
                 }
             }
-        }
-    } else
+    } else {
+        uint2 rr[MI][NJ];
+        if (plain_res) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = mrow[i] + r;
-        if (m >= p.M) continue;
-        const int b = bidx[i];
+            for (int i = 0; i < MI; ++i) {
+                const size_t mo = (size_t)min(mrow[i] + r, p.M - 1) * p.res_ld;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = nbase + j * 16 + 4 * g;
-            if (n >= p.N) continue;
-            float v[4] = {acc[j][i][0] + bv[j].x + rv[UB ? 0 : i][j].x, acc[j][i][1] + bv[j].y + rv[UB ? 0 : i][j].y,
-                          acc[j][i][2] + bv[j].z + rv[UB ? 0 : i][j].z, acc[j][i][3] + bv[j].w + rv[UB ? 0 : i][j].w};
-            if (p.act == MSD_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            } else if (p.act == MSD_ACT_QUICK_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_rcp(1.0f + __expf(-1.702f * v[e]));
+                for (int j = 0; j < NJ; ++j)
+                    rr[i][j] = *reinterpret_cast<const uint2*>(p.residual + mo + min(nbase + j * 16 + cgo, p.N - 4));
             }
-            if (p.split_mode == 0) {
-                v[0] += bf_lo(rr[i][j].x); v[1] += bf_hi(rr[i][j].x); v[2] += bf_lo(rr[i][j].y); v[3] += bf_hi(rr[i][j].y);
-                if (p.out_f32) {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) rr[i][j] = make_uint2(0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every epilogue load has landed
+        ln_apply();
+        add_bias_rowvec();
+        if (compact) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = mrow[i] + r;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = nbase + j * 16 + cgo;
+                    const bool ok = m < p.M && n < p.N;
+                    float v[4];
+                    pre4(i, j, v);
+                    v[0] += bf_lo(rr[i][j].x); v[1] += bf_hi(rr[i][j].x); v[2] += bf_lo(rr[i][j].y); v[3] += bf_hi(rr[i][j].y);
                     uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
-                    if (p.ln_out) {   // moments of the ROUNDED values: what a LayerNorm reading `out` would see
+                    if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+                    if (p.ln_out) {   // (every lane takes part in the row swaps: predicated values, no early exit)
                         const float q0 = bf_lo(o.x), q1 = bf_hi(o.x), q2 = bf_lo(o.y), q3 = bf_hi(o.y);
-                        ls1[i] += (q0 + q1) + (q2 + q3);
-                        ls2[i] += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+                        float s1 = ok ? (q0 + q1) + (q2 + q3) : 0.f;
+                        float s2 = ok ? (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3) : 0.f;
+                        s1 = xadd32(s1); s2 = xadd32(s2);   // channels [0,4) + [4,8) (lane groups 0, 2) and [8,12) + [12,16) (1, 3)
+                        s1 = xadd16(s1); s2 = xadd16(s2);
+                        if (g == 0) ln_put(i, j, s1, s2);
                     }
                 }
-            } else {
-                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                if (n < p.ns0) {
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
-                } else if (n < p.ns0 + p.ns1) {
-                    *reinterpret_cast<uint2*>(p.out1 + (size_t)m * p.out1_ld + (n - p.ns0)) = o;
-                } else {
-                    const int nv = p.N - p.ns0 - p.ns1;
-                    const int nn = n - p.ns0 - p.ns1;
-                    const int sidx = m - b * p.hw_out;
-                    bf16_t* dst = p.out2 + ((size_t)b * nv + nn) * p.out2_ld + sidx;
-                    dst[0] = (bf16_t)(o.x & 0xFFFF);
-                    dst[(size_t)p.out2_ld] = (bf16_t)(o.x >> 16);
-                    dst[(size_t)2 * p.out2_ld] = (bf16_t)(o.y & 0xFFFF);
-                    dst[(size_t)3 * p.out2_ld] = (bf16_t)(o.y >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nb = nbase + j * 16;
+                // q | k parts of the split epilogue on the 16-byte form (a 16-column block lies in ONE part: ns0, ns1 % 16 == 0)
+                if (s16 && nb < p.ns0 + p.ns1) {
+#pragma unroll
+                    for (int ip = 0; ip < MP; ++ip) {
+                        float a[4], b[4], v[8];
+                        pre4(2 * ip, j, a);
+                        pre4(2 * ip + 1, j, b);
+                        swap8(a, b, v);
+                        const int n8 = nb + cg8;
+                        if (msw[ip] >= p.M) continue;
+                        bf16_t* dst = n8 < p.ns0 ? reinterpret_cast<bf16_t*>(p.out) + (size_t)msw[ip] * p.out_ld + n8
+                                                 : p.out1 + (size_t)msw[ip] * p.out1_ld + (n8 - p.ns0);
+                        *reinterpret_cast<uint4*>(dst) = pack8(v);
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int m = mrow[i] + r;
+                    const int n = nb + cgo;
+                    if (m >= p.M || n >= p.N) continue;
+                    const int b = bidx[i];
+                    float v[4];
+                    pre4(i, j, v);
+                    if (p.act == MSD_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    } else if (p.act == MSD_ACT_QUICK_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_rcp(1.0f + __expf(-1.702f * v[e]));
+                    }
+                    if (split_mode == 0) {
+                        v[0] += bf_lo(rr[i][j].x); v[1] += bf_hi(rr[i][j].x); v[2] += bf_lo(rr[i][j].y); v[3] += bf_hi(rr[i][j].y);
+                        if (p.out_f32) {
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n) =
+                                make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+                        }
+                    } else {
+                        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                        if (n < p.ns0) {
+                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+                        } else if (n < p.ns0 + p.ns1) {
+                            *reinterpret_cast<uint2*>(p.out1 + (size_t)m * p.out1_ld + (n - p.ns0)) = o;
+                        } else {
+                            const int nv = p.N - p.ns0 - p.ns1;
+                            const int nn = n - p.ns0 - p.ns1;
+                            const int sidx = m - b * p.hw_out;
+                            bf16_t* dst = p.out2 + ((size_t)b * nv + nn) * p.out2_ld + sidx;
+                            dst[0] = (bf16_t)(o.x & 0xFFFF);
+                            dst[(size_t)p.out2_ld] = (bf16_t)(o.x >> 16);
+                            dst[(size_t)2 * p.out2_ld] = (bf16_t)(o.y & 0xFFFF);
+                            dst[(size_t)3 * p.out2_ld] = (bf16_t)(o.y >> 16);
+                        }
+                    }
                 }
             }
         }
     }
     MSD_STAMP(7);
-    if (p.ln_out) {
-        __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the ring can be reused
-        // lanes of one row (g = 0..3) -> wave partial; the WGN column slabs of the workgroup are summed in
-        // slab order by the wn == 0 wave through LDS -> one (sum, sumsq) per row and column tile
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            ls1[i] += __shfl_xor(ls1[i], 16); ls2[i] += __shfl_xor(ls2[i], 16);
-            ls1[i] += __shfl_xor(ls1[i], 32); ls2[i] += __shfl_xor(ls2[i], 32);
-            if (g == 0) {
-                lnred[((size_t)wn * bm + row0 + i * 16 + r) * 2 + 0] = ls1[i];
-                lnred[((size_t)wn * bm + row0 + i * 16 + r) * 2 + 1] = ls2[i];
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the partials are in LDS (raw barrier: the stores stay in flight)
+    if (p.ln_out) {   // (plain mode, bf16 output, no activation: the two `compact` forms above; host-checked)
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the block sums are in LDS (raw barrier: the stores stay in flight)
         __builtin_amdgcn_s_barrier();
         if (wn == 0 && g == 0) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = mrow[i] + r;
                 if (m >= p.M) continue;
+                const float* src = lnred + (size_t)(row0 + i * 16 + r) * nb16 * 2;
                 float a = 0.f, q = 0.f;
-                for (int w = 0; w < wgn; ++w) {
-                    a += lnred[((size_t)w * bm + row0 + i * 16 + r) * 2 + 0];
-                    q += lnred[((size_t)w * bm + row0 + i * 16 + r) * 2 + 1];
-                }
+                for (int k = 0; k < nb16; ++k) { a += src[2 * k]; q += src[2 * k + 1]; }   // ascending blocks: the canonical order
                 reinterpret_cast<float2*>(p.ln_out)[(size_t)m * p.ln_out_slots + tile_n] = make_float2(a, q);
             }
         }

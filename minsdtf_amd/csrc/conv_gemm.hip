@@ -112,14 +112,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
             ab[i] = 0; ay[i] = -(1 << 20); ax[i] = -(1 << 20);
         }
     }
-    const bf16_t* wsrc[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
         const int row = lrow + RPP * i;
         const int n = n0 + row;
-        wsrc[i] = (row < BN && n < p.N) ? (p.w + (size_t)n * p.K + (cpos ^ ((row >> 1) & 7)) * 8) : nullptr;
-        // DENSE: columns past N re-read the last weight row (never stored)
-        woff[i] = ((uint32_t)min(n, p.N - 1) * (uint32_t)p.K + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 8)) * 2u;
+        // columns past N re-read the last weight row (never stored)
+        woff[i] = (uint32_t)min(n, p.N - 1) * p.w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
     }
     // LDS destination of this wave's pass i: 8 rows x 128 B, lane-linear
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
@@ -134,7 +132,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
 #pragma unroll
             for (int i = 0; i < AR; ++i) dma16s(abase, (first ? aoff0[i] : aoff1[i]) + cb, sbase + (uint32_t)(RPP * i) * 128u);
 #pragma unroll
-            for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * 128u, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
+            for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * p.w_ks, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
             return;
         }
         // general form, branch-free: coordinates clamped into the image, an out-of-image tap selects the zero page by
@@ -164,7 +162,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
             dma16(reinterpret_cast<const void*>(((sb + off) & m64) | (zaddr & ~m64)), sbase + (uint32_t)(RPP * i) * 128u);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * 128u, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
+        for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * p.w_ks, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
     };
 
     f32x4 acc[NJ][MI];
@@ -179,17 +177,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     MSD_STAMP(1);
 
     const int swz = r >> 1;  // (row>>1)&7 for row = 16*q + r
+    const int rw = cg_wrow(r), swzw = rw >> 1;   // weight rows enter the MFMA in the order 0-3, 8-11, 4-7, 12-15 (cg_epilogue)
     struct Frags { bf16x8 a[2][MI], w[2][NJ]; };
     auto read_frags = [&](Frags& f, int stg) {
         const char* bA = smem + stg * ST_BYTES + (wm * WMT + r) * 128;
-        const char* bB = smem + stg * ST_BYTES + A_BYTES + (wn * WNT + r) * 128;
+        const char* bB = smem + stg * ST_BYTES + A_BYTES + (wn * WNT + rw) * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((ks * 4 + g) ^ swz) << 4;
+            const int coff = ((ks * 4 + g) ^ swz) << 4, coffw = ((ks * 4 + g) ^ swzw) << 4;
 #pragma unroll
             for (int i = 0; i < MI; ++i) f.a[ks][i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) f.w[ks][j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coff);
+            for (int j = 0; j < NJ; ++j) f.w[ks][j] = *reinterpret_cast<const bf16x8*>(bB + j * 16 * 128 + coffw);
         }
     };
     auto mfma_tile = [&](const Frags& f) {
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * WMT + i * 16;
-    cg_epilogue<MI, NJ>(p, acc, mrow, n0 + wn * WNT, r, g, reinterpret_cast<float*>(smem), wn, WGN, wm * WMT, BM, tile_n);
+    cg_epilogue<MI, NJ, false, DENSE>(p, acc, mrow, n0 + wn * WNT, r, g, reinterpret_cast<float*>(smem), wn, WGN, wm * WMT, BM, tile_n);
 #ifdef MSD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
     MSD_STAMP(4);
@@ -413,6 +412,10 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.out_ld = q->out_ld; a.res_ld = q->res_ld;
     a.rv_step_stride = q->rv_step_stride; a.rv_batch_stride = q->rv_batch_stride;
     a.split_mode = q->split_mode; a.ns0 = q->ns0; a.ns1 = q->ns1; a.out1_ld = q->out1_ld; a.out2_ld = q->out2_ld;
+    // 16-byte epilogue form (conv_common.h): every row it stores to / loads from starts on a 16-byte boundary, and in split
+    // mode a 16-column block lies in one part
+    a.vec16 = (q->out_ld % 8 == 0) && (!q->residual || q->res_ld % 8 == 0) &&
+              (!q->split_mode || ((q->ns0 % 16) == 0 && (q->ns1 % 16) == 0 && (q->ns1 == 0 || q->out1_ld % 8 == 0)));
 
     a.a2 = (const bf16_t*)q->a2; a.a3 = (const bf16_t*)q->a3; a.c2 = q->c2; a.nk_main = a.nk;
     if (q->a2) {
@@ -427,6 +430,9 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     }
     // (again, with the shortcut channels in K: the weight loader's 32-bit byte offsets are n * K * 2 + ...)
     if ((long long)a.N * a.K * 2 >= (1ll << 32) - 4096) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: an operand of 4 GB or more");
+    if (q->w_layout != 0 && q->w_layout != 1) MSD_FAIL(MSD_E_ARG, "conv_gemm: w_layout %d", q->w_layout);
+    a.w_rs = q->w_layout ? 128u : (uint32_t)a.K * 2u;
+    a.w_ks = q->w_layout ? (uint32_t)a.N * 128u : 128u;
     a.ln_in = q->ln_in; a.ln_colsum = q->ln_colsum; a.ln_out = q->ln_out;
     a.ln_in_slots = q->ln_in_slots; a.ln_out_slots = q->ln_out_slots; a.ln_eps = q->ln_eps;
     a.ln_inv_k = 1.0f / (float)a.K;
@@ -436,9 +442,9 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         if (!msd_aligned16(q->ln_colsum) || (((uintptr_t)q->ln_in) & 7u)) MSD_FAIL(MSD_E_ALIGN, "conv_gemm: ln_in / ln_colsum alignment");
     }
     if (q->ln_out) {
-        if (q->split_mode || q->out_dtype != MSD_OUT_BF16 || q->act == MSD_ACT_GEGLU || q->ksize != 1 || q->tile_m >= 1000 ||
+        if (q->split_mode || q->out_dtype != MSD_OUT_BF16 || q->act != MSD_ACT_NONE || q->ksize != 1 || q->tile_m >= 1000 ||
             (((uintptr_t)q->ln_out) & 7u))
-            MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out needs a plain 1x1 launch with a bf16 output");
+            MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out needs a plain 1x1 launch with a bf16 output and no activation");
         if (q->ln_out_slots != msd_conv_gemm_ln_slots(q))
             MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out_slots=%d, this launch writes %d partials per row", q->ln_out_slots,
                      msd_conv_gemm_ln_slots(q));
@@ -511,9 +517,14 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.mg_tps = a.mg_tx = 0;
     dim3 grid(tiles_m * a.tiles_n, slices);
     // 1x1 / Dense form: 32-bit byte offsets from the tensor bases
-    const bool dense = g_conv_dense && !q->a2 && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in &&
+    // (the DENSE kernel carries the LayerNorm-fold consumer and no time-embedding row, the general kernel the reverse)
+    const bool needs_dense = q->ln_in || q->act == MSD_ACT_GEGLU || q->split_mode;
+    const bool dense = (g_conv_dense || needs_dense) && !q->rowvec && !q->a2 && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in &&
                        (long long)a.M * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 < (1ll << 32) - 4096 &&
                        (long long)a.N * a.K * 2 < (1ll << 32) - 4096;
+    if (needs_dense && !dense)
+        MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold, GEGLU and the q|k|v^T split run on the 1x1 / Dense form only (ksize 1, "
+                                    "stride 1, no upsampling, no rowvec, no shortcut operand)");
     switch (cfg) {
 #define X(id, bm_, bn_, wgm, wgn, st, code)                                                                             \
     case id:                                                                                                            \

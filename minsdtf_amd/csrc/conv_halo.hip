@@ -110,10 +110,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
 #pragma unroll
     for (int i = 0; i < BR1; ++i) {
         const int row = lrow + RPP * i;
-        woff[i] = ((uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.K + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 8)) * 2u;
+        woff[i] = (uint32_t)min(n0 + row, p.N - 1) * p.w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
     }
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;   // this wave's 8 rows inside a DMA round
-    const int cin = p.c0 + p.c1;
     const uint64_t zaddr = (uint64_t)(reinterpret_cast<const char*>(g_zero_page) + cpos * 16);
 
     auto issue_halo = [&](int c, int buf) {
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     auto issue_w = [&](int c, int tg, int stage) {   // tg = tap (TAPS = 1) or filter row (TAPS = 3)
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-            const uint32_t koff = (uint32_t)((tg * TAPS + t) * cin + c * 64) * 2u;
+            const uint32_t koff = (uint32_t)((tg * TAPS + t) * nchunks + c) * p.w_ks;
             // (readfirstlane: with the tap loop unrolled hipcc no longer proves this sum wave-uniform and M0 needs an SGPR)
             const uint32_t base = __builtin_amdgcn_readfirstlane(lds_wave + 2u * H_BYTES + (uint32_t)stage * W_BYTES + (uint32_t)t * W1_BYTES);
 #pragma unroll
@@ -187,13 +186,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         auto read_tap = [&](int t, bf16x8 (&af)[2][MI], bf16x8 (&wf)[2][NJ]) {
             const int tp = tap * TAPS + t;
             const int ky = TAPS == 3 ? tap : tp / 3, kx = TAPS == 3 ? t : tp - ky * 3;
-            const char* bW = smem + 2 * H_BYTES + stage * W_BYTES + t * W1_BYTES + (wn * WNT + r) * 128;
+            const int rw = cg_wrow(r);   // weight rows enter the MFMA in the order 0-3, 8-11, 4-7, 12-15 (cg_epilogue)
+            const char* bW = smem + 2 * H_BYTES + stage * W_BYTES + t * W1_BYTES + (wn * WNT + rw) * 128;
             int hrow[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) hrow[i] = (wm * MI + i + ky) * HW_ + kx + r;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int wc = ((ks * 4 + g) ^ (r >> 1)) << 4;
+                const int wc = ((ks * 4 + g) ^ (rw >> 1)) << 4;
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
                     af[ks][i] = *reinterpret_cast<const bf16x8*>(bH + hrow[i] * 128 + (((ks * 4 + g) ^ ((hrow[i] >> 1) & 7)) << 4));
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) mrow[i] = (b * p.h_in + ty0 + wm * MI + i) * p.w_in + tx0;
-    cg_epilogue<MI, NJ, true>(p, acc, mrow, n0 + wn * WNT, r, g);   // (a spatial tile lies inside one sample)
+    cg_epilogue<MI, NJ, true, false>(p, acc, mrow, n0 + wn * WNT, r, g);   // (a spatial tile lies inside one sample)
 #ifdef MSD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MSD_STAMP(4);

@@ -44,7 +44,7 @@ def conv_gemm(*, a0, w, out, batch, h_in, w_in, c0, N, a1=None, c1=0, ksize=1, s
               rowvec=None, rv_step_stride=0, rv_batch_stride=0, step_ptr=None, residual=None, res_ld=None, act=ACT_NONE,
               out_dtype=OUT_BF16, out_ld=None, split=None, workspace=None, workspace_floats=0, splitk=1, tile_n=0,
               tile_m=0, stages=0, pad=None, pad_end=None, ln_in=None, ln_in_slots=0, ln_colsum=None, ln_out=None,
-              ln_out_slots=0, ln_eps=1e-5, a2=None, c2=0, a3=None, c3=0, name="conv_gemm") -> Call:
+              ln_out_slots=0, ln_eps=1e-5, a2=None, c2=0, a3=None, c3=0, w_layout=0, name="conv_gemm") -> Call:
     """split = (ns0, ns1, out1, out1_ld, out2, out2_ld) selects the q|k|v^T epilogue.
     pad / pad_end: leading / trailing zero padding (default: symmetric 1 for 3x3, 0 for 1x1);
     (0, 1) is the VAE encoder's stride-2 padding ((0,1),(0,1))."""
@@ -79,6 +79,7 @@ def conv_gemm(*, a0, w, out, batch, h_in, w_in, c0, N, a1=None, c1=0, ksize=1, s
     s.ln_in, s.ln_colsum, s.ln_out = _p(ln_in), _p(ln_colsum), _p(ln_out)
     s.ln_in_slots, s.ln_out_slots, s.ln_eps = ln_in_slots, ln_out_slots, float(ln_eps)
     s.a2, s.a3, s.c2, s.c3 = _p(a2), _p(a3), c2, c3   # shortcut operand: extra K tiles read at the output pixel
+    s.w_layout = int(w_layout)   # 0: [N][K]; 1: chunk-major [K/64][N][64] (pack.chunk_major)
     return Call(lib.msd_conv_gemm, (C.byref(s),), name, keep=s)
 
 
