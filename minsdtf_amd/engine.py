@@ -231,6 +231,8 @@ FF_PROJ_FOLD = True
 MFMA_CONV_OUT = True
 # ResBlock with a 1x1 shortcut: conv2 and conv_shortcut as one GEMM (the shortcut's channels are extra K tiles)
 SHORTCUT_FOLD = os.environ.get("MSD_SHORTCUT_FOLD", "1") != "0"   # (env switch: same-box A/B runs)
+# packed msd_conv_gemm weights stored chunk-major [K/64][N][64] (packing.chunk_major) instead of [N][K] rows
+W_CHUNK_MAJOR = os.environ.get("MSD_W_CHUNK_MAJOR", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- layer emitters
@@ -278,7 +280,7 @@ class Emitter:
                   residual=None if residual is None else residual.buf, res_ld=None if residual is None else residual.C,
                   workspace=p.ws if sk > 1 else None, workspace_floats=sk * M * N if sk > 1 else 0, splitk=sk,
                   tile_m=tile_m, tile_n=tile_n, stages=stages, pad=pad_lead, pad_end=pad_end,
-                  step_ptr=self.step_ptr if rowvec is not None else None, name=name)
+                  step_ptr=self.step_ptr if rowvec is not None else None, w_layout=1 if W_CHUNK_MAJOR else 0, name=name)
         if e0 is not None:
             kw.update(a2=e0.buf, c2=e0.C, a3=None if e1 is None else e1.buf, c3=0 if e1 is None else e1.C)
         if ln_in is not None:

@@ -105,7 +105,13 @@ class HipModel:
             if tuple(a.shape) != tuple(s.shape):
                 raise ValueError(f"{self.name}: {s.name} has shape {a.shape}, expected {s.shape}")
             named[(s.name, s.kind)] = a
-        self._W = self._pack(named)
+        W = self._pack(named)
+        if engine.W_CHUNK_MAJOR:
+            # every bf16 matrix of the packed set is a msd_conv_gemm weight: store it chunk-major (packing.chunk_major)
+            for k, t in W.items():
+                if t.dtype == torch.bfloat16 and t.dim() == 2 and k.endswith((".w", ".lnw")):
+                    W[k] = packing.chunk_major(t)
+        self._W = W
         self.weights_version += 1
         self._plans.clear()
 

@@ -20,6 +20,14 @@ def _dev_bf16(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(torch.bfloat16).contiguous().to(device)
 
 
+def chunk_major(w_nk: torch.Tensor) -> torch.Tensor:
+    """[N][K] -> [K/64][N][64] (MsdConvGemm.w_layout = 1): the 64-element K chunk of ALL output columns is one contiguous
+    run, so the weight tile of a K step is a single block of HBM whatever the column tile.  Same values, same K order."""
+    n, k = w_nk.shape
+    assert k % 64 == 0, (n, k)
+    return w_nk.view(n, k // 64, 64).permute(1, 0, 2).contiguous()
+
+
 def pack_conv(w_hwio: np.ndarray, device) -> torch.Tensor:
     """(kh,kw,cin,cout) fp32 -> [cout][kh*kw*cin] bf16 on device."""
     t = torch.from_numpy(np.ascontiguousarray(w_hwio))

@@ -141,6 +141,15 @@ def test_conv_gemm(gpu, case):
                                 residual=resid.to(torch.bfloat16).to(d), act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
                                 out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, tile_n=tn, tile_m=tm, stages=stg))
         assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "tile shape changed the bits"
+    # chunk-major weights [K/64][N][64] (w_layout = 1, the form the models keep): storage order only, the same bits
+    out3 = torch.full_like(out, float("nan"))
+    run_calls(ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=packing.chunk_major(wp), w_layout=1, out=out3, batch=B, h_in=H, w_in=W, c0=c0, N=N,
+                            ksize=ks, stride=stride, upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N,
+                            rv_batch_stride=N, step_ptr=step, residual=resid.to(torch.bfloat16).to(d),
+                            act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE, out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16,
+                            workspace=ws, workspace_floats=ws.numel(), splitk=splitk, tile_n=case.get("tile_n", 0),
+                            tile_m=case.get("tile_m", 0), stages=case.get("stages", 0), **(dict(pad=0, pad_end=1) if asym else {})))
+    assert torch.equal(out.view(torch.int32 if f32out else torch.int16), out3.view(torch.int32 if f32out else torch.int16)), "weight layout changed the bits"
 
 
 @pytest.mark.parametrize("case", [
@@ -177,6 +186,13 @@ def test_conv_gemm_shortcut_operand(gpu, case):
                          tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0))
     run_calls(call)
     close(out.reshape(B, H, W, N), ref, what=str(case))
+    from minsdtf_amd import packing
+
+    out2 = torch.full_like(out, float("nan"))
+    run_calls(ops.conv_gemm(a0=keep[0], w=packing.chunk_major(wcat), w_layout=1, out=out2, batch=B, h_in=H, w_in=W, c0=c, N=N, ksize=ks,
+                            bias=keep[3], a2=keep[1], c2=cx0, a3=keep[2], c3=cx1, workspace=keep[4], workspace_floats=keep[4].numel(),
+                            splitk=sk, tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0)))
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "weight layout changed the bits"
 
 
 def test_conv_gemm_geglu(gpu):
