@@ -231,6 +231,12 @@ FF_PROJ_FOLD = True
 MFMA_CONV_OUT = True
 # ResBlock with a 1x1 shortcut: conv2 and conv_shortcut as one GEMM (the shortcut's channels are extra K tiles)
 SHORTCUT_FOLD = os.environ.get("MSD_SHORTCUT_FOLD", "1") != "0"   # (env switch: same-box A/B runs)
+# ... except at the UNet / ControlNet levels with >= this many pixels per SAMPLE (64x64 and up), where conv2 runs on the halo-tile kernel
+# (which has no shortcut operand) and conv2 + a separate 1x1 shortcut launch is faster than the folded general-kernel
+# contraction (in place at batch 1: 26.3 + 12.5 us against 43-47 us folded; below 64x64 the fold wins by 6-13 us).  The
+# rule reads the per-sample shape only: folding changes the order of a layer's sums, and a sample's bits must not depend
+# on the batch it runs in.
+SHORTCUT_FOLD_MAX_PIXELS = int(os.environ.get("MSD_SHORTCUT_FOLD_MAX_PIXELS", "4096"))
 # packed msd_conv_gemm weights stored chunk-major [K/64][N][64] (packing.chunk_major) instead of [N][K] rows
 W_CHUNK_MAJOR = os.environ.get("MSD_W_CHUNK_MAJOR", "1") != "0"
 
@@ -326,7 +332,8 @@ class Emitter:
         p.free(g1)
         g2 = self.group_norm(h, name + ".norm2", silu=True)
         p.free(h)
-        if cin != cout and SHORTCUT_FOLD and (name + ".conv2sc.w") in self.W:
+        fold = SHORTCUT_FOLD and (temb is None or x0.H * x0.W < SHORTCUT_FOLD_MAX_PIXELS)   # (VAE blocks: measured equal, stay folded)
+        if cin != cout and fold and (name + ".conv2sc.w") in self.W:
             # conv2(h) + conv_shortcut(x) as ONE contraction: K = 9 C_out taps of g2, then the C_in channels of x
             out = self.conv(g2, name + ".conv2sc", cout, ksize=3, extra=x)
             p.free(g2)

@@ -169,8 +169,15 @@ def main():
                         if c not in cs:
                             cs.append(c)
                 if not cs:
-                    print(f"  (no stage-1 results for {key}: left as is)")
-                    continue
+                    # a layer stage 1 has not seen: every plain tile, and the split counts stage 1 would have tried
+                    s = parse_key(key)
+                    for (bm, bn, stg) in tuning.TILES:
+                        if (bn == 128 and s[4] <= 64) or (bn == 80 and (s[4] % 80 or not s[8])):
+                            continue
+                        nkt = s[5] * s[5] * s[3] // 64 + s[9] // 64
+                        for sk in (1, 2, 4) if (s[8] and nkt >= 16 and (s[1] * s[2]) // (s[6] * s[6]) <= 1024) else (1,):
+                            cs.append((bm, bn, sk, stg))
+                    print(f"  (no stage-1 results for {key}: {len(cs)} generic candidates)")
                 cands[key] = cs
             npass = max(len(c) for c in cands.values())
             for k in range(npass):
