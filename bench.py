@@ -165,7 +165,7 @@ def main():
 
 class phase:
     """roctx range around one phase of a job (rocprofv3 --marker-trace); with `sync` the device is drained at the range
-    end so that tools/phase_summary.py can attribute the kernel trace to phases by time (profiling runs only)."""
+    end so that tools/trace_summary.py can attribute the kernel trace to phases by time (profiling runs only)."""
 
     def __init__(self, name, sync=False):
         self.name, self.sync = name, sync
