@@ -298,6 +298,8 @@ static const TileCfg g_cfgs[] = {
 constexpr int NUM_TILE_CFGS = 18;
 
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream);
+bool msd_conv_rowpanel_eligible(const CGArgs& a, int rows, int wg_cols);
+int msd_conv_rowpanel_launch(CGArgs a, int rows, int wg_cols, hipStream_t stream);
 
 static bool g_cg_attr_done = false;
 static int g_conv_dense = 1; // 1 = 1x1 / Dense layers take the DENSE loader (default), 0 = the general loader (A/B runs)
@@ -323,7 +325,7 @@ int msd_conv_gemm_init() {
 
 // tile width the launch will use (same rules as msd_conv_gemm below)
 static int cg_effective_bn(const MsdConvGemm* q) {
-    int bn = q->tile_n;
+    int bn = q->tile_m >= 3000 ? 64 : q->tile_n;   // (a row-panel request that is not eligible runs on the 128x64 tile)
     if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
     if (bn == 80 && q->act == MSD_ACT_GEGLU) bn = 64;
     return bn;
@@ -498,6 +500,13 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
             hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices, udiv_magic_of(a.N / 4));
             MSD_CHECK_LAUNCH();
         }
+        return MSD_OK;
+    }
+    // row-panel Dense kernel (tile_m = 3000 + rows per workgroup, tile_n = columns per workgroup): conv_rowpanel.hip
+    if (q->tile_m >= 3000 && q->tile_m < 4000 && msd_conv_rowpanel_eligible(a, q->tile_m - 3000, q->tile_n)) {
+        rc = msd_conv_rowpanel_launch(a, q->tile_m - 3000, q->tile_n, stream);
+        if (rc) return rc;
+        MSD_CHECK_LAUNCH();
         return MSD_OK;
     }
     int cfg = -1;

@@ -1,0 +1,273 @@
+// Row-panel Dense kernel: the A rows of a wave stay in REGISTERS for the whole launch, only the weights stream through LDS.
+//
+// The tile kernel (conv_gemm.hip) is bound by the LDS read port on the short-K Dense layers of the transformer blocks:
+// with 32x32 wave tiles every K step reads 2 A + 2 W fragments for 4 MFMAs, 8 waves x 8 ds_read_b128 x 8 clocks = 512
+// clocks of LDS port per K step against 128-256 clocks of MFMA (in-kernel stamps: 0.30 us per K step = 720 clocks), and
+// every one of the N / BN column tiles re-stages the same A rows from L2.  Here a wave owns MI x 16 rows and loads their
+// K <= 640 channels ONCE, straight from global memory into MFMA operand registers (160 VGPRs); a workgroup (4 waves =
+// BM rows) then walks its share of the output columns in steps of 32: per step the 32 x K weight tile arrives by LDS-DMA
+// (3-stage ring), each wave reads 2 W fragments per 32-channel slice and issues 2 x MI MFMAs on them — 0.25 (MI = 4) or
+// 0.5 (MI = 2) fragment reads per MFMA instead of 1.0 — and finishes the 32 columns (LayerNorm-fold correction, bias,
+// GEGLU gate or q | k | v^T split, store) while the next weight tile is already in LDS.
+//
+// Serves the three LayerNorm-consumer GEMMs of a transformer block (q|k|v, attn2.to_q, the GEGLU projection:
+// diffusion_model.py:102-108,132-153): ksize 1, one input tensor, K = 320 or 640, N % 32 == 0, no residual, bf16 output,
+// 16-byte-aligned rows.  Everything else falls back to the tile kernel (host: msd_conv_gemm).
+// Numerics: the K walk (64-channel chunks ascending, two 32-channel MFMA slices each) and every epilogue expression are
+// those of conv_gemm_dma_kernel / cg_epilogue, so the bits are the tile kernel's (tests/test_ops_gpu.py compares them).
+#include "conv_common.h"
+
+template <int KC, int MI>
+__global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int wg_cols, int nsplits, uint32_t mg_nsplits) {
+    constexpr int S = 3, NJ = 2, MP = MI / 2;
+    constexpr int BM = 4 * MI * 16;
+    constexpr int W_BYTES = KC * 4096;   // one step's weight tile: KC chunks x 32 weight rows x 128 B
+    static_assert(MI % 2 == 0, "row fragments pair up for the 16-byte stores");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    float* l_bias = reinterpret_cast<float*>(smem + S * W_BYTES);
+    float* l_cs = l_bias + wg_cols;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);   // (= gridDim.x; consecutive tiles = one XCD = one row panel)
+    const int panel = udiv_magic(tile, nsplits, mg_nsplits), ns = tile - panel * nsplits;
+    const int m0 = panel * BM + wave * (MI * 16);
+    const int n0 = ns * wg_cols;
+    const int nsteps = (min(wg_cols, p.N - n0)) >> 5;
+
+    // ---- weight DMA: thread -> (row = tid >> 3 of the 32, 16-byte piece tid & 7), one instruction per 64-channel chunk
+    const int cpos = tid & 7, lrow = tid >> 3;
+    const uint32_t wsw = (uint32_t)((cpos ^ ((lrow >> 1) & 7)) * 16);
+    const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
+    auto issue_w = [&](int step, int stage) {
+        const uint32_t off = (uint32_t)min(n0 + step * 32 + lrow, p.N - 1) * p.w_rs + wsw;
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)stage * W_BYTES);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) dma16s(p.w, off + (uint32_t)kc * p.w_ks, base + (uint32_t)kc * 4096u);
+    };
+    if (nsteps > 0) issue_w(0, 0);
+    if (nsteps > 1) issue_w(1, 1);
+
+    // ---- this wave's rows into MFMA operand registers: lane (r, g) holds channels 32 ks + 8 g .. + 8 of row m0 + 16 i + r
+    bf16x8 af[MI][KC * 2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const bf16_t* src = p.a0 + (size_t)min(m0 + i * 16 + r, p.M - 1) * p.c0 + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KC * 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(src + ks * 32);
+    }
+    // bias and LayerNorm column sums of this workgroup's columns -> LDS (read per step without a memory round trip)
+    for (int t = tid; t < wg_cols; t += 256) {
+        const int n = min(n0 + t, p.N - 1);
+        l_bias[t] = p.bias ? p.bias[n] : 0.f;
+        l_cs[t] = p.ln_in ? p.ln_colsum[n] : 0.f;
+    }
+    // LayerNorm fold, consumer side: row moments from the producer's partials, summed exactly as cg_epilogue does
+    // (lane group g takes slots g, g + 4, ...; then (g0 + g1) + (g2 + g3)) — once per row instead of once per tile
+    constexpr int LNS = LN_MAX_SLOTS / 4;
+    float mean[MI], rstd[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { mean[i] = 0.f; rstd[i] = 1.f; }
+    if (p.ln_in) {
+        float2 lnp[MI][LNS];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float2* src = reinterpret_cast<const float2*>(p.ln_in) + (size_t)min(m0 + i * 16 + r, p.M - 1) * p.ln_in_slots;
+#pragma unroll
+            for (int k = 0; k < LNS; ++k) lnp[i][k] = src[min(g + 4 * k, p.ln_in_slots - 1)];
+        }
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNS; ++k)
+                if (g + 4 * k < p.ln_in_slots) { s1 += lnp[i][k].x; s2 += lnp[i][k].y; }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            mean[i] = s1 * p.ln_inv_k;
+            rstd[i] = rsqrtf(fmaxf(s2 * p.ln_inv_k - mean[i] * mean[i], 0.f) + p.ln_eps);
+        }
+    }
+    wait_vmcnt<0>();   // A rows, weight tiles 0 and 1
+    __syncthreads();   // ... and the bias / column-sum rows in LDS
+
+    const int cgo = cg_col(g), cg8 = (g & 1) << 3;
+    const int rw = cg_wrow(r);
+    int msw[MP], bidx[MI];
+#pragma unroll
+    for (int ip = 0; ip < MP; ++ip) msw[ip] = m0 + (g < 2 ? 2 * ip : 2 * ip + 1) * 16 + r;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bidx[i] = p.split_mode ? udiv_magic(min(m0 + i * 16 + r, p.M - 1), p.hw_out, p.mg_hw) : 0;
+    auto swap8 = [&](const float (&a)[4], const float (&b)[4], float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[e]), __float_as_uint(b[e]), false, false);
+            v[e] = __uint_as_float(sw[0]);
+            v[4 + e] = __uint_as_float(sw[1]);
+        }
+    };
+
+    int stage = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        // Retire weight tile `step`.  Younger in the queue, in issue order: the KC DMAs of tile step + 1, then the stores
+        // of the previous step's epilogue; vmcnt(KC) therefore lets stores (and what is left of the KC) stay in flight.
+        if (step) {
+            wait_vmcnt<KC>();
+            __builtin_amdgcn_s_barrier();   // tile `step` visible to all waves; stage (step - 1) % S free
+        }
+        if (step + 2 < nsteps) {
+            int st = stage + 2;
+            if (st >= S) st -= S;
+            issue_w(step + 2, st);
+        }
+        f32x4 acc[NJ][MI];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const char* bW = smem + stage * W_BYTES + rw * 128;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            bf16x8 wf[2][NJ];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    wf[ks][j] = *reinterpret_cast<const bf16x8*>(bW + kc * 4096 + j * 16 * 128 + (((ks * 4 + g) ^ (rw >> 1)) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[i][kc * 2 + ks], acc[j][i], 0, 0, 0);
+        }
+        // ---- the 32 columns nb .. nb + 31 of this wave's rows
+        const int nb = n0 + step * 32;
+        float4 bv[NJ], cs[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bv[j] = *reinterpret_cast<const float4*>(l_bias + step * 32 + j * 16 + cgo);
+            cs[j] = *reinterpret_cast<const float4*>(l_cs + step * 32 + j * 16 + cgo);
+        }
+        if (p.ln_in) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[j][i][0] = rstd[i] * (acc[j][i][0] - mean[i] * cs[j].x);
+                    acc[j][i][1] = rstd[i] * (acc[j][i][1] - mean[i] * cs[j].y);
+                    acc[j][i][2] = rstd[i] * (acc[j][i][2] - mean[i] * cs[j].z);
+                    acc[j][i][3] = rstd[i] * (acc[j][i][3] - mean[i] * cs[j].w);
+                }
+        }
+        if (p.act == MSD_ACT_GEGLU) {   // x columns nb + [0,16), gate nb + 16 + [0,16) -> output columns nb / 2 + [0,16)
+            auto gl4 = [&](int i, float (&v)[4]) {
+                v[0] = geglu_f(acc[0][i][0] + bv[0].x, acc[1][i][0] + bv[1].x);
+                v[1] = geglu_f(acc[0][i][1] + bv[0].y, acc[1][i][1] + bv[1].y);
+                v[2] = geglu_f(acc[0][i][2] + bv[0].z, acc[1][i][2] + bv[1].z);
+                v[3] = geglu_f(acc[0][i][3] + bv[0].w, acc[1][i][3] + bv[1].w);
+            };
+#pragma unroll
+            for (int ip = 0; ip < MP; ++ip) {
+                float a[4], b[4], v[8];
+                gl4(2 * ip, a);
+                gl4(2 * ip + 1, b);
+                swap8(a, b, v);
+                if (msw[ip] < p.M)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)msw[ip] * p.out_ld + (nb >> 1) + cg8) = pack8(v);
+            }
+        } else {
+            const float zero = 0.f;   // (the tile kernel's epilogue adds its absent time-embedding row as 0.f: mirrored)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[j][i][0] = (acc[j][i][0] + bv[j].x) + zero; acc[j][i][1] = (acc[j][i][1] + bv[j].y) + zero;
+                    acc[j][i][2] = (acc[j][i][2] + bv[j].z) + zero; acc[j][i][3] = (acc[j][i][3] + bv[j].w) + zero;
+                }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int nbj = nb + j * 16;
+                if (p.split_mode == 0 || nbj < p.ns0 + p.ns1) {   // plain output, or the q | k parts (a 16-column block lies in one part)
+#pragma unroll
+                    for (int ip = 0; ip < MP; ++ip) {
+                        float a[4] = {acc[j][2 * ip][0], acc[j][2 * ip][1], acc[j][2 * ip][2], acc[j][2 * ip][3]};
+                        float b[4] = {acc[j][2 * ip + 1][0], acc[j][2 * ip + 1][1], acc[j][2 * ip + 1][2], acc[j][2 * ip + 1][3]};
+                        float v[8];
+                        swap8(a, b, v);
+                        if (p.split_mode == 0) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = v[e] + zero;   // (the absent residual of the tile kernel's 16-byte form)
+                        }
+                        const int n8 = nbj + cg8;
+                        if (msw[ip] >= p.M) continue;
+                        bf16_t* dst = (p.split_mode == 0 || n8 < p.ns0) ? reinterpret_cast<bf16_t*>(p.out) + (size_t)msw[ip] * p.out_ld + n8
+                                                                         : p.out1 + (size_t)msw[ip] * p.out1_ld + (n8 - p.ns0);
+                        *reinterpret_cast<uint4*>(dst) = pack8(v);
+                    }
+                } else {   // v part: transposed, token contiguous
+                    const int nv = p.N - p.ns0 - p.ns1;
+                    const int nn = nbj + cgo - p.ns0 - p.ns1;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int m = m0 + i * 16 + r;
+                        if (m >= p.M) continue;
+                        const int sidx = m - bidx[i] * p.hw_out;
+                        const uint32_t ox = pack_bf2(acc[j][i][0], acc[j][i][1]), oy = pack_bf2(acc[j][i][2], acc[j][i][3]);
+                        bf16_t* dst = p.out2 + ((size_t)bidx[i] * nv + nn) * p.out2_ld + sidx;
+                        dst[0] = (bf16_t)(ox & 0xFFFF);
+                        dst[(size_t)p.out2_ld] = (bf16_t)(ox >> 16);
+                        dst[(size_t)2 * p.out2_ld] = (bf16_t)(oy & 0xFFFF);
+                        dst[(size_t)3 * p.out2_ld] = (bf16_t)(oy >> 16);
+                    }
+                }
+            }
+        }
+        if (++stage == S) stage = 0;
+    }
+}
+
+static bool g_rp_attr_done = false;
+constexpr int rp_lds(int kc, int wg_cols) { return 3 * kc * 4096 + 2 * wg_cols * 4; }
+constexpr int RP_MAX_COLS = 1024;   // columns per workgroup (bias + column sums in LDS)
+
+int msd_conv_rowpanel_init() {
+    if (g_rp_attr_done) return MSD_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<5, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(5, RP_MAX_COLS));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(5, RP_MAX_COLS));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<10, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(10, RP_MAX_COLS));
+    if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_rowpanel): %s", hipGetErrorString(e));
+    g_rp_attr_done = true;
+    return MSD_OK;
+}
+
+// Whether a validated launch can run here: rows (256 or 128 per workgroup) and columns per workgroup as requested.
+bool msd_conv_rowpanel_eligible(const CGArgs& a, int rows, int wg_cols) {
+    const bool shape = a.ksize == 1 && a.stride == 1 && !a.upsample && a.c1 == 0 && !a.a2 && (a.K == 320 || a.K == 640) && (a.N % 32) == 0 &&
+                       !a.residual && !a.rowvec && !a.out_f32 && !a.ln_out && a.nslices == 1 && a.vec16 &&
+                       (a.act == MSD_ACT_NONE || (a.act == MSD_ACT_GEGLU && a.split_mode == 0)) &&
+                       (long long)a.M * a.c0 * 2 < (1ll << 32) - 4096;
+    const bool cfg = (rows == 256 && a.K == 320) || rows == 128;
+    return shape && cfg && wg_cols >= 32 && wg_cols <= RP_MAX_COLS && (wg_cols % 32) == 0;
+}
+
+int msd_conv_rowpanel_launch(CGArgs a, int rows, int wg_cols, hipStream_t stream) {
+    int rc = msd_conv_rowpanel_init();
+    if (rc) return rc;
+    if (wg_cols > a.N) wg_cols = a.N;
+    const int panels = (a.M + rows - 1) / rows, nsplits = (a.N + wg_cols - 1) / wg_cols;
+    a.tiles_m = panels; a.tiles_n = nsplits;
+    const dim3 grid(panels * nsplits);
+    const uint32_t mg = udiv_magic_of(nsplits);
+    if (a.K == 320 && rows == 256)
+        hipLaunchKernelGGL((dense_rowpanel_kernel<5, 4>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
+    else if (a.K == 320)
+        hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
+    else
+        hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2>), grid, dim3(256), rp_lds(10, wg_cols), stream, a, wg_cols, nsplits, mg);
+    return MSD_OK;
+}

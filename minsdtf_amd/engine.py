@@ -239,6 +239,8 @@ SHORTCUT_FOLD = os.environ.get("MSD_SHORTCUT_FOLD", "1") != "0"   # (env switch:
 SHORTCUT_FOLD_MAX_PIXELS = int(os.environ.get("MSD_SHORTCUT_FOLD_MAX_PIXELS", "4096"))
 # packed msd_conv_gemm weights stored chunk-major [K/64][N][64] (packing.chunk_major) instead of [N][K] rows
 W_CHUNK_MAJOR = os.environ.get("MSD_W_CHUNK_MAJOR", "1") != "0"
+# the concatenated time_emb_proj Dense of the preparation plan on the MFMA path (bf16 weights and input, fp32 table)
+MFMA_TEMB_PROJ = os.environ.get("MSD_MFMA_TEMB_PROJ", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- layer emitters
@@ -459,18 +461,25 @@ def resblock_names(encoder_only: bool) -> List[Tuple[str, int]]:
 
 def emit_time_embedding(e: Emitter, t_emb_f32, rows: int, out_table, encoder_only: bool):
     """time_embedding MLP + every ResBlock's time_emb_proj for `rows` embeddings at once
-    (diffusion_model.py:184-188,30,47).  fp32 throughout (vector-FMA path)."""
+    (diffusion_model.py:184-188,30,47).  The MLP runs in fp32 on the vector-FMA path; the 22 (UNet) / 10 (ControlNet)
+    projections, concatenated to ONE 1280 -> 20,160 / 9,600 Dense, run on the MFMA path when the model packed them in
+    bf16 (MFMA_TEMB_PROJ): 105 MB of fp32 weights through the vector-FMA kernel took 1.4 ms per image."""
     p = e.p
     total = sum(c for _, c in resblock_names(encoder_only))
+    mfma = e.W["time_emb_proj_cat.w"].dtype == torch.bfloat16
     h1 = p.alloc(rows * 1280 * 4)
-    h2 = p.alloc(rows * 1280 * 4)
-    common = dict(batch=rows, h_in=1, w_in=1, ksize=1, in_dtype=ops.OUT_F32, out_dtype=ops.OUT_F32)
+    h2 = p.alloc(rows * 1280 * (2 if mfma else 4))
+    common = dict(batch=rows, h_in=1, w_in=1, ksize=1, in_dtype=ops.OUT_F32)
     p.rec(ops.conv_direct, x=t_emb_f32, w=e.W["time_embedding.linear_1.w"], bias=e.W["time_embedding.linear_1.b"], out=h1,
-          c_in=320, c_out=1280, act=ops.ACT_SILU, name="time_embedding.linear_1", **common)
+          c_in=320, c_out=1280, act=ops.ACT_SILU, out_dtype=ops.OUT_F32, name="time_embedding.linear_1", **common)
+    # (the swish in front of every time_emb_proj, diffusion_model.py:30, is the output activation of linear_2)
     p.rec(ops.conv_direct, x=h1, w=e.W["time_embedding.linear_2.w"], bias=e.W["time_embedding.linear_2.b"], out=h2,
-          c_in=1280, c_out=1280, act=ops.ACT_SILU, name="time_embedding.linear_2", **common)
-    p.rec(ops.conv_direct, x=h2, w=e.W["time_emb_proj_cat.w"], bias=e.W["time_emb_proj_cat.b"], out=out_table,
-          c_in=1280, c_out=total, name="time_emb_proj_cat", **common)
+          c_in=1280, c_out=1280, act=ops.ACT_SILU, out_dtype=ops.OUT_BF16 if mfma else ops.OUT_F32, name="time_embedding.linear_2", **common)
+    if mfma:
+        e.conv(Act(h2, 1, rows, 1, 1280), "time_emb_proj_cat", total, out_dtype=ops.OUT_F32, out=Act(out_table, 1, rows, 1, total))
+    else:
+        p.rec(ops.conv_direct, x=h2, w=e.W["time_emb_proj_cat.w"], bias=e.W["time_emb_proj_cat.b"], out=out_table,
+              c_in=1280, c_out=total, out_dtype=ops.OUT_F32, name="time_emb_proj_cat", **common)
     p.free(h1, h2)
     return total
 

@@ -239,7 +239,9 @@ class HipModel:
             W[rb + ".conv2sc.w"] = torch.cat([t2, tsc], dim=1).to(torch.bfloat16).contiguous().to(d)
             W[rb + ".conv2sc.b"] = packing.dev_f32(np.asarray(b2, np.float32) + np.asarray(bs, np.float32), d)
         if tproj_w:
-            W["time_emb_proj_cat.w"] = packing.dev_f32(np.concatenate(tproj_w, axis=1).reshape(1, 1, 1280, -1), d)
+            cat = np.concatenate(tproj_w, axis=1)   # (1280, sum of the ResBlocks' C_out)
+            W["time_emb_proj_cat.w"] = (packing.pack_dense(cat, d) if engine.MFMA_TEMB_PROJ
+                                        else packing.dev_f32(cat.reshape(1, 1, 1280, -1), d))
             W["time_emb_proj_cat.b"] = packing.dev_f32(np.concatenate(tproj_b), d)
         return W
 

@@ -28,6 +28,12 @@ HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (125
               (1128, 64, 33), (1128, 64, 34), (1128, 80, 33), (2128, 64, 33))   # 30 + depth: 3 taps (a filter row) per K step
 
 
+# (rows per workgroup + 3000, columns per workgroup): row-panel Dense kernel (csrc/conv_rowpanel.hip) for the LayerNorm-
+# consumer GEMMs of the transformer blocks (K = 320: 256 or 128 rows; K = 640: 128 rows)
+ROWPANEL_ROWS = {320: (3256, 3128), 640: (3128,)}
+ROWPANEL_COLS = (96, 160, 192, 320, 480, 640, 960)
+
+
 def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=True, cx=0) -> str:
     """cx: channels of the shortcut operand (extra K tiles at the output pixel), 0 = none."""
     return (f"{batch}x{h_in}x{w_in}x{cin}->{N}k{ksize}s{stride}u{int(bool(upsample))}{'' if allow_split else 'n'}"
@@ -87,4 +93,6 @@ def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int) -> Tuple[b
     """The part of a launch configuration that decides the ORDER of the layer's fp32 sums: kernel family (halo-tile 3x3
     kernel: chunk-major K walk), split-K slices, and for 1x1 / dense layers the column tile (grouping of the LayerNorm
     fold's row-moment partials).  The table holds ONE class per layer shape for all batch sizes (tools/tune_conv.py)."""
+    if tile_m >= 3000:   # row-panel Dense kernel: the tile kernel's bits (a launch it cannot take runs on the 128x64 tile)
+        return (False, splitk, 64 if ksize == 1 else 0)
     return (tile_m >= 1000, splitk, tile_n if ksize == 1 else 0)

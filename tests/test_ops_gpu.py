@@ -222,6 +222,15 @@ def test_conv_gemm_geglu(gpu):
     dict(M=256, C=320, tile=(64, 128, 24), mode="dense"),      # one slab per tile
     dict(M=200, C=320, tile=(128, 80, 0), mode="geglu", ctile=(128, 128, 0)),     # consumer tiles chosen explicitly
     dict(M=136, C=640, tile=(64, 64, 0), mode="qkv", ctile=(64, 128, 13)),
+    # consumer on the row-panel kernel (conv_rowpanel.hip: tile_m = 3000 + rows per workgroup, tile_n = columns per
+    # workgroup); `csame`: the same bits as the tile kernel
+    dict(M=600, C=320, tile=(128, 128, 0), mode="geglu", ctile=(3256, 320, 0), csame=True),   # 3 ragged row panels x 8 column shares
+    dict(M=300, C=320, tile=(128, 64, 0), mode="qkv", ctile=(3128, 192, 0), csame=True),      # q | k | v^T, a share that straddles k | v
+    dict(M=200, C=640, tile=(64, 64, 0), mode="geglu", ctile=(3128, 640, 0), csame=True),     # K = 640
+    dict(M=136, C=640, tile=(128, 128, 0), mode="qkv", ctile=(3128, 480, 0), csame=True),
+    dict(M=520, C=320, tile=(128, 80, 0), mode="dense", ctile=(3256, 160, 0), csame=True),    # attn2.to_q
+    dict(M=260, C=640, tile=(64, 64, 0), mode="dense", ctile=(3128, 320, 0), csame=True),
+    dict(M=130, C=1280, tile=(64, 64, 14), mode="dense", ctile=(3128, 320, 0), csame=True),   # K = 1280: not eligible, runs on the 128x64 tile
 ])
 def test_conv_gemm_layer_norm_fold(gpu, case):
     """LayerNormalization folded into the GEMMs around it (diffusion_model.py:84-88 + Dense): the producer
@@ -263,6 +272,11 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
                              ln_in=stats, ln_in_slots=slots, ln_colsum=cs, **ckw)
         run_calls([prod, cons])
         close(out, ref, atol=2e-2 * float(ref.abs().max()), what=str(case))
+        if case.get("csame"):
+            out2 = torch.full_like(out, float("nan"))
+            run_calls(ops.conv_gemm(a0=tdev, w=wf, out=out2, batch=1, h_in=M, w_in=1, c0=C, N=8 * C, bias=cb, act=ops.ACT_GEGLU,
+                                    ln_in=stats, ln_in_slots=slots, ln_colsum=cs))
+            assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "row-panel kernel changed the bits"
     elif mode == "qkv":
         w1 = bf(torch.randn(C, 3 * C) / math.sqrt(C))
         ref = ln @ w1
@@ -278,6 +292,12 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
         close(q, ref[:, :C], atol=atol, what=str(case) + " q")
         close(k, ref[:, C:2 * C], atol=atol, what=str(case) + " k")
         close(vt[0, :, :M].t(), ref[:, 2 * C:], atol=atol, what=str(case) + " v^T")
+        if case.get("csame"):
+            q2, k2, vt2 = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.zeros_like(vt)
+            run_calls(ops.conv_gemm(a0=tdev, w=wf, out=q2, batch=1, h_in=M, w_in=1, c0=C, N=3 * C, bias=cb, split=(C, C, k2, C, vt2, sp),
+                                    ln_in=stats, ln_in_slots=slots, ln_colsum=cs))
+            for a_, b_ in ((q, q2), (k, k2), (vt, vt2)):
+                assert torch.equal(a_.view(torch.int16), b_.view(torch.int16)), "row-panel kernel changed the bits"
     else:
         w1 = bf(torch.randn(C, C) / math.sqrt(C))
         b1 = torch.randn(C) * 0.1
@@ -288,6 +308,11 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
                              ln_colsum=cs, **ckw)
         run_calls([prod, cons])
         close(out, ref, atol=2e-2 * float(ref.abs().max()), what=str(case))
+        if case.get("csame"):
+            out2 = torch.full_like(out, float("nan"))
+            run_calls(ops.conv_gemm(a0=tdev, w=wf, out=out2, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=cb, ln_in=stats, ln_in_slots=slots,
+                                    ln_colsum=cs))
+            assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "row-panel kernel changed the bits"
     close(tdev, t, what=str(case) + " producer output")
     # the partials themselves: sum / sum of squares of the stored bf16 values
     tt = tdev.float().cpu()

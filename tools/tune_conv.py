@@ -125,15 +125,18 @@ def tune_one(shape, iters=10):
     cands = list(tuning.TILES)
     if ks == 3 and stride == 1 and not ups and w_in % 16 == 0 and not cx:  # halo-tile kernel (tile_m = 1000 + pixels per tile)
         cands += [t for t in tuning.HALO_TILES if h_in % ((t[0] % 1000) // 16) == 0]
+    if ks == 1 and stride == 1 and not ups and not cx and cin in tuning.ROWPANEL_ROWS and N % 32 == 0:   # row-panel Dense kernel
+        cands += [(rows, cols, 0) for rows in tuning.ROWPANEL_ROWS[cin] for cols in tuning.ROWPANEL_COLS if N % cols == 0]
     for (bm, bn, stg) in cands:
-        if bm == 256 and M < 1024:
-            continue
-        if bn == 128 and N <= 64:
-            continue
-        if bn == 80 and (N % 80 or not allow_split):   # (the 'n' shapes include GEGLU, which pairs fragments)
-            continue
+        if bm < 3000:
+            if bm == 256 and M < 1024:
+                continue
+            if bn == 128 and N <= 64:
+                continue
+            if bn == 80 and (N % 80 or not allow_split):   # (the 'n' shapes include GEGLU, which pairs fragments)
+                continue
         sks = [1]
-        if allow_split:
+        if allow_split and bm < 3000:
             # candidates from the PER-SAMPLE shape, so every batch of a layer is measured on the same set of slice counts
             bme = bm % 1000 if bm >= 1000 else bm
             tiles = ((M // batch + bme - 1) // bme) * ((N + bn - 1) // bn)
@@ -166,8 +169,9 @@ BATCH_WEIGHT = {1: 1.0, 2: 4.0, 4: 1.5, 8: 2.0}   # fused cond+uncond batch: 2 =
 
 def numerics_class(shape, bm, bn, sk):
     """What of a configuration changes the order of the fp32 sums (see the module docstring)."""
-    ks = shape[5]
-    return (bm >= 1000, sk, bn if ks == 1 else 0)
+    from minsdtf_amd import tuning
+
+    return tuning.numerics_class(shape[5], bm, bn, sk)
 
 
 def pin_classes(shapes, all_results):
