@@ -444,7 +444,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         if (!msd_aligned16(q->ln_colsum) || (((uintptr_t)q->ln_in) & 7u)) MSD_FAIL(MSD_E_ALIGN, "conv_gemm: ln_in / ln_colsum alignment");
     }
     if (q->ln_out) {
-        if (q->split_mode || q->out_dtype != MSD_OUT_BF16 || q->act != MSD_ACT_NONE || q->ksize != 1 || q->tile_m >= 1000 ||
+        if (q->split_mode || q->out_dtype != MSD_OUT_BF16 || q->act != MSD_ACT_NONE || q->ksize != 1 || (q->tile_m >= 1000 && q->tile_m < 3000) ||
             (((uintptr_t)q->ln_out) & 7u))
             MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out needs a plain 1x1 launch with a bf16 output and no activation");
         if (q->ln_out_slots != msd_conv_gemm_ln_slots(q))
@@ -456,7 +456,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     if ((q->ln_in || q->ln_out) && splitk > 1) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold is plain-K only (splitk=%d)", splitk);
     // halo variant (tile_m = 1000 + pixels per tile: 1128 = 8x16, 1256 = 16x16): spatially blocked 3x3
     int halo_th = 0;
-    if (q->tile_m >= 1000) {
+    if (q->tile_m >= 1000 && q->tile_m < 3000) {
         const int th = (q->tile_m % 1000) / 16;   // 1128 / 1256: 8x16 / 16x16 pixels; 2128: 8x16 on 8 waves
         const bool ok = !q->a2 && q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
                         q->w_out == q->w_in && !q->upsample && (q->w_in % 16) == 0 &&

@@ -4,10 +4,10 @@
 // with 32x32 wave tiles every K step reads 2 A + 2 W fragments for 4 MFMAs, 8 waves x 8 ds_read_b128 x 8 clocks = 512
 // clocks of LDS port per K step against 128-256 clocks of MFMA (in-kernel stamps: 0.30 us per K step = 720 clocks), and
 // every one of the N / BN column tiles re-stages the same A rows from L2.  Here a wave owns MI x 16 rows and loads their
-// K <= 640 channels ONCE, straight from global memory into MFMA operand registers (160 VGPRs); a workgroup (4 waves =
-// BM rows) then walks its share of the output columns in steps of 32: per step the 32 x K weight tile arrives by LDS-DMA
-// (3-stage ring), each wave reads 2 W fragments per 32-channel slice and issues 2 x MI MFMAs on them — 0.25 (MI = 4) or
-// 0.5 (MI = 2) fragment reads per MFMA instead of 1.0 — and finishes the 32 columns (LayerNorm-fold correction, bias,
+// K <= 640 channels ONCE, straight from global memory into MFMA operand registers (80 / 160 VGPRs); a workgroup (4 waves
+// = 128 rows) then walks its share of the output columns in steps of 32: per step the 32 x K weight tile arrives by LDS-DMA
+// (3-stage ring), each wave reads 2 W fragments per 32-channel slice and issues 2 x MI = 4 MFMAs on them — 0.5 fragment
+// reads per MFMA instead of 1.0 — and finishes the 32 columns (LayerNorm-fold correction, bias,
 // GEGLU gate or q | k | v^T split, store) while the next weight tile is already in LDS.
 //
 // Serves the three LayerNorm-consumer GEMMs of a transformer block (q|k|v, attn2.to_q, the GEGLU projection:
@@ -237,8 +237,7 @@ constexpr int RP_MAX_COLS = 1024;   // columns per workgroup (bias + column sums
 
 int msd_conv_rowpanel_init() {
     if (g_rp_attr_done) return MSD_OK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<5, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(5, RP_MAX_COLS));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(5, RP_MAX_COLS));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(5, RP_MAX_COLS));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<10, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(10, RP_MAX_COLS));
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_rowpanel): %s", hipGetErrorString(e));
     g_rp_attr_done = true;
@@ -251,7 +250,9 @@ bool msd_conv_rowpanel_eligible(const CGArgs& a, int rows, int wg_cols) {
                        !a.residual && !a.rowvec && !a.out_f32 && !a.ln_out && a.nslices == 1 && a.vec16 &&
                        (a.act == MSD_ACT_NONE || (a.act == MSD_ACT_GEGLU && a.split_mode == 0)) &&
                        (long long)a.M * a.c0 * 2 < (1ll << 32) - 4096;
-    const bool cfg = (rows == 256 && a.K == 320) || rows == 128;
+    // (MI = 4, 256 rows per workgroup, was built for K = 320: 256 VGPRs, one wave per SIMD — slower than MI = 2 on every
+    //  shape, 27.5 vs 24.5 us on the 64x64 GEGLU projection: with two workgroups per CU one's epilogue overlaps the other's MFMAs)
+    const bool cfg = rows == 128;
     return shape && cfg && wg_cols >= 32 && wg_cols <= RP_MAX_COLS && (wg_cols % 32) == 0;
 }
 
@@ -263,9 +264,7 @@ int msd_conv_rowpanel_launch(CGArgs a, int rows, int wg_cols, hipStream_t stream
     a.tiles_m = panels; a.tiles_n = nsplits;
     const dim3 grid(panels * nsplits);
     const uint32_t mg = udiv_magic_of(nsplits);
-    if (a.K == 320 && rows == 256)
-        hipLaunchKernelGGL((dense_rowpanel_kernel<5, 4>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
-    else if (a.K == 320)
+    if (a.K == 320)
         hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
     else
         hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2>), grid, dim3(256), rp_lds(10, wg_cols), stream, a, wg_cols, nsplits, mg);

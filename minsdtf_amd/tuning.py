@@ -29,8 +29,8 @@ HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (125
 
 
 # (rows per workgroup + 3000, columns per workgroup): row-panel Dense kernel (csrc/conv_rowpanel.hip) for the LayerNorm-
-# consumer GEMMs of the transformer blocks (K = 320: 256 or 128 rows; K = 640: 128 rows)
-ROWPANEL_ROWS = {320: (3256, 3128), 640: (3128,)}
+# consumer GEMMs of the transformer blocks (K = 320 / 640, 128 rows per workgroup)
+ROWPANEL_ROWS = {320: (3128,), 640: (3128,)}
 ROWPANEL_COLS = (96, 160, 192, 320, 480, 640, 960)
 
 
