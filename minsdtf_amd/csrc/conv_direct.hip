@@ -83,6 +83,54 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const CDArgs p) {
     }
 }
 
+// ---- Dense on a handful of rows (the time-embedding MLP: `steps` rows x 320 -> 1280 -> 1280, fp32) ---------------
+// conv_direct_kernel gives such a launch one thread per (row, 8 outputs) = 16 workgroups walking K serially (170-680 us
+// per layer).  Here a workgroup owns 64 output columns x DR_ROWS rows: wave q takes a quarter of K, lane n one column —
+// a weight row segment is one coalesced 256-byte load per wave and k, the input values are wave-uniform (scalar
+// operands of the FMAs) — and the four partial sums of a column meet in LDS, added in wave order.
+constexpr int DR_ROWS = 16;
+__global__ __launch_bounds__(256) void dense_rows_kernel(const CDArgs p) {
+    __shared__ float part[4][DR_ROWS][64];
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.x * 64 + lane;
+    const int row0 = blockIdx.y * DR_ROWS;
+    const int nrows = min(DR_ROWS, p.batch - row0);   // (wave-uniform)
+    const int K = p.c_in, kq = K >> 2;
+    const float* __restrict__ x = reinterpret_cast<const float*>(p.in) + (size_t)row0 * K + q * kq;
+    const float* __restrict__ w = p.w + (size_t)(q * kq) * p.c_out + min(n, p.c_out - 1);
+    float acc[DR_ROWS];
+#pragma unroll
+    for (int m = 0; m < DR_ROWS; ++m) acc[m] = 0.f;
+    for (int k0 = 0; k0 < kq; k0 += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k0 + u) * p.c_out];
+#pragma unroll
+        for (int m = 0; m < DR_ROWS; ++m) {
+            if (m < nrows) {
+                const float* xr = x + (size_t)m * K + k0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[m] += xr[u] * wv[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < DR_ROWS; ++m) part[q][m][lane] = acc[m];
+    __syncthreads();
+    // 64 columns x nrows rows, 4 per thread
+    for (int e = threadIdx.x; e < nrows * 64; e += 256) {
+        const int m = e >> 6, c = e & 63, nn = blockIdx.x * 64 + c;
+        if (nn >= p.c_out) continue;
+        float v = ((part[0][m][c] + part[1][m][c]) + part[2][m][c]) + part[3][m][c];
+        if (p.bias) v += p.bias[nn];
+        if (p.act == MSD_ACT_SILU) v = silu_f(v);
+        const size_t o = (size_t)(row0 + m) * p.c_out + nn;
+        if (p.out_dtype == MSD_OUT_F32) reinterpret_cast<float*>(p.out)[o] = v;
+        else reinterpret_cast<bf16_t*>(p.out)[o] = f2bf(v);
+    }
+}
+
 // ---- few-output-channel specialisation (UNet conv_out 320->4, VAE conv_out 128->3) -------------
 // 4 lanes share one output pixel: lane s reads the 16-byte channel vectors cv = s, s+4, ... of each
 // tap (so a wave's loads stay contiguous per pixel), the whole fp32 filter sits in LDS as
@@ -247,6 +295,15 @@ extern "C" int msd_conv_direct(const MsdConvDirect* q, msd_stream_t stream_) {
         if (tpx == 32) hipLaunchKernelGGL(conv_in4_kernel<32>, dim3(blocks), dim3(256), 0, stream, a, cq_n, pxg_n, tiles_x, udiv_magic_of(tiles_x), udiv_magic_of(cq_n));
         else if (tpx == 16) hipLaunchKernelGGL(conv_in4_kernel<16>, dim3(blocks), dim3(256), 0, stream, a, cq_n, pxg_n, tiles_x, udiv_magic_of(tiles_x), udiv_magic_of(cq_n));
         else hipLaunchKernelGGL(conv_in4_kernel<8>, dim3(blocks), dim3(256), 0, stream, a, cq_n, pxg_n, tiles_x, udiv_magic_of(tiles_x), udiv_magic_of(cq_n));
+        MSD_CHECK_LAUNCH();
+        return MSD_OK;
+    }
+    // Dense on a few rows (time-embedding MLP): fp32 in, fp32 / bf16 out, K a multiple of 32
+    if (a.in_f32 && q->ksize == 1 && q->h_in == 1 && q->w_in == 1 && q->stride == 1 && q->pad == 0 && q->in_batch_mod == q->batch &&
+        q->batch <= 4096 && (q->c_in % 32) == 0 && q->c_out >= 64 && !q->residual && !q->act_in && q->in_scale == 1.0f &&
+        q->out_dtype != MSD_OUT_U8) {
+        hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)((q->c_out + 63) / 64), (unsigned)((q->batch + DR_ROWS - 1) / DR_ROWS)), dim3(256), 0,
+                           stream, a);
         MSD_CHECK_LAUNCH();
         return MSD_OK;
     }

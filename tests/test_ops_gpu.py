@@ -356,6 +356,8 @@ def test_conv_gemm_qkv_split(gpu, nq):
     dict(B=1, mod=1, H=16, W=16, cin=32, cout=96, in_f32=False, stride=2, act=True),
     dict(B=1, mod=1, H=8, W=8, cin=4, cout=4, in_f32=True, ks=1, scale=1 / 0.18215, out="f32"),  # post_quant
     dict(B=5, mod=5, H=1, W=1, cin=320, cout=1280, in_f32=True, ks=1, act=True, out="f32"),      # time-embedding dense
+    dict(B=25, mod=25, H=1, W=1, cin=1280, cout=1280, in_f32=True, ks=1, act=True),               # ... 25 steps: 2 row chunks, bf16 out (feeds the MFMA projection)
+    dict(B=50, mod=50, H=1, W=1, cin=320, cout=1344, in_f32=True, ks=1, out="f32"),               # ... 50 steps, a last 64-column block that is cut
     dict(B=1, mod=1, H=8, W=8, cin=4, cout=320, in_f32=True, resid=True),        # ControlNet conv_in + hint
     dict(B=2, mod=1, H=64, W=64, cin=4, cout=320, in_f32=True, resid=True),      # ... at the real size: 32-pixel row segments
     dict(B=3, mod=3, H=24, W=48, cin=4, cout=512, in_f32=True, scale=1 / 0.18215),  # VAE decoder.conv_in: 16-pixel segments, 2 px groups
