@@ -157,6 +157,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(unet_arrays, vae_arrays, ctx[:1], unc[:1], noise[:1], nsteps)
     if rank == 0:
+        if args.sync_phases and phase.wall_ms:   # (profiling runs: host wall time per phase, device drained at each end)
+            log("phase wall ms per job: " + ", ".join(f"{k} {v[0] / v[1]:.3f}" for k, v in phase.wall_ms.items()))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -167,6 +169,8 @@ class phase:
     """roctx range around one phase of a job (rocprofv3 --marker-trace); with `sync` the device is drained at the range
     end so that tools/trace_summary.py can attribute the kernel trace to phases by time (profiling runs only)."""
 
+    wall_ms = {}   # with sync: accumulated host wall time per phase name, and the number of ranges (printed by main)
+
     def __init__(self, name, sync=False):
         self.name, self.sync = name, sync
 
@@ -175,6 +179,7 @@ class phase:
 
         if torch.cuda.is_available():
             torch.cuda.nvtx.range_push(self.name)
+        self.t0 = time.perf_counter()
 
     def __exit__(self, *exc):
         import torch
@@ -182,6 +187,9 @@ class phase:
         if torch.cuda.is_available():
             if self.sync:
                 torch.cuda.synchronize()
+                e = phase.wall_ms.setdefault(self.name, [0.0, 0])
+                e[0] += (time.perf_counter() - self.t0) * 1e3
+                e[1] += 1
             torch.cuda.nvtx.range_pop()
 
 

@@ -604,8 +604,10 @@ def emit_controlnet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: i
         p.free(o)
 
 
-def emit_hintnet(e: Emitter, image_f32, B: int, H: int, W: int, out: Act) -> None:
-    """HintNet (control_net.py:10-31): 8 convs with swish between; last conv (256->320) on MFMA."""
+def emit_hintnet(e: Emitter, image_f32, B: int, H: int, W: int, out: Act, copies: int = 1) -> None:
+    """HintNet (control_net.py:10-31): 8 convs with swish between; last conv (256->320) on MFMA.  `copies`: `out` holds
+    that many replicas of the B-sample result back to back (the cond and uncond halves of a fused forward read the same
+    hint): the last conv writes each of them, nothing else runs twice."""
     p = e.p
     x_buf, x_f32 = image_f32, True
     h, w = H, W
@@ -622,7 +624,8 @@ def emit_hintnet(e: Emitter, image_f32, B: int, H: int, W: int, out: Act) -> Non
                 p.free(cur)
             cur, x_buf, x_f32 = nxt, nxt.buf, False
         else:
-            e.conv(cur, f"input_hint_block.{i}", cout, ksize=3, out=out)
+            for rep in range(copies):
+                e.conv(cur, f"input_hint_block.{i}", cout, ksize=3, out=Act(out.buf.at(rep * B * ho * wo * cout * 2), B, ho, wo, cout))
             p.free(cur)
         h, w = ho, wo
 

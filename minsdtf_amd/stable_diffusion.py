@@ -126,10 +126,10 @@ class DenoiseEngine:
         if self.has_control:
             # hint computed once per image batch (stable_diffusion.py:427-441), tiled to both halves
             nb_max = max(nb for (_r, nb, _t, _g) in passes)
-            self.hint_img = torch.zeros(nb_max, 8 * h, 8 * w, 3, dtype=torch.float32, device=dev)
+            self.hint_img = torch.zeros(B, 8 * h, 8 * w, 3, dtype=torch.float32, device=dev)
             e_h = engine.Emitter(prep, hint_net._W)
             hint_act = prep.act(nb_max, h, w, 320)
-            engine.emit_hintnet(e_h, self.hint_img, nb_max, 8 * h, 8 * w, hint_act)
+            engine.emit_hintnet(e_h, self.hint_img, B, 8 * h, 8 * w, hint_act, copies=nb_max // B)
         prep.finalize()
         self.prep = prep
 
@@ -304,8 +304,9 @@ class DenoiseEngine:
             self.step_noise.copy_(torch.from_numpy(z))
         if self.has_control:
             hi = np.ascontiguousarray(hint_image, dtype=np.float32)
-            reps = self.hint_img.shape[0] // hi.shape[0]
-            self.hint_img.copy_(torch.from_numpy(np.tile(hi, (reps, 1, 1, 1))))
+            if hi.shape[0] != self.B:   # (one hint for the whole batch: the reference tiles it, :435)
+                hi = np.tile(hi, (self.B // hi.shape[0], 1, 1, 1))
+            self.hint_img.copy_(torch.from_numpy(hi))   # the cond / uncond replicas are made on the device (emit_hintnet)
         self.prep.run(torch.cuda.current_stream().cuda_stream)
 
 
