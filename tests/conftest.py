@@ -47,9 +47,10 @@ def run_calls(calls):
 
 
 # ---- orderly end of a GPU session ---------------------------------------------------------------
-# Round 1 left the interpreter with os._exit() here after one unexplained core dump at teardown.  The cause: captured
-# hipGraphs (module-scoped fixtures keep pipelines alive to the very end) were destroyed by torch AFTER the C runtime had
-# unregistered this library's code object.  minsdtf_amd now owns that order (minsdtf_amd._lib.shutdown, also registered with
+# Round 1 left the interpreter with os._exit() here after one unexplained core dump at teardown.  Most likely cause:
+# captured hipGraphs (module-scoped fixtures keep pipelines alive to the very end) destroyed by torch AFTER the C runtime
+# had unregistered this library's code object (not reproduced in isolation; every full run since the change has exited
+# with code 0).  minsdtf_amd now owns that order (minsdtf_amd._lib.shutdown, also registered with
 # Python's atexit): graphs are released first, then the device is drained, then the normal interpreter teardown runs.
 @pytest.fixture(scope="session", autouse=True)
 def _release_graphs_at_session_end():

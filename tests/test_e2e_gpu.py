@@ -78,8 +78,9 @@ def test_unet_forward_graph_replay(unet_pair):
         g2 = m.predict_on_batch([lat, t_emb, ctx])
     finally:
         m.compile(jit_compile=False)
-    # GroupNorm statistics accumulate with float atomics: identical up to fp32 summation order
-    assert rel_rms(g1, eager) < 2e-3 and rel_rms(g2, g1) < 2e-3
+    # every kernel sums in a fixed order (no atomics anywhere): graph replays and the eager run give the same bits
+    np.testing.assert_array_equal(g1, eager)
+    np.testing.assert_array_equal(g2, g1)
 
 
 def test_decoder_forward(decoder_pair):
