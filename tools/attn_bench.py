@@ -17,6 +17,10 @@ SHAPES = [
     ("L2 self  S=256 d=160", 2, 8, 160, 256, 256),
     ("L0 self  B=8", 8, 8, 40, 4096, 4096),
     ("768^2 self S=9216 d=40", 2, 8, 40, 9216, 9216),
+    ("L1 self  B=8", 8, 8, 80, 1024, 1024),
+    ("L2 self  B=8", 8, 8, 160, 256, 256),
+    ("L1 cross S=1024 T=77 d=80", 2, 8, 80, 1024, 77),
+    ("L2 cross S=256 T=77 d=160", 2, 8, 160, 256, 77),
 ]
 
 
