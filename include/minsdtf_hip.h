@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 6
+#define MSD_ABI_VERSION 7
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -235,6 +235,32 @@ typedef struct MsdAttention {
 } MsdAttention;
 
 int msd_attention(const MsdAttention* p, msd_stream_t stream);
+
+/* msd_cross_attention_q — cross-attention over a short context with its query projection inside: the `attn2.to_q` Dense
+ * (with the LayerNormalization in front of it folded in, as MsdConvGemm.ln_in does) and the attention over the text
+ * context (diffusion_model.py:102-127, context = 77 tokens) as ONE launch instead of two latency-bound ones.
+ *   q = LN(x) Wq^T computed per (64 queries, head) as rstd * (x wq^T - mean * ln_colsum) + bias, rounded to bf16;
+ *   out = softmax(q k^T) v with the softmax as exp2 of the raw product: wq MUST carry scale * log2(e) (q_prescaled form).
+ * x: bf16 [batch*s][c] (the block's raw rows), ln_in: float2 [batch*s][ln_in_slots] (the producer's ln_out partials),
+ * wq: bf16 gamma-folded weights [c][c] in `w_layout`, ln_colsum / bias: [c]; k: bf16 [batch][t][k_ld], vt: bf16
+ * [batch][heads][head_dim][vt_ld] (key contiguous), out: bf16 [batch*s][o_ld].  heads = 8, head_dim 40 or 80, t <= 96. */
+typedef struct MsdCrossAttnQ {
+    const void* x;
+    const float* ln_in;
+    const void* wq;
+    const float* ln_colsum;
+    const float* bias;       /* [c] or NULL */
+    const void* k;
+    const void* vt;
+    void* out;
+    int32_t batch, heads, head_dim, s, t;
+    int32_t k_ld, vt_ld, o_ld;
+    int32_t ln_in_slots;
+    float ln_eps;
+    int32_t w_layout;        /* 0: [c][c] rows, 1: chunk-major [c/64][c][64] (MsdConvGemm.w_layout) */
+} MsdCrossAttnQ;
+
+int msd_cross_attention_q(const MsdCrossAttnQ* p, msd_stream_t stream);
 
 /* msd_softmax_rows — out[r, :cols] = softmax(scale * x[r, :cols]); x fp32 [rows][ld_in], out bf16
  * [rows][ld_out] (VAE single-head attention, layers.py:48-50). cols % 8 == 0. */

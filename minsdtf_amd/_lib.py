@@ -15,7 +15,7 @@ import weakref
 LIB_NAME = "libminsdtf_hip.so"
 # $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
 LIB_PATH = os.environ.get("MSD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -61,6 +61,16 @@ class MsdGroupNorm(C.Structure):
     ]
 
 
+class MsdCrossAttnQ(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ln_in", C.c_void_p), ("wq", C.c_void_p), ("ln_colsum", C.c_void_p), ("bias", C.c_void_p),
+        ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
+        ("batch", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("s", C.c_int32), ("t", C.c_int32),
+        ("k_ld", C.c_int32), ("vt_ld", C.c_int32), ("o_ld", C.c_int32), ("ln_in_slots", C.c_int32), ("ln_eps", C.c_float),
+        ("w_layout", C.c_int32),
+    ]
+
+
 class MsdAttention(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
@@ -90,6 +100,7 @@ SYMBOLS = {
     "msd_conv_gemm_ln_slots": (C.c_int, [C.POINTER(MsdConvGemm)]),
     "msd_conv_direct": (C.c_int, [C.POINTER(MsdConvDirect), C.c_void_p]),
     "msd_group_norm": (C.c_int, [C.POINTER(MsdGroupNorm), C.c_void_p]),
+    "msd_cross_attention_q": (C.c_int, [C.POINTER(MsdCrossAttnQ), C.c_void_p]),
     "msd_layer_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                  C.c_void_p]),
     "msd_attention": (C.c_int, [C.POINTER(MsdAttention), C.c_void_p]),

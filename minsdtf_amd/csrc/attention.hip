@@ -408,6 +408,254 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     }
 }
 
+// ---- cross-attention with its query projection inside (text context: T <= 96 keys) --------------------------------
+// CrossAttention over the text context (diffusion_model.py:102-127 with a context of 77 tokens): in the launch list the
+// query projection (LayerNorm-fold Dense, C -> C) and the attention over 77 keys are two latency-bound launches of ~12 us
+// each for 1.7 + 0.8 GFLOP.  Here a workgroup = (64 queries, one head): each wave loads its 16 rows of the RAW block
+// input straight into MFMA operand registers, the head's D rows of the (gamma-folded, prescaled) to_q weights arrive by
+// LDS-DMA, and q^T = W_h x^T comes out of the matrix core with the query on the MFMA column — i.e. already in the layout of
+// the S^T = K q^T product's B operand: the accumulators of two 16-row blocks, LayerNorm-corrected and packed to bf16 (the
+// same rounding the stored q had), ARE the operand for 32 head channels (k-slot order {4g+e, 16+4g+e}; the K fragment is
+// read from LDS in the same order, two 8-byte pieces per lane).  All T keys fit one tile, so the softmax is a single pass
+// over 5-6 key blocks in registers, and P packs into the B operand of O^T = V^T P^T the same way.  x is re-read by the 8
+// heads of a query tile, which run next to each other on one XCD.
+struct XArgs {
+    const bf16_t* x; const float* ln_in; const bf16_t* wq; const float* colsum; const float* bias;
+    const bf16_t* k; const bf16_t* vt; bf16_t* out;
+    int batch, heads, s, t, c, k_ld, vt_ld, o_ld, ln_slots;
+    float ln_inv_k, ln_eps;
+    uint32_t w_rs, w_ks;            // to_q weight addressing in bytes: row stride, 64-channel chunk stride
+    uint32_t mg_heads, mg_qtiles;
+};
+
+// NW waves = 16 NW queries per workgroup (4 or 8: the weight / K / V^T images are shared by twice the queries; the host picks 8
+// when the 64-query grid would need more than one round of workgroups).
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
+    constexpr int NT = 64 * NW, QT = 16 * NW;
+    constexpr int C = 8 * D;                  // (8 heads: SD1.5)
+    constexpr int KC = C / 64;                // 64-channel chunks of the projection's K
+    constexpr int DB = (D + 15) / 16;         // 16-row blocks of q^T / O^T
+    constexpr int DCK = (DB + 1) / 2;         // 32-channel chunks of the QK^T contraction
+    constexpr int WR = (DB * 16 + 31) / 32 * 32;   // weight rows staged per chunk (DMA rounds of 32 rows)
+    constexpr int W_BYTES = KC * WR * 128;
+    constexpr int TB = 6, TPAD = TB * 16;     // key blocks (T <= 96), 32-key chunks of the PV contraction = 3
+    constexpr int KROW = DCK * 64 + 16, VROW = TPAD * 2 + 16;
+    constexpr int K_BYTES = TPAD * KROW, V_BYTES = DB * 16 * VROW;
+    constexpr int DCH = D / 8;                // 16-byte chunks per K row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;
+    char* sK = smem + W_BYTES;
+    char* sV = sK + K_BYTES;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int qtiles = (p.s + QT - 1) / QT;
+    const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);
+    const int qt_b = udiv_magic(wi, p.heads, p.mg_heads), h = wi - qt_b * p.heads;     // head fastest: the 8 heads of a tile share x
+    const int b = udiv_magic(qt_b, qtiles, p.mg_qtiles);
+    const int q0 = (qt_b - b * qtiles) * QT + wave * 16;
+
+    // ---- 1. everything this workgroup reads, issued at once: weight DMAs first (oldest in the queue), then plain loads
+    if (wave < 4) {   // (waves 0-3 issue the weight DMAs: 32 rows x 128 B per instruction round)
+        const int cpos = tid & 7, lrow = tid >> 3;
+        const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
+#pragma unroll
+        for (int rr = 0; rr < WR / 32; ++rr) {
+            const int row = rr * 32 + lrow;
+            const uint32_t off = (uint32_t)(h * D + min(row, D - 1)) * p.w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                dma16s(p.wq, off + (uint32_t)kc * p.w_ks, __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)(kc * WR + rr * 32) * 128u));
+        }
+    }
+    bf16x8 xf[KC * 2];
+    const int qrow = min(q0 + r, p.s - 1);
+    {
+        const bf16_t* src = p.x + ((size_t)b * p.s + qrow) * C + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KC * 2; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 32);
+    }
+    constexpr int LNS = 5;   // (LN_MAX_SLOTS / 4 of conv_common.h)
+    float2 lnp[LNS];
+    {
+        const float2* src = reinterpret_cast<const float2*>(p.ln_in) + ((size_t)b * p.s + qrow) * p.ln_slots;
+#pragma unroll
+        for (int k = 0; k < LNS; ++k) lnp[k] = src[min(g + 4 * k, p.ln_slots - 1)];
+    }
+    float4 csv[DB], bsv[DB];   // column sums / folded bias of this lane's 4 head channels per block (clamped: masked below)
+#pragma unroll
+    for (int bb = 0; bb < DB; ++bb) {
+        const int d = min(bb * 16 + 4 * g, D - 4);
+        csv[bb] = *reinterpret_cast<const float4*>(p.colsum + h * D + d);
+        bsv[bb] = p.bias ? *reinterpret_cast<const float4*>(p.bias + h * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    constexpr int KCH = (TPAD * DCH + NT - 1) / NT, VCH = (D * (TPAD / 8) + NT - 1) / NT;
+    uint4 rk[KCH], rv[VCH];
+    const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
+    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int idx = tid + NT * i, key = idx / DCH, ch = idx - key * DCH;
+        rk[i] = make_uint4(0, 0, 0, 0);
+        if (key < p.t) rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * p.k_ld + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int idx = tid + NT * i, d = idx / (TPAD / 8), ch = idx - d * (TPAD / 8);
+        rv[i] = make_uint4(0, 0, 0, 0);
+        if (d < D && ch * 8 + 8 <= p.vt_ld && ch * 8 < p.t) rv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + ch * 8);
+    }
+    // K / V^T images: zero everything (pad rows / columns are never written), then the loaded pieces
+    for (int off = tid * 16; off < K_BYTES + V_BYTES; off += NT * 16) *reinterpret_cast<uint4*>(sK + off) = make_uint4(0, 0, 0, 0);
+    __syncthreads();   // (also waits for every load above)
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int idx = tid + NT * i, key = idx / DCH, ch = idx - key * DCH;
+        if (key < p.t) *reinterpret_cast<uint4*>(sK + key * KROW + ch * 16) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int idx = tid + NT * i, d = idx / (TPAD / 8), ch = idx - d * (TPAD / 8);
+        if (d >= D || ch * 8 >= p.t) continue;
+        uint4 v = rv[i];
+        const int valid = p.t - ch * 8;   // keys >= t are padding of unspecified content: force to 0
+        if (valid < 8) {
+            uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (2 * j >= valid) u[j] = 0;
+                else if (2 * j + 1 >= valid) u[j] &= 0xFFFFu;
+            }
+        }
+        *reinterpret_cast<uint4*>(sV + d * VROW + ch * 16) = v;
+    }
+    // LayerNorm row moments, summed as cg_epilogue does (lane group g: slots g, g + 4, ...; then (g0 + g1) + (g2 + g3))
+    float mean, rstd;
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNS; ++k)
+            if (g + 4 * k < p.ln_slots) { s1 += lnp[k].x; s2 += lnp[k].y; }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        mean = s1 * p.ln_inv_k;
+        rstd = rsqrtf(fmaxf(s2 * p.ln_inv_k - mean * mean, 0.f) + p.ln_eps);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();   // weights (DMA) and the K / V^T images are in LDS
+
+    // ---- 2. q^T = W_h x^T: block bb holds head channels 16 bb + 4 g + e of query r
+    f32x4 qacc[DB];
+#pragma unroll
+    for (int bb = 0; bb < DB; ++bb) qacc[bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int bb = 0; bb < DB; ++bb) {
+                const int row = bb * 16 + r;
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sW + (kc * WR + row) * 128 + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 4));
+                qacc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[kc * 2 + ks], qacc[bb], 0, 0, 0);
+            }
+    // LayerNorm fold + bias (the Dense epilogue's expressions), head channels >= D forced to zero; two blocks -> one operand
+    uint32_t qpk[DB + (DB & 1)][2];
+#pragma unroll
+    for (int bb = 0; bb < DB + (DB & 1); ++bb) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bb < DB) {
+            const bool ok = bb * 16 + 4 * g < D;   // (D % 4 == 0: a lane's 4 channels are all inside or all outside)
+            v[0] = ok ? (rstd * (qacc[bb][0] - mean * csv[bb].x) + bsv[bb].x) : 0.f;
+            v[1] = ok ? (rstd * (qacc[bb][1] - mean * csv[bb].y) + bsv[bb].y) : 0.f;
+            v[2] = ok ? (rstd * (qacc[bb][2] - mean * csv[bb].z) + bsv[bb].z) : 0.f;
+            v[3] = ok ? (rstd * (qacc[bb][3] - mean * csv[bb].w) + bsv[bb].w) : 0.f;
+        }
+        qpk[bb][0] = pack_bf2(v[0], v[1]);
+        qpk[bb][1] = pack_bf2(v[2], v[3]);
+    }
+    // ---- 3. S^T = K q^T (q carries scale * log2 e): lane holds keys 16 kb + 4 g + e of query r
+    f32x4 sacc[TB];
+#pragma unroll
+    for (int kb = 0; kb < TB; ++kb) {
+        sacc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) {
+            union { bf16x8 v; uint32_t u[4]; } qo;
+            qo.u[0] = qpk[2 * c][0]; qo.u[1] = qpk[2 * c][1]; qo.u[2] = qpk[2 * c + 1][0]; qo.u[3] = qpk[2 * c + 1][1];
+            union { bf16x8 v; uint2 h2[2]; } kf;
+            const char* kp = sK + (kb * 16 + r) * KROW + c * 64 + g * 8;
+            kf.h2[0] = *reinterpret_cast<const uint2*>(kp);
+            kf.h2[1] = *reinterpret_cast<const uint2*>(kp + 32);
+            sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qo.v, sacc[kb], 0, 0, 0);
+        }
+    }
+    // single-pass softmax over the T keys of the lane's query
+    float m = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < TB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (kb * 16 + 4 * g + e >= p.t) sacc[kb][e] = -1e30f;
+            m = fmaxf(m, sacc[kb][e]);
+        }
+    m = rows_max4(m);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < TB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float pv = __builtin_amdgcn_exp2f(sacc[kb][e] - m);
+            sacc[kb][e] = pv;
+            lsum += pv;
+        }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    // ---- 4. O^T = V^T P^T over 32-key chunks (P packed to bf16 = the B operand, key order {4g+e, 16+4g+e} of the chunk)
+    f32x4 oacc[DB];
+#pragma unroll
+    for (int bb = 0; bb < DB; ++bb) oacc[bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < TB / 2; ++c) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+        pk.u[0] = pack_bf2(sacc[2 * c][0], sacc[2 * c][1]);
+        pk.u[1] = pack_bf2(sacc[2 * c][2], sacc[2 * c][3]);
+        pk.u[2] = pack_bf2(sacc[2 * c + 1][0], sacc[2 * c + 1][1]);
+        pk.u[3] = pack_bf2(sacc[2 * c + 1][2], sacc[2 * c + 1][3]);
+#pragma unroll
+        for (int bb = 0; bb < DB; ++bb) {
+            union { bf16x8 v; uint2 h2[2]; } vf;
+            const char* vp = sV + (bb * 16 + r) * VROW + c * 64 + g * 8;
+            vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
+            vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 32);
+            oacc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, oacc[bb], 0, 0, 0);
+        }
+    }
+    if (q0 + r < p.s) {
+        const float inv = 1.0f / lsum;
+        bf16_t* op = p.out + ((size_t)b * p.s + q0 + r) * p.o_ld + h * D;
+#pragma unroll
+        for (int bb = 0; bb < DB; ++bb) {
+            const int d = bb * 16 + 4 * g;
+            if (d < D) {
+                uint2 o;
+                o.x = pack_bf2(oacc[bb][0] * inv, oacc[bb][1] * inv);
+                o.y = pack_bf2(oacc[bb][2] * inv, oacc[bb][3] * inv);
+                *reinterpret_cast<uint2*>(op + d) = o;
+            }
+        }
+    }
+}
+
+template <int D>
+static constexpr int xattn_lds() {
+    constexpr int DB = (D + 15) / 16, DCK = (DB + 1) / 2, WR = (DB * 16 + 31) / 32 * 32;
+    return (8 * D / 64) * WR * 128 + 96 * (DCK * 64 + 16) + DB * 16 * (96 * 2 + 16);
+}
+static_assert(xattn_lds<40>() <= 160 * 1024 && xattn_lds<80>() <= 160 * 1024, "LDS budget");
+
 // ---- d = 512: the VAE's single-head AttentionBlock (layers.py:28-59) ----------------------------------------------
 // The head does not fit the kernel above (O^T of 32 queries x 512 channels alone is 256 registers per lane), and the
 // reference's route — materialise softmax(q k^T / sqrt(C)) — is 64 MB of fp32 scores + 32 MB of probabilities per image
@@ -570,6 +818,8 @@ static constexpr int attn_lds_bytes() {
 static bool g_attn_attr_done = false;
 static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = queries per wave / 16 forced (A/B runs)
 void msd_set_attn_qf(int v) { g_attn_qf = v; }
+static int g_xattn_nw = 0;    // 0 = automatic, 4 / 8 = waves (x 16 queries) per workgroup of the fused cross-attention (A/B runs)
+void msd_set_xattn_nw(int v) { g_xattn_nw = v; }
 
 template <int D, int NBUF, int QF, bool PRESC>
 static hipError_t attn_attr1() {
@@ -593,6 +843,10 @@ int msd_attention_init() {
     if (e == hipSuccess) e = attn_attr<64>();
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATTN512_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<40, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<40>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<40, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<40>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<80, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<80>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<80, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<80>());
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
     g_attn_attr_done = true;
     return MSD_OK;
@@ -653,6 +907,48 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
             break;
         }
         default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 64, 80, 160, 512)", q->head_dim);
+    }
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}
+
+extern "C" int msd_cross_attention_q(const MsdCrossAttnQ* q, msd_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!q || !q->x || !q->ln_in || !q->wq || !q->ln_colsum || !q->k || !q->vt || !q->out) MSD_FAIL(MSD_E_ARG, "cross_attention_q: null pointer");
+    if (q->batch <= 0 || q->s <= 0 || q->t <= 0) MSD_FAIL(MSD_E_ARG, "cross_attention_q: bad dims");
+    if (q->heads != 8 || (q->head_dim != 40 && q->head_dim != 80) || q->t > 96)
+        MSD_FAIL(MSD_E_UNSUPPORTED, "cross_attention_q: 8 heads of 40 or 80 channels and at most 96 keys (heads=%d head_dim=%d t=%d)", q->heads,
+                 q->head_dim, q->t);
+    const int C = q->heads * q->head_dim;
+    if (q->ln_in_slots < 1 || q->ln_in_slots > 20 || !(q->ln_eps > 0.f)) MSD_FAIL(MSD_E_ARG, "cross_attention_q: 1 <= ln_in_slots <= 20, ln_eps > 0");
+    if ((q->k_ld % 8) || (q->vt_ld % 8) || (q->o_ld % 4) || q->k_ld < C || q->o_ld < C || q->vt_ld < q->t)
+        MSD_FAIL(MSD_E_ALIGN, "cross_attention_q: leading dimensions");
+    if (!msd_aligned16(q->x) || !msd_aligned16(q->wq) || !msd_aligned16(q->ln_colsum) || !msd_aligned16(q->bias) || !msd_aligned16(q->k) ||
+        !msd_aligned16(q->vt) || !msd_aligned16(q->out) || (((uintptr_t)q->ln_in) & 7u))
+        MSD_FAIL(MSD_E_ALIGN, "cross_attention_q: pointer alignment");
+    if (q->w_layout != 0 && q->w_layout != 1) MSD_FAIL(MSD_E_ARG, "cross_attention_q: w_layout");
+    int rc = msd_attention_init();
+    if (rc) return rc;
+    XArgs a;
+    a.x = (const bf16_t*)q->x; a.ln_in = q->ln_in; a.wq = (const bf16_t*)q->wq; a.colsum = q->ln_colsum; a.bias = q->bias;
+    a.k = (const bf16_t*)q->k; a.vt = (const bf16_t*)q->vt; a.out = (bf16_t*)q->out;
+    a.batch = q->batch; a.heads = q->heads; a.s = q->s; a.t = q->t; a.c = C; a.k_ld = q->k_ld; a.vt_ld = q->vt_ld; a.o_ld = q->o_ld;
+    a.ln_slots = q->ln_in_slots; a.ln_inv_k = 1.0f / (float)C; a.ln_eps = q->ln_eps;
+    a.w_rs = q->w_layout ? 128u : (uint32_t)C * 2u;
+    a.w_ks = q->w_layout ? (uint32_t)C * 128u : 128u;
+    // 128 queries per workgroup where the 64-query grid would need more than ~1.5 workgroups per CU (a query's result does
+    // not depend on which queries share its workgroup)
+    const long long wgs64 = (long long)((q->s + 63) / 64) * q->heads * q->batch;
+    const int nw = g_xattn_nw ? g_xattn_nw : (wgs64 >= 768 ? 8 : 4);
+    const int qtiles = (q->s + 16 * nw - 1) / (16 * nw);
+    a.mg_heads = udiv_magic_of(q->heads); a.mg_qtiles = udiv_magic_of(qtiles);
+    const dim3 grid((unsigned)qtiles * q->heads * q->batch);
+    if (q->head_dim == 40) {
+        if (nw == 8) hipLaunchKernelGGL((xattn_q_kernel<40, 8>), grid, dim3(512), xattn_lds<40>(), stream, a);
+        else hipLaunchKernelGGL((xattn_q_kernel<40, 4>), grid, dim3(256), xattn_lds<40>(), stream, a);
+    } else {
+        if (nw == 8) hipLaunchKernelGGL((xattn_q_kernel<80, 8>), grid, dim3(512), xattn_lds<80>(), stream, a);
+        else hipLaunchKernelGGL((xattn_q_kernel<80, 4>), grid, dim3(256), xattn_lds<80>(), stream, a);
     }
     MSD_CHECK_LAUNCH();
     return MSD_OK;

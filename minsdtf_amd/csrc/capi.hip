@@ -27,6 +27,7 @@ void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
 void msd_set_attn_qf(int v);
+void msd_set_xattn_nw(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "gn_impl" (1 = single-launch per-group
  * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
 extern "C" int msd_set_option(const char* key, int value) {
@@ -36,6 +37,10 @@ extern "C" int msd_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "attn_qf") == 0) {     // 0 = automatic [default], 1 / 2 = 64 / 128 queries per workgroup
         msd_set_attn_qf(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "xattn_nw") == 0) {    // 0 = automatic [default], 4 / 8 = 64 / 128 queries per fused cross-attention workgroup
+        msd_set_xattn_nw(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "gn_wide") == 0) {   // 1 = 1024-thread GroupNorm workgroups for mid-sized tensors [default]

@@ -241,6 +241,8 @@ SHORTCUT_FOLD_MAX_PIXELS = int(os.environ.get("MSD_SHORTCUT_FOLD_MAX_PIXELS", "4
 W_CHUNK_MAJOR = os.environ.get("MSD_W_CHUNK_MAJOR", "1") != "0"
 # the concatenated time_emb_proj Dense of the preparation plan on the MFMA path (bf16 weights and input, fp32 table)
 MFMA_TEMB_PROJ = os.environ.get("MSD_MFMA_TEMB_PROJ", "1") != "0"
+# attn2.to_q + the attention over the text context as one launch at the 64x64 / 32x32 levels (msd_cross_attention_q)
+XATTN_FUSED = os.environ.get("MSD_XATTN_FUSED", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- layer emitters
@@ -383,18 +385,27 @@ class Emitter:
         t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0, ln_out=fold)
         p.free(a1, t0)
         # cross-attention over the text context (k, v^T precomputed once per prompt)
-        if fold:
-            q2 = self.conv(t1, tb + ".attn2.to_q", C, bias=False, ln_in=t1.ln)
-            p.free(t1.ln[0])
-        else:
-            n2 = self.layer_norm(t1, tb + ".norm2")
-            q2 = self.conv(n2, tb + ".attn2.to_q", C, bias=False)
-            p.free(n2)
         kc, vtc, tp = ctx_kv[tb + ".attn2"]
         a2 = p.act(B, H, Wd, C)
-        p.rec(ops.attention, q=q2.buf, k=kc, vt=vtc, out=a2.buf, batch=B, heads=heads, head_dim=d, s=S, t=ctx_len, q_ld=C,
-              k_ld=C, vt_ld=tp, o_ld=C, scale=d ** -0.5, q_prescaled=True, name=tb + ".attn2")
-        p.free(q2)
+        if fold and XATTN_FUSED and heads == 8 and d in (40, 80) and ctx_len <= 96:
+            # norm2 -> to_q -> attention over the 77 context tokens as ONE launch (msd_cross_attention_q)
+            wn = tb + ".attn2.to_q"
+            p.rec(ops.cross_attention_q, x=t1.buf, ln_in=t1.ln[0], ln_in_slots=t1.ln[1], wq=self.W[wn + ".lnw"],
+                  ln_colsum=self.W[wn + ".lncs"], bias=self.W[wn + ".lnb"], k=kc, vt=vtc, out=a2.buf, batch=B, heads=heads,
+                  head_dim=d, s=S, t=ctx_len, k_ld=C, vt_ld=tp, o_ld=C, ln_eps=EPS, w_layout=1 if W_CHUNK_MAJOR else 0,
+                  name=tb + ".attn2")
+            p.free(t1.ln[0])
+        else:
+            if fold:
+                q2 = self.conv(t1, tb + ".attn2.to_q", C, bias=False, ln_in=t1.ln)
+                p.free(t1.ln[0])
+            else:
+                n2 = self.layer_norm(t1, tb + ".norm2")
+                q2 = self.conv(n2, tb + ".attn2.to_q", C, bias=False)
+                p.free(n2)
+            p.rec(ops.attention, q=q2.buf, k=kc, vt=vtc, out=a2.buf, batch=B, heads=heads, head_dim=d, s=S, t=ctx_len, q_ld=C,
+                  k_ld=C, vt_ld=tp, o_ld=C, scale=d ** -0.5, q_prescaled=True, name=tb + ".attn2")
+            p.free(q2)
         t2 = self.conv(a2, tb + ".attn2.to_out.0", C, residual=t1, ln_out=fold)
         p.free(a2, t1)
         # feed-forward: GEGLU fused into the first GEMM's epilogue

@@ -141,6 +141,17 @@ def attention(*, q, k, vt, out, batch, heads, head_dim, s, t, q_ld, k_ld, vt_ld,
     return Call(lib.msd_attention, (C.byref(a),), name, keep=a)
 
 
+def cross_attention_q(*, x, ln_in, ln_in_slots, wq, ln_colsum, bias, k, vt, out, batch, heads, head_dim, s, t, k_ld, vt_ld, o_ld,
+                      ln_eps=1e-5, w_layout=0, name="cross_attention_q") -> Call:
+    """attn2.to_q (LayerNorm folded in) + attention over the text context in one launch (msd_cross_attention_q)."""
+    lib = _lib.load()
+    a = _lib.MsdCrossAttnQ()
+    a.x, a.ln_in, a.wq, a.ln_colsum, a.bias, a.k, a.vt, a.out = _p(x), _p(ln_in), _p(wq), _p(ln_colsum), _p(bias), _p(k), _p(vt), _p(out)
+    a.batch, a.heads, a.head_dim, a.s, a.t = batch, heads, head_dim, s, t
+    a.k_ld, a.vt_ld, a.o_ld, a.ln_in_slots, a.ln_eps, a.w_layout = k_ld, vt_ld, o_ld, ln_in_slots, float(ln_eps), int(w_layout)
+    return Call(lib.msd_cross_attention_q, (C.byref(a),), name, keep=a)
+
+
 def softmax_rows(*, x, out, rows, cols, ld_in, ld_out, scale, name="softmax_rows") -> Call:
     lib = _lib.load()
     return Call(lib.msd_softmax_rows, (_p(x), _p(out), rows, cols, ld_in, ld_out, C.c_float(scale)), name)

@@ -562,6 +562,68 @@ def test_attention(gpu, case, qf, presc):
     close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"{case} qf={qf} presc={presc}")
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=2, S=256, d=40, T=77, slots=5),      # the UNet's 64x64-level shape family (C = 320), text context
+    dict(B=1, S=200, d=40, T=77, slots=4),      # ragged query tile
+    dict(B=2, S=128, d=80, T=77, slots=10),     # 32x32 level (C = 640)
+    dict(B=1, S=64, d=80, T=96, slots=5),       # the largest context the kernel takes
+    dict(B=1, S=64, d=40, T=13, slots=3, spike=True),   # short context, one dominant key
+])
+@pytest.mark.parametrize("layout,nw", [(1, 4), (0, 4), (1, 8)])   # weight layout; 64 / 128 queries per workgroup (picked by grid size: both forced)
+def test_cross_attention_q(gpu, case, layout, nw):
+    """msd_cross_attention_q: attn2.to_q (LayerNorm folded in) + attention over the text context in one launch, against the
+    fp32 reference LayerNorm -> Dense -> softmax(q k^T) v and against the two launches it replaces."""
+    from minsdtf_amd import _lib, ops, packing
+
+    torch.manual_seed(17)
+    B, S, d, T, slots = case["B"], case["S"], case["d"], case["T"], case["slots"]
+    H, C = 8, 8 * case["d"]
+    Tp = (T + 7) // 8 * 8
+    x = bf(torch.randn(B * S, C) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.3 * torch.randn(C), 0.2 * torch.randn(C)
+    wq = bf(torch.randn(C, C) / math.sqrt(C))            # (in, out)
+    k, v = bf(torch.randn(B, T, C)), bf(torch.randn(B, T, C))
+    if case.get("spike"):
+        k[:, T // 2] *= 8.0
+        k = bf(k)
+    c2 = (d ** -0.5) * 1.4426950408889634                 # folded into the projection, as models._q_prescale does
+    ln = F.layer_norm(x, (C,), gamma, beta, eps=1e-5)
+    q = bf(ln @ (wq * c2))
+    qh = q.view(B, S, H, d).permute(0, 2, 1, 3)
+    kh = k.view(B, T, H, d).permute(0, 2, 1, 3)
+    vh = v.view(B, T, H, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax((qh @ kh.transpose(-1, -2)) * math.log(2.0), -1) @ vh).permute(0, 2, 1, 3).reshape(B * S, C)
+
+    dev = gpu
+    wf, cs, cb = packing.fold_layer_norm((wq * c2).t().contiguous(), None, gamma.numpy(), beta.numpy(), dev)
+    wdev = packing.chunk_major(wf) if layout else wf
+    # row-moment partials as a producing GEMM would leave them: (sum, sum of squares) of the stored bf16 row per column group
+    edges = [round(i * C / slots) for i in range(slots + 1)]
+    st = torch.stack([torch.stack([x[:, a:b_].sum(1), (x[:, a:b_] ** 2).sum(1)], -1) for a, b_ in zip(edges[:-1], edges[1:])], 1)
+    stats = st.to(torch.float32).contiguous().to(dev)
+    xd, kd = x.to(torch.bfloat16).to(dev), k.to(torch.bfloat16).to(dev)
+    vt = torch.full((B, C, Tp), float("nan"), dtype=torch.bfloat16, device=dev)   # (padding keys hold garbage, as in the arena)
+    vt[:, :, :T] = v.permute(0, 2, 1).to(torch.bfloat16).to(dev)
+    out = torch.full((B * S, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    _lib.load().msd_set_option(b"xattn_nw", nw)
+    try:
+        run_calls(ops.cross_attention_q(x=xd, ln_in=stats, ln_in_slots=slots, wq=wdev, ln_colsum=cs, bias=cb, k=kd, vt=vt, out=out, batch=B,
+                                        heads=H, head_dim=d, s=S, t=T, k_ld=C, vt_ld=Tp, o_ld=C, w_layout=layout))
+    finally:
+        _lib.load().msd_set_option(b"xattn_nw", 0)
+    tol = dict(rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())))
+    close(out, ref, what=f"{case} fused", **tol)
+    # the two launches it replaces
+    q2 = torch.full((B * S, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    out2 = torch.full_like(out, float("nan"))
+    run_calls([ops.conv_gemm(a0=xd, w=wdev, out=q2, batch=1, h_in=B * S, w_in=1, c0=C, N=C, bias=cb, ln_in=stats, ln_in_slots=slots,
+                             ln_colsum=cs, w_layout=layout),
+               ops.attention(q=q2, k=kd, vt=vt, out=out2, batch=B, heads=H, head_dim=d, s=S, t=T, q_ld=C, k_ld=C, vt_ld=Tp, o_ld=C,
+                             scale=d ** -0.5, q_prescaled=True)])
+    close(out2, ref, what=f"{case} two launches", **tol)
+    close(out, out2.float().cpu(), what=f"{case} fused vs two launches", **tol)
+
+
 def test_softmax_rows(gpu):
     from minsdtf_amd import ops
 
