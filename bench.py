@@ -279,6 +279,11 @@ def kernel_roofline(sd, b, nsteps, control=False):
             fl = 4.0 * s.batch * s.heads * s.s * s.t * s.head_dim
             byt = 2 * s.batch * s.heads * s.head_dim * (2 * s.s + 2 * s.t)
             return ("self-attention" if s.s == s.t else "cross-attention"), fl, byt
+        if isinstance(s, _lib.MsdCrossAttnQ):   # attn2.to_q + attention over the text context in one launch
+            C = s.heads * s.head_dim
+            fl = 2.0 * s.batch * s.s * C * C + 4.0 * s.batch * s.heads * s.s * s.t * s.head_dim
+            byt = 2 * (2 * s.batch * s.s * C + C * C + 2 * s.batch * s.t * C)
+            return "cross-attention + to_q (fused)", fl, byt
         if isinstance(s, _lib.MsdGroupNorm):
             return "group_norm(+swish)", 0.0, 4 * s.batch * s.hw * (s.c0 + s.c1)
         fn = c.fn.__name__ if hasattr(c.fn, "__name__") else str(c.fn)
