@@ -114,3 +114,25 @@ def test_lora_file_vs_oracle_on_merged_weights(gpu, ckpt, tmp_path):
     p, p_plain = O.psnr(got, ref), O.psnr(plain, ref)
     print(f"LoRA file route: final-latent PSNR {p:.1f} dB vs the oracle on merged weights (without the LoRA: {p_plain:.1f} dB)")
     assert p >= 40.0 and p_plain < p - 6.0
+
+
+def test_new_weights_retire_the_cached_engine(gpu):
+    """set_weights / load_synthetic on a model AFTER an image was generated: the cached DenoiseEngine (plans + captured
+    hipGraphs hold raw addresses of the packed weights) must not be reused — the second result equals a fresh pipeline's
+    with the new weights, bit for bit, and differs from the first."""
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+
+    ctx, unc, noise = _inputs()
+    a = StableDiffusion(64, 64, jit_compile=True, device=gpu)
+    a.diffusion_model.load_synthetic(seed=0, bias_scale=0.05)
+    first = _run(a, ctx, unc, noise, return_latent=True)
+    a.diffusion_model.load_synthetic(seed=1, bias_scale=0.05)      # frees the old packed weights
+    junk = [torch.full((1 << 22,), float("nan"), device=gpu) for _ in range(16)]   # recycle the freed memory with NaNs
+    second = _run(a, ctx, unc, noise, return_latent=True)
+    del junk
+    b = StableDiffusion(64, 64, jit_compile=True, device=gpu)
+    b.diffusion_model.load_synthetic(seed=1, bias_scale=0.05)
+    fresh = _run(b, ctx, unc, noise, return_latent=True)
+    assert np.isfinite(second).all()
+    np.testing.assert_array_equal(second, fresh)
+    assert not np.array_equal(first, second)
