@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: 512x512 images/sec (whole node), SD1.5 25-step txt2img on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by torch.distributed.run (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE in the environment), or
+run plainly — then this process becomes a launcher that starts the N ranks itself (`launch_ranks`) and relays rank 0's
+line.  The line carries `n_ranks_seen` (the process group's world size) and `rank_devices` (what each rank ran on).
 
 One "step" = one full pass of the hot path over this rank's batch: the 25-step cond+uncond denoise
 loop (50 UNet forwards per image, CFG 7.5, rescale 0.7) + the VAE decode to uint8, on synthetic
@@ -41,7 +45,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -57,67 +61,199 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="library A/B switch passed to msd_set_option (same-box comparisons), e.g. --opt attn_swp=0")
     ap.add_argument("--streams", type=int, default=0, help="1: cond+uncond as one batch-2B forward; 2: two HIP streams; 0: automatic")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (the measured path); gloo: launcher self-test on CPU")
+    ap.add_argument("--stub-local", action="store_true",
+                    help="replace the GPU pipeline by a trivial per-sample generator (launcher / sharding self-test; the "
+                         "line is marked stub and is not a measurement)")
+    return ap.parse_args(argv)
+
+
+def _free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks ourselves, one child process per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the child's environment, exactly what torch.distributed.run would set).
+    This parent never initialises the GPU (no torch.cuda call; counting devices is not one), so starting children is safe;
+    the children are fresh interpreters, nothing is re-exec'd.  Rank 0's stdout (the ONE JSON line) is relayed; the exit
+    code is the worst of the children's; a failed rank ends the others (exact PIDs), there is no retry."""
+    import subprocess
+
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSD_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only mode this host driver supports for RCCL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    log(f"launcher: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    rc = 0
+    line = None
+    pending = set(range(n))
+    out0 = []
+    import threading
+
+    def pump():   # rank 0's stdout must be drained while we poll, or a full pipe would stall it
+        for ln in procs[0].stdout:
+            out0.append(ln.decode(errors="replace"))
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                log(f"launcher: rank {r} exited with code {code}")
+                rc = rc or code
+                for q in pending:   # the other ranks would wait for it in a collective forever
+                    procs[q].terminate()
+        time.sleep(0.05)
+    th.join(timeout=10)
+    for ln in out0:
+        if ln.lstrip().startswith("{"):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    if rc == 0 and line is None:
+        log("launcher: rank 0 printed no JSON line")
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc if 0 <= rc < 256 else 1
+
+
+def stub_generate(ctx, unc, z, *rest):
+    """--stub-local: a per-sample function of the sliced inputs (no cross-sample coupling, like the real pipeline), so the
+    gathered batch proves broadcast, slicing and gather order.  uint8 [b, 4, 4, 3]."""
+    import torch
+
+    ctx, unc, z = (torch.as_tensor(np.asarray(a.cpu()) if isinstance(a, torch.Tensor) else a).float() for a in (ctx, unc, z))
+    v = z.reshape(z.shape[0], -1)[:, :48] * 20 + ctx.mean(dim=(1, 2))[:, None] * 100 + unc.std(dim=(1, 2), unbiased=False)[:, None] * 10
+    for e in rest:   # per-sample extras (hint images) move their own sample only
+        e = torch.as_tensor(np.asarray(e.cpu()) if isinstance(e, torch.Tensor) else e).float()
+        v = v + e.reshape(e.shape[0], -1).mean(dim=1, keepdim=True) * 50
+    return torch.clamp(v + 128, 0, 255).to(torch.uint8).reshape(z.shape[0], 4, 4, 3)
+
+
+def rank_devices(dev, world):
+    """What every rank ran on, gathered: proves to the reader of the line that the process group saw `world` ranks on
+    `world` different devices (hipGetDevice ordinal + PCI bus id where the runtime reports one)."""
+    import torch
+    import torch.distributed as dist
+
+    me = {"rank": int(os.environ.get("RANK", 0)), "pid": os.getpid(), "device": str(dev)}
+    if dev.type == "cuda":
+        me["hip_device"] = int(torch.cuda.current_device())
+        pr = torch.cuda.get_device_properties(dev)
+        me["name"] = pr.name
+        for k in ("pci_bus_id", "uuid"):
+            if hasattr(pr, k):
+                me[k] = str(getattr(pr, k))
+    if world == 1:
+        return [me]
+    got = [None] * world
+    dist.all_gather_object(got, me)
+    return got
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's plain `python bench.py --gpus N`: become the launcher BEFORE anything touches a GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
 
     import torch
     import torch.distributed as dist
 
     from minsdtf_amd import dist as mdist
-    from minsdtf_amd import weights as Wt
-    from minsdtf_amd.stable_diffusion import StableDiffusion
 
-    if args.opt:
-        from minsdtf_amd import _lib
-
-        for kv in args.opt:
-            k, v = kv.split("=")
-            _lib.check(_lib.load().msd_set_option(k.encode(), int(v)), f"msd_set_option({kv})")
     rank, local_rank, world = mdist.env_rank()
     if world != args.gpus:
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    mdist.init("nccl")
+    stub = args.stub_local
+    if args.backend == "nccl":
+        if torch.cuda.device_count() <= local_rank:
+            log(f"[rank {rank}] needs HIP device {local_rank}, {torch.cuda.device_count()} visible")
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        if not stub:
+            raise SystemExit("--backend gloo is the CPU self-test of the launcher / sharding path: it needs --stub-local")
+        dev = torch.device("cpu")
+    mdist.init(args.backend)
+    n_ranks_seen = mdist.world_size()
+    assert n_ranks_seen == world, (n_ranks_seen, world)
 
     size, nsteps, b = args.size, args.denoise_steps, args.batch_per_gpu
     h = size // 8
     gb = b * world
-    t0 = time.time()
-    sd = StableDiffusion(size, size, jit_compile=not args.no_graph, device=dev)
-    sd.denoise_streams = args.streams or None
-    unet_arrays = sd.diffusion_model.load_synthetic(seed=0)
-    vae_arrays = sd.image_decoder.load_synthetic(seed=0)
-    hint_img = None
-    if args.controlnet:  # zero-convs are NOT zero (bias_scale > 0 also draws non-trivial biases), else the path is vacuous
-        sd.control_net.load_synthetic(seed=0, bias_scale=0.05)
-        sd.hint_net.load_synthetic(seed=0, bias_scale=0.05)
-        hint_img = np.random.default_rng(7).integers(0, 256, (b, size, size, 3)).astype(np.float32) / 255.0
-    if rank != 0 or args.no_cpu_baseline:
-        unet_arrays = vae_arrays = None
-    log(f"[rank {rank}] weights generated + packed in {time.time() - t0:.1f}s")
-
     rng = np.random.default_rng(1234)
     ctx = rng.standard_normal((gb, 77, 768)).astype(np.float32)
     unc = rng.standard_normal((gb, 77, 768)).astype(np.float32)
     noise = np.random.default_rng(0).standard_normal((gb, h, h, 4)).astype(np.float32)
+    hints = ()
+    if args.controlnet:   # one hint image per sample of the GLOBAL batch; it travels in the same broadcast (§8e)
+        hints = (np.random.default_rng(7).integers(0, 256, (gb, size, size, 3)).astype(np.float32) / 255.0,)
+    if rank != 0:   # only rank 0's inputs count: the others hand in right-shaped garbage
+        ctx, unc, noise = np.zeros_like(ctx), np.ones_like(unc), np.full_like(noise, 7.0)
+        hints = tuple(np.zeros_like(x) for x in hints)
 
-    def local(c, u, z):
-        """This rank's slice: prepare -> 25-step loop -> decode.  c / u / z arrive as device tensors (N > 1: views of the
-        one broadcast buffer) or host arrays (N = 1)."""
-        with phase("prepare", args.sync_phases):   # uploads + context K/V, time-embedding tables (+ HintNet)
-            eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, args.controlnet)
-            eng.prepare(eng.contexts(u, c), z, sd.scheduler, None, 0, hint_img)
-        with phase("denoise_loop", args.sync_phases):
-            eng.run_steps(nsteps, None)
-        with phase("vae_decode", args.sync_phases):
-            return sd.image_decoder.decode_to_uint8(eng.latent)
+    sd = unet_arrays = vae_arrays = None
+    if stub:
+        local = stub_generate
+        out_shape = (gb, 4, 4, 3)
+    else:
+        from minsdtf_amd.stable_diffusion import StableDiffusion
+
+        if args.opt:
+            from minsdtf_amd import _lib
+
+            for kv in args.opt:
+                k, v = kv.split("=")
+                _lib.check(_lib.load().msd_set_option(k.encode(), int(v)), f"msd_set_option({kv})")
+        t0 = time.time()
+        sd = StableDiffusion(size, size, jit_compile=not args.no_graph, device=dev)
+        sd.denoise_streams = args.streams or None
+        unet_arrays = sd.diffusion_model.load_synthetic(seed=0)
+        vae_arrays = sd.image_decoder.load_synthetic(seed=0)
+        if args.controlnet:  # zero-convs are NOT zero (bias_scale > 0 also draws non-trivial biases), else the path is vacuous
+            sd.control_net.load_synthetic(seed=0, bias_scale=0.05)
+            sd.hint_net.load_synthetic(seed=0, bias_scale=0.05)
+        if rank != 0 or args.no_cpu_baseline:
+            unet_arrays = vae_arrays = None
+        log(f"[rank {rank}] weights generated + packed in {time.time() - t0:.1f}s")
+        out_shape = (gb, size, size, 3)
+
+        def local(c, u, z, *hint):
+            """This rank's slice: prepare -> 25-step loop -> decode.  c / u / z (/ hint) arrive as device tensors (N > 1:
+            views of the one broadcast buffer) or host arrays (N = 1)."""
+            with phase("prepare", args.sync_phases):   # uploads + context K/V, time-embedding tables (+ HintNet)
+                eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, args.controlnet)
+                eng.prepare(eng.contexts(u, c), z, sd.scheduler, None, 0, hint[0] if hint else None)
+            with phase("denoise_loop", args.sync_phases):
+                eng.run_steps(nsteps, None)
+            with phase("vae_decode", args.sync_phases):
+                return sd.image_decoder.decode_to_uint8(eng.latent)
 
     def one_job():
-        sd.scheduler.set_timesteps(nsteps)
-        return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases)
+        if sd is not None:
+            sd.scheduler.set_timesteps(nsteps)
+        return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases, per_sample=hints)
 
     elapsed, img = timed_jobs(one_job, args.steps, args.warmup, dev)
-    assert tuple(img.shape) == (gb, size, size, 3) and img.dtype == torch.uint8 and (rank != 0 or img.device.type == "cpu")
+    assert tuple(img.shape) == out_shape and img.dtype == torch.uint8 and (rank != 0 or img.device.type == "cpu")
 
     images = gb * args.steps
     value = images / elapsed
@@ -129,33 +265,22 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"SD1.5 {size}x{size} {nsteps}-step txt2img, CFG 7.5 + rescale 0.7, batch {b}/GPU, "
                                f"UNet+VAE{'+ControlNet' if args.controlnet else ''} HIP path, random-init weights", "global_batch": gb,
-                   "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph,
-                   "cond_uncond": "two HIP streams" if sd._engine(b, 77, 77, nsteps, 7.5, 0.7, args.controlnet).dual else "one fused batch"},
-        "tflops_per_gpu": round(tflop_per_image * b * args.steps / elapsed, 2),
+                   "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph},
+        "n_ranks_seen": n_ranks_seen, "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
+        "launcher": os.environ.get("MSD_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "external" if world > 1 else "none"),
+        "rank_devices": rank_devices(dev, world),
     }
+    if stub:
+        # a self-test of launcher + broadcast + slicing + gather: NOT a measurement, and it says so in every field a reader uses
+        out.update(metric="STUB launcher self-test (no GPU work; not a measurement)", dtype="none", data="stub", stub=True,
+                   config={"workload": "stub per-sample generator", "global_batch": gb, "parallelism": f"batch-shard x{world}"},
+                   image_sha1=__import__("hashlib").sha1(img.numpy().tobytes()).hexdigest() if rank == 0 else None)
+    else:
+        out["config"]["cond_uncond"] = "two HIP streams" if sd._engine(b, 77, 77, nsteps, 7.5, 0.7, args.controlnet).dual else "one fused batch"
+        out["tflops_per_gpu"] = round(tflop_per_image * b * args.steps / elapsed, 2)
 
-    if rank == 0:
-        # the two halves of the job, timed separately (SURVEY.md §8d timing protocol): hipGraph replays on resident inputs
-        eng = sd._engine(b, 77, 77, nsteps, 7.5, 0.7, args.controlnet)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        sd.scheduler.set_timesteps(nsteps)
-        eng.prepare(eng.contexts(unc[:b], ctx[:b]), noise[:b], sd.scheduler, None, 0, hint_img)
-        torch.cuda.synchronize()
-        ev[0].record()
-        eng.run_steps(nsteps, None)
-        ev[1].record()
-        sd.image_decoder.decode_to_uint8(eng.latent)
-        ev[2].record()
-        torch.cuda.synchronize()
-        out["ms_denoise_loop"] = round(ev[0].elapsed_time(ev[1]), 3)
-        out["ms_vae_decode"] = round(ev[1].elapsed_time(ev[2]), 3)
-    if rank == 0 and not args.no_roofline:
-        out["roofline"], out["roofline_by_kernel"], extra = kernel_roofline(sd, b, nsteps, args.controlnet)
-        out["eager_ms_per_unet_step_by_entry_point"] = extra  # event-per-launch pass (includes ~1-2 us of event gap per call)
-    if rank == 0 and world == 1 and not args.controlnet:
-        out["psnr_db_vs_oracle_golden"] = golden_psnr(sd, size, nsteps)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(unet_arrays, vae_arrays, ctx[:1], unc[:1], noise[:1], nsteps)
+    if rank == 0 and not stub:
+        rank0_extras(out, args, sd, world, b, nsteps, size, ctx, unc, noise, hints, unet_arrays, vae_arrays)
     if rank == 0:
         if args.sync_phases and phase.wall_ms:   # (profiling runs: host wall time per phase, device drained at each end)
             log("phase wall ms per job: " + ", ".join(f"{k} {v[0] / v[1]:.3f}" for k, v in phase.wall_ms.items()))
@@ -163,6 +288,35 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rank0_extras(out, args, sd, world, b, nsteps, size, ctx, unc, noise, hints, unet_arrays, vae_arrays):
+    """Rank 0, outside the timed region: the two halves of a job timed separately, the roofline block of the dominant
+    kernel family, parity against the committed oracle latent, and the CPU baseline."""
+    import torch
+
+    # the two halves of the job, timed separately (SURVEY.md §8d timing protocol): hipGraph replays on resident inputs
+    eng = sd._engine(b, 77, 77, nsteps, 7.5, 0.7, args.controlnet)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    sd.scheduler.set_timesteps(nsteps)
+    eng.prepare(eng.contexts(unc[:b], ctx[:b]), noise[:b], sd.scheduler, None, 0, hints[0][:b] if hints else None)
+    torch.cuda.synchronize()
+    ev[0].record()
+    eng.run_steps(nsteps, None)
+    ev[1].record()
+    sd.image_decoder.decode_to_uint8(eng.latent)
+    ev[2].record()
+    torch.cuda.synchronize()
+    out["ms_denoise_loop"] = round(ev[0].elapsed_time(ev[1]), 3)
+    out["ms_vae_decode"] = round(ev[1].elapsed_time(ev[2]), 3)
+    out["launches_per_step"] = len(eng.calls)   # C-ABI calls of one sampler step (split-K reductions / second GroupNorm launches come on top)
+    if not args.no_roofline:
+        out["roofline"], out["roofline_by_kernel"], extra = kernel_roofline(sd, b, nsteps, args.controlnet)
+        out["eager_ms_per_unet_step_by_entry_point"] = extra  # event-per-launch pass (includes ~1-2 us of event gap per call)
+    if world == 1 and not args.controlnet:
+        out["psnr_db_vs_oracle_golden"] = golden_psnr(sd, size, nsteps)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(unet_arrays, vae_arrays, ctx[:1], unc[:1], noise[:1], nsteps)
 
 
 class phase:
@@ -193,16 +347,14 @@ class phase:
             torch.cuda.nvtx.range_pop()
 
 
-def sharded_job(local, ctx, unc, noise, dev, sync_phases=False):
-    """One whole job on this rank: ONE packed broadcast of the global contexts + noise (RCCL, device resident), the local
-    generator on this rank's slice, all-gather of the uint8 images, and the copy of the gathered batch to host memory on
-    rank 0 (the timed job ends with the uint8 images on the host)."""
-    import torch.distributed as dist
-
+def sharded_job(local, ctx, unc, noise, dev, sync_phases=False, per_sample=()):
+    """One whole job on this rank: ONE packed broadcast of the global contexts + noise (+ ControlNet hint images) (RCCL,
+    device resident), the local generator on this rank's slice, all-gather of the uint8 images, and the copy of the
+    gathered batch to host memory on rank 0 (the timed job ends with the uint8 images on the host)."""
     from minsdtf_amd import dist as mdist
 
-    img = mdist.generate_sharded(local, ctx, unc, noise, dev)
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    img = mdist.generate_sharded(local, ctx, unc, noise, dev, per_sample=per_sample)
+    rank = mdist.rank()
     with phase("d2h", sync_phases):
         return img.cpu() if rank == 0 else img
 

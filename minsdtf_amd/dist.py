@@ -15,7 +15,7 @@ Both are a few MB at most (latency-bound), so they are plain RCCL collectives
 from __future__ import annotations
 
 import os
-from typing import Callable, Optional, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -48,16 +48,27 @@ def shard_bounds(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
+def world_size() -> int:
+    """Ranks of the initialised default process group (1 when torch.distributed is not in use)."""
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def broadcast_inputs(arrays, device, src: int = 0):
     """ONE broadcast from `src` of a list of fp32 arrays (same shapes on every rank; contents only matter on `src`),
     packed into a single flat device buffer; returns device-resident views of it, one per array — nothing comes back to
-    the host (the denoise engine copies device -> device).  Single process: the arrays are returned as they are."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return list(arrays)
+    the host (the denoise engine copies device -> device).  Single process: host inputs come back as fp32 numpy arrays,
+    tensors as they are (so a caller sees the same kinds of object at world = 1 and world > 1: something with
+    ``.shape`` that slices along the batch)."""
+    if world_size() == 1:
+        return [a if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float32) for a in arrays]
     shapes = [tuple(np.shape(a)) for a in arrays]
     sizes = [int(np.prod(sh)) for sh in shapes]
     if dist.get_rank() == src:
-        flat = np.concatenate([np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in arrays])
+        flat = np.concatenate([_host_f32(a).reshape(-1) for a in arrays])
         buf = torch.from_numpy(flat).to(device)
     else:
         buf = torch.empty(sum(sizes), dtype=torch.float32, device=device)
@@ -69,9 +80,15 @@ def broadcast_inputs(arrays, device, src: int = 0):
     return out
 
 
+def _host_f32(a) -> np.ndarray:
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
 def all_gather_images(local: torch.Tensor) -> torch.Tensor:
-    """uint8 [b, H, W, 3] per rank -> [world*b, H, W, 3] on every rank, rank order = batch order."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    """[b, ...] per rank (uint8 images, or fp32 latents) -> [world*b, ...] on every rank, rank order = batch order."""
+    if world_size() == 1:
         return local
     world = dist.get_world_size()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -79,16 +96,26 @@ def all_gather_images(local: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def generate_sharded(generate_local: Callable[[np.ndarray, np.ndarray, np.ndarray], torch.Tensor], context: np.ndarray,
-                     uncond_context: np.ndarray, noise: np.ndarray, device) -> torch.Tensor:
-    """Run `generate_local(ctx_slice, uncond_slice, noise_slice) -> uint8 tensor [b,H,W,3]` on this
-    rank's slice of the global batch and gather all images.
+def generate_sharded(generate_local: Callable[..., torch.Tensor], context, uncond_context, noise, device,
+                     per_sample: Sequence = (), shared: Sequence = (), shard: bool = True) -> torch.Tensor:
+    """Run ``generate_local(ctx_slice, uncond_slice, noise_slice, *per_sample_slices, *shared) -> tensor [b, ...]`` on this
+    rank's slice of the global batch and gather the results of all ranks in batch order.
 
-    context / uncond_context: (B, T, 768); noise: (B, h, w, 4) for the GLOBAL batch (valid on
-    rank 0, right shape elsewhere)."""
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    context, uncond_context, noise = broadcast_inputs([context, uncond_context, noise], device)   # device tensors when world > 1
-    lo, hi = shard_bounds(noise.shape[0], rank, world)
-    img = generate_local(context[lo:hi], uncond_context[lo:hi], noise[lo:hi])
+    context / uncond_context: (B, T, 768); noise: (B, h, w, 4) — for the GLOBAL batch, valid on rank 0, right shape
+    elsewhere (host arrays or tensors).  ``per_sample``: further arrays with the global batch as leading dimension (the
+    ControlNet hint images, reference stable_diffusion.py:427-441; the inpaint noise) — sliced like the noise.  ``shared``:
+    arrays every rank needs whole (an encoded reference image).  ALL of them travel in the ONE packed broadcast.
+    `generate_local` receives device tensors when world > 1 (views of the broadcast buffer) and fp32 host arrays /
+    the caller's tensors when world = 1.  ``shard=False``: no exchange at all, this rank runs the whole batch it was given
+    (independent replicas under a process group that exists for other reasons)."""
+    r, world = (rank(), world_size()) if shard else (0, 1)
+    n_ps = len(per_sample)
+    arrays = [context, uncond_context, noise, *per_sample, *shared]
+    if world == 1:
+        got = [a if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float32) for a in arrays]
+        return generate_local(*got)
+    got = broadcast_inputs(arrays, device)
+    lo, hi = shard_bounds(int(got[2].shape[0]), r, world)
+    sliced = [a[lo:hi] for a in got[:3 + n_ps]]
+    img = generate_local(*sliced, *got[3 + n_ps:])
     return all_gather_images(img)

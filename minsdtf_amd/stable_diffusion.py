@@ -15,8 +15,13 @@ properties, same return value (``uint8 (B, H, W, 3)``).  What differs is where t
   what a maintainer gets by only swapping the model classes; tests use it to check that both
   routes agree.
 
-Out of scope here: the CLIP text front-end (prompts must arrive as embeddings, or
-through a user-supplied ``text_frontend``), inpainting, TCD.
+* Under a ``torch.distributed`` process group ``generate_image`` shards the batch over the ranks (SURVEY.md §8e;
+  ``shard_batch``): one packed broadcast of rank 0's inputs, no traffic inside a step, one all-gather of the result.
+
+Also on this path: ``image_to_image`` (VAE encoder + shortened schedule), ``inpaint`` (latent blend
+inside the sampler kernel, pixel blend before the uint8 cast), the TCD sampler, and the CLIP text models behind
+``encode_text`` (token ids or, with a local BPE merge list, strings).  Not here: the reference's download helpers and
+its Gradio / Streamlit shells.
 """
 from __future__ import annotations
 
@@ -73,11 +78,9 @@ class DenoiseEngine:
         #  * fused: ONE batch-2B forward;
         #  * dual (streams=2): two batch-B forwards on two HIP streams that fork after the previous
         #    sampler step and join before the next one.
-        # Measured on MI355X at 512x512 (profiles/ r1 notes): one batch-1 pass alone takes 5.1 ms of
-        # kernel time, two of them overlapped on two streams 6.6 ms per step, the fused batch-2 pass
-        # 6.7 ms — the same within noise (5.98 vs 6.03 images/s at batch 1, 8.46 vs 8.55 at batch 2),
-        # because the small-batch kernels are bounded by per-workgroup latency with idle CUs either
-        # way.  Fused is the default (one arena, one kernel chain); dual stays selectable.
+        # The two forms measure the same within noise on MI355X at 512x512 because the small-batch
+        # kernels are bounded by per-workgroup latency with idle CUs either way.  Fused is the default (one arena,
+        # one kernel chain); dual stays selectable.
         if streams is None:
             streams = 1
         self.dual = bool(cfg and streams == 2)
@@ -199,8 +202,9 @@ class DenoiseEngine:
         if not self.cfg:
             return {"cond": context}
         if len(self.passes) == 1:
-            if isinstance(context, torch.Tensor):
-                return {"both": torch.cat([unconditional_context, context], dim=0)}
+            if isinstance(context, torch.Tensor) or isinstance(unconditional_context, torch.Tensor):
+                u, c = _f32_tensor(unconditional_context), _f32_tensor(context)
+                return {"both": torch.cat([u.to(c.device) if isinstance(context, torch.Tensor) else u, c.to(u.device)], dim=0)}
             return {"both": np.concatenate([unconditional_context, context], axis=0)}
         return {"uncond": unconditional_context, "cond": context}
 
@@ -273,14 +277,17 @@ class DenoiseEngine:
             callback(i + 1)
 
     def prepare(self, contexts: Dict[str, np.ndarray], noise: np.ndarray, scheduler: Scheduler, timesteps,
-                start_index: int = 0, hint_image: Optional[np.ndarray] = None, inpaint=None) -> None:
-        """Upload the per-call inputs and run the preparation plan.  inpaint = (init_latent (1,h,w,4),
-        noise (B,h,w,4), latent mask (h,w) or (h,w,1)) for an engine built with inpaint=True."""
+                start_index: int = 0, hint_image: Optional[np.ndarray] = None, inpaint=None, step_noise=None) -> None:
+        """Upload the per-call inputs and run the preparation plan.  Every array may be a host array or a (device) tensor.
+        inpaint = (init_latent (1,h,w,4), noise (B,h,w,4), latent mask (h,w) or (h,w,1)) for an engine built with
+        inpaint=True; step_noise = (B, num_steps, h*w*4) TCD draws made by the caller (sharded runs: the slice of the
+        draws for the global batch) instead of the draws made here."""
         if self.inpaint is not None:
             init, ip_noise, mask = inpaint
-            self.inpaint["init"].copy_(torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32).reshape(-1)))
-            self.inpaint["noise"].copy_(torch.from_numpy(np.ascontiguousarray(ip_noise, dtype=np.float32).reshape(self.B, -1)))
-            m = np.asarray(mask, dtype=np.float32)
+            self.inpaint["init"].copy_(_f32_tensor(init).reshape(-1))
+            self.inpaint["noise"].copy_(_f32_tensor(ip_noise).reshape(self.B, -1))
+            m = mask.detach().cpu().numpy() if isinstance(mask, torch.Tensor) else mask
+            m = np.asarray(m, dtype=np.float32)
             # preprocessed_mask keeps the reference's (width//8, height//8) resize (:301), which is only the latent's
             # (h, w) for square images; the reference's blend then fails to broadcast — fail the same way, loudly
             if m.shape[:2] != (self.h, self.w):
@@ -298,15 +305,18 @@ class DenoiseEngine:
         if self.step_noise is not None:
             # scheduler.py:301 draws np.random.randn(*latent.shape) once per executed step except the last
             self.noise_coef.copy_(torch.from_numpy(scheduler.noise_coefficients()))
-            z = np.zeros((self.num_steps, self.B, self.h * self.w * 4), dtype=np.float32)
-            for i in range(int(start_index), self.num_steps - 1):
-                z[i] = np.random.randn(self.B, self.h, self.w, 4).astype(np.float32).reshape(self.B, -1)
-            self.step_noise.copy_(torch.from_numpy(z))
+            if step_noise is not None:
+                self.step_noise.copy_(_f32_tensor(step_noise).reshape(self.B, self.num_steps, -1).transpose(0, 1))
+            else:
+                z = np.zeros((self.num_steps, self.B, self.h * self.w * 4), dtype=np.float32)
+                for i in range(int(start_index), self.num_steps - 1):
+                    z[i] = np.random.randn(self.B, self.h, self.w, 4).astype(np.float32).reshape(self.B, -1)
+                self.step_noise.copy_(torch.from_numpy(z))
         if self.has_control:
-            hi = np.ascontiguousarray(hint_image, dtype=np.float32)
+            hi = _f32_tensor(hint_image)
             if hi.shape[0] != self.B:   # (one hint for the whole batch: the reference tiles it, :435)
-                hi = np.tile(hi, (self.B // hi.shape[0], 1, 1, 1))
-            self.hint_img.copy_(torch.from_numpy(hi))   # the cond / uncond replicas are made on the device (emit_hintnet)
+                hi = hi.repeat(self.B // hi.shape[0], 1, 1, 1)
+            self.hint_img.copy_(hi)   # the cond / uncond replicas are made on the device (emit_hintnet)
         self.prep.run(torch.cuda.current_stream().cuda_stream)
 
 
@@ -344,6 +354,9 @@ class StableDiffusionBase:
         self.text_frontend = None
         self.bpe_path = None  # local copy of CLIP's bpe_simple_vocab_16e6.txt.gz (or $MSD_BPE_PATH) for string prompts
         self.unconditional_context = None  # (77, 768) embedding of the empty prompt, supplied by the caller
+        # True: under an initialised torch.distributed process group generate_image() treats batch_size as the GLOBAL batch
+        # and shards it over the ranks; False: every rank runs the whole batch on its own (independent replicas)
+        self.shard_batch = True
 
     # ---- public entry points (reference :84-139)
     def text_to_image(self, prompt, negative_prompt=None, batch_size=1, num_steps=50, unconditional_guidance_scale=7.5,
@@ -472,11 +485,8 @@ class StableDiffusionBase:
         return u[None] if u.ndim == 2 else u
 
     def _expand_tensor(self, text_embedding, batch_size):
-        """Reference :495-503."""
-        text_embedding = np.squeeze(text_embedding)
-        if len(text_embedding.shape) == 2:
-            text_embedding = np.repeat(np.expand_dims(text_embedding, axis=0), batch_size, axis=0)
-        return text_embedding
+        """Reference :495-503: one (T, 768) context -> (B, T, 768); a batch of contexts passes through."""
+        return self._batch_of(text_embedding, batch_size, 2)
 
     _get_timestep_embedding = staticmethod(lambda timestep, batch_size, dim=320, max_period=10000:
                                            get_timestep_embedding(timestep, batch_size, dim, max_period))
@@ -516,121 +526,169 @@ class StableDiffusionBase:
         out = correlate1d(image, weights, axis=h_axis, output=None, mode="reflect", cval=0.0, origin=0)
         return correlate1d(out, weights, axis=v_axis, output=None, mode="reflect", cval=0.0, origin=0)
 
-    def preprocessed_mask(self, x, blur_radius=5):
-        """Reference :288-302: path or HxW[xC] array -> ((1,H,W,1) image-resolution mask in [0,1], (1,w/8,h/8,1)
-        latent-resolution mask).  The latent resize takes (img_width//8, img_height//8) as (new_h, new_w), as the
-        reference does — identical for square images."""
-        if type(x) is str:
+    @staticmethod
+    def _pixels(source, pil_mode):
+        """A file path (decoded with PIL in `pil_mode`) or anything array-like -> ndarray."""
+        if type(source) is str:
             from PIL import Image
 
-            x = np.array(Image.open(x).convert("L"))
-        else:
-            x = np.array(x)
-        if len(x.shape) == 2:
-            x = np.expand_dims(x, axis=-1)
-        mask_array = self.resize(x, self.img_height, self.img_width)
-        if mask_array.shape[-1] != 1:
-            mask_array = np.mean(mask_array, axis=-1, keepdims=True)
-        input_mask_array = np.array(mask_array, dtype=np.float32) / 255.0
+            with Image.open(source) as im:
+                return np.array(im.convert(pil_mode))
+        return np.array(source)
+
+    def preprocessed_mask(self, x, blur_radius=5):
+        """Mask (path or HxW[xC] array, 0..255) -> (image-resolution mask (1,H,W,1) in [0,1], latent-resolution mask
+        (1,·,·,1)); behaviour of reference :288-302, pinned by goldens G2e / G7: channels are averaged AFTER the bilinear
+        resize, the optional binomial blur runs at image resolution, and the latent mask is a second bilinear resize of the
+        blurred one to (img_width//8, img_height//8) — rows from the width, as the reference has it (equal for squares)."""
+        m = self._pixels(x, "L")
+        m = m[..., None] if m.ndim == 2 else m
+        m = self.resize(m, self.img_height, self.img_width)
+        if m.shape[-1] > 1:
+            m = m.mean(axis=-1, keepdims=True)
+        unit = np.asarray(m, dtype=np.float32) / 255.0
         if blur_radius is not None:
-            input_mask_array = self.gaussian_blur(input_mask_array, radius=blur_radius, h_axis=0, v_axis=1)
-        latent_mask_tensor = self.resize(input_mask_array, self.img_width // 8, self.img_height // 8)
-        return np.expand_dims(input_mask_array, axis=0), np.expand_dims(latent_mask_tensor, axis=0)
+            unit = self.gaussian_blur(unit, radius=blur_radius, h_axis=0, v_axis=1)
+        small = self.resize(unit, self.img_width // 8, self.img_height // 8)
+        return unit[None], small[None]
 
     def preprocessed_image(self, x):
-        """Reference :277-286: path or HxWx3 array -> ((1,H,W,3) in [0,1], (1,H,W,3) in [-1,1])."""
-        if type(x) is str:
-            from PIL import Image
-
-            x = np.array(Image.open(x).convert("RGB"))
-        else:
-            x = np.array(x)
-        image_array = self.resize(x, self.img_height, self.img_width)
-        image_array = np.array(image_array, dtype=np.float32) / 255.0
-        input_image_array = image_array[None, ..., :3]
-        input_image_tensor = input_image_array * 2.0 - 1.0
-        return input_image_array, input_image_tensor
+        """Picture (path or HxWx3 array, 0..255) -> ((1,H,W,3) in [0,1] for the pixel blend, the same in [-1,1] for the VAE
+        encoder); reference :277-286."""
+        px = self.resize(self._pixels(x, "RGB"), self.img_height, self.img_width)
+        unit = (np.asarray(px, dtype=np.float32) / 255.0)[None, :, :, :3]
+        return unit, unit * 2.0 - 1.0
 
     # ---- the loop (reference :317-486)
+    def _batch_of(self, value, batch_size, sample_ndim):
+        """One sample (rank `sample_ndim`, after dropping size-1 axes like the reference's np.squeeze, :395,:498) is
+        repeated `batch_size` times; a full batch passes through."""
+        value = np.squeeze(value)
+        if value.ndim == sample_ndim:
+            value = np.repeat(value[None], batch_size, axis=0)
+        return value
+
+    def _negative_context(self, negative_prompt, negative_embedding, batch_size):
+        """(B, 77k, 768) unconditional half of the guidance pair (reference :384-392)."""
+        if negative_prompt is None and negative_embedding is None:
+            return np.repeat(self._get_unconditional_context(), batch_size, axis=0)
+        if isinstance(negative_prompt, (np.ndarray, torch.Tensor)):
+            enc = np.asarray(negative_prompt, dtype=np.float32)
+        else:
+            enc = self.encode_text(negative_prompt or "", negative_embedding)
+        return self._batch_of(enc, batch_size, 2)
+
+    def _hint_batch(self, control_net_image, batch_size):
+        """ControlNet conditioning picture -> (B, H, W, 3) in [0,1] (reference :427-437: arrays go through the bilinear
+        resize, files through PIL's)."""
+        if control_net_image is None:
+            return None
+        if isinstance(control_net_image, np.ndarray):
+            px = self.resize(control_net_image, self.img_height, self.img_width)
+        else:
+            from PIL import Image
+
+            px = Image.open(control_net_image).convert("RGB").resize((self.img_width, self.img_height))
+        unit = np.array(px, dtype=np.float32) / 255.0
+        return np.tile(unit[None], (batch_size, 1, 1, 1))
+
     def generate_image(self, encoded_text, negative_prompt=None, batch_size=1, num_steps=50, unconditional_guidance_scale=7.5,
                        diffusion_noise=None, seed=None, negative_embedding=None, control_net_image=None, inpaint_mask=None,
                        mask_blur_strength=None, reference_image=None, reference_image_strength=0.8, guidance_rescale=0.0,
                        callback=None, host_loop=False, return_latent=False):
+        """Reference :317-486.  `batch_size` is the GLOBAL batch: under an initialised torch.distributed process group
+        (and ``shard_batch`` left on) every rank calls this with the same arguments, rank 0's inputs are broadcast, each
+        rank denoises + decodes its contiguous slice and every rank returns the whole gathered batch (minsdtf_amd/dist.py)."""
         if diffusion_noise is not None and seed is not None:
             raise ValueError("`diffusion_noise` and `seed` should not both be passed to `generate_image`. `seed` is only "
                              "used to generate diffusion noise when it's not already user-specified.")
-        context = self._expand_tensor(encoded_text, batch_size)
-        if negative_prompt is None and negative_embedding is None:
-            unconditional_context = np.repeat(self._get_unconditional_context(), batch_size, axis=0)
-        else:
-            if isinstance(negative_prompt, (np.ndarray, torch.Tensor)):
-                unconditional_context = np.asarray(negative_prompt, dtype=np.float32)
-            else:
-                unconditional_context = self.encode_text("" if negative_prompt is None else negative_prompt, negative_embedding)
-            unconditional_context = self._expand_tensor(unconditional_context, batch_size)
-        if diffusion_noise is not None:
-            diffusion_noise = np.squeeze(diffusion_noise)
-            if len(diffusion_noise.shape) == 3:
-                diffusion_noise = np.repeat(np.expand_dims(diffusion_noise, axis=0), batch_size, axis=0)
-        else:
-            diffusion_noise = self._get_initial_diffusion_noise(batch_size, seed)
+        B = batch_size
+        context = self._batch_of(encoded_text, B, 2)
+        unconditional_context = self._negative_context(negative_prompt, negative_embedding, B)
+        noise = self._get_initial_diffusion_noise(B, seed) if diffusion_noise is None else self._batch_of(diffusion_noise, B, 3)
         self.scheduler.set_timesteps(num_steps)
-        # image_to_image (reference :410-418,559-568): encode the reference image, keep only the last
-        # int(n*strength+0.5) steps and start from signal[t_init]*z0 + noise[t_init]*eps.  A strength
-        # outside (0,1) silently falls back to txt2img, like the reference (:410).
-        timesteps_asc = self.scheduler.timesteps[::-1]
+
+        # image_to_image (reference :410-418,559-568): encode the picture, run only the last int(n*strength+0.5) steps,
+        # starting from signal[t]*z0 + noise[t]*eps; a strength outside (0,1) silently means txt2img, like the reference.
+        # inpainting (:406-409,469-475,484-485) needs both mask and picture: every step the latent outside the mask is
+        # replaced by the encoded picture re-noised for that step, and the decoded pixels are blended once more.
+        ascending = self.scheduler.timesteps[::-1]
         run_steps = num_steps
-        # inpainting (reference :406-409,469-475,484-485): the mask only takes effect together with a reference
-        # image; every step the latent outside the mask is replaced by the encoded image re-noised at that step
-        input_mask_array = latent_mask = input_image_array = init_latent = None
-        raw_noise = diffusion_noise
+        pixel_mask = latent_mask = picture01 = encoded = None
+        start_latent = noise
         if inpaint_mask is not None:
-            input_mask_array, latent_mask = self.preprocessed_mask(inpaint_mask, mask_blur_strength)
-        if reference_image is not None and (0.0 < reference_image_strength < 1.0):
-            input_image_array, input_image_tensor = self.preprocessed_image(reference_image)
+            pixel_mask, latent_mask = self.preprocessed_mask(inpaint_mask, mask_blur_strength)
+        if reference_image is not None and 0.0 < reference_image_strength < 1.0:
+            picture01, picture11 = self.preprocessed_image(reference_image)
             run_steps = int(num_steps * reference_image_strength + 0.5)
-            init_time = timesteps_asc[run_steps]
-            init_latent = self.image_encoder.predict_on_batch(input_image_tensor)
-            timesteps_asc = timesteps_asc[:run_steps]
-            diffusion_noise = (self.scheduler.signal_rates[init_time] * np.repeat(init_latent, batch_size, axis=0)
-                               + self.scheduler.noise_rates[init_time] * diffusion_noise)
-        inpaint = (init_latent, raw_noise, latent_mask[0]) if (latent_mask is not None and init_latent is not None) else None
+            t_entry = ascending[run_steps]
+            ascending = ascending[:run_steps]
+            encoded = self.image_encoder.predict_on_batch(picture11)
+            start_latent = (self.scheduler.signal_rates[t_entry] * np.repeat(encoded, B, axis=0)
+                            + self.scheduler.noise_rates[t_entry] * noise)
+        inpainting = latent_mask is not None and encoded is not None
+        blend_pixels = pixel_mask is not None and picture01 is not None
         start_index = num_steps - run_steps  # position of the first executed timestep in the descending schedule
-        hint_image = None
-        if control_net_image is not None:
-            if isinstance(control_net_image, np.ndarray):
-                image_array = self.resize(control_net_image, self.img_height, self.img_width)
-            else:
-                from PIL import Image
+        hint = self._hint_batch(control_net_image, B)
+        g, phi = float(unconditional_guidance_scale), float(guidance_rescale)
 
-                image_array = Image.open(control_net_image).convert("RGB").resize((self.img_width, self.img_height))
-            hint_image = np.tile(np.expand_dims(np.array(image_array, dtype=np.float32) / 255.0, axis=0), (batch_size, 1, 1, 1))
-
-        def finish(decoded):
-            """Reference :482-486 (with the pixel-space inpaint blend)."""
+        def finish(decoded, picture=picture01, mask=pixel_mask):
+            """Decoder output in [-1,1] -> uint8, truncating (reference :482-486), through the pixel-space inpaint blend."""
             decoded = np.array(((decoded + 1.0) * 0.5), dtype=np.float32)
-            if input_mask_array is not None and input_image_array is not None:
-                decoded = input_image_array * (1.0 - input_mask_array) + decoded * input_mask_array
+            if blend_pixels:
+                decoded = picture * (1.0 - mask) + decoded * mask
             return np.clip(decoded * 255.0, 0, 255).astype("uint8")
 
         if host_loop:
-            latent = self._host_loop(context, unconditional_context, diffusion_noise, unconditional_guidance_scale,
-                                     guidance_rescale, hint_image, callback, timesteps_asc, inpaint)
+            latent = self._host_loop(context, unconditional_context, start_latent, g, phi, hint, callback, ascending,
+                                     (encoded, noise, latent_mask[0]) if inpainting else None)
             if return_latent:
                 return np.asarray(latent, dtype=np.float32)
             return finish(self.image_decoder.predict_on_batch(latent))
 
-        eng = self._engine(batch_size, context.shape[1], unconditional_context.shape[1], num_steps,
-                           float(unconditional_guidance_scale), float(guidance_rescale), hint_image is not None,
-                           inpaint is not None)
-        eng.prepare(eng.contexts(unconditional_context, context), diffusion_noise, self.scheduler, self.scheduler.timesteps,
-                    start_index, hint_image, inpaint)
-        eng.run_steps(run_steps, callback)
-        if return_latent:
-            return eng.latent.cpu().numpy()
-        if input_mask_array is not None and input_image_array is not None:
-            return finish(self.image_decoder.predict_on_batch(eng.latent))   # pixel blend in fp32 before the uint8 cast
-        return self.image_decoder.decode_to_uint8(eng.latent).cpu().numpy()
+        # ---- device loop, sharded over the process group when there is one (SURVEY.md §8e) --------------------------------
+        from . import dist as mdist
+
+        world = mdist.world_size() if getattr(self, "shard_batch", True) else 1
+        tcd_global = bool(self.active_tcd and world > 1)
+        per_sample, shared = {}, {}   # name -> array; insertion order = argument order of `local`
+        if hint is not None:
+            per_sample["hint"] = hint
+        if inpainting:
+            per_sample["noise"] = noise
+            shared["encoded"], shared["mask"] = encoded, latent_mask[0]
+        if blend_pixels and world > 1:   # rank 0's picture and mask are the ones every slice is blended with
+            shared["picture"], shared["pixel_mask"] = picture01, pixel_mask
+        if tcd_global:
+            # the TCD sampler draws N(0,1) for the whole batch once per executed step but the last (scheduler.py:301): made
+            # here for the GLOBAL batch, in that order, so that a sample's draws do not depend on the number of ranks
+            zs = np.zeros((num_steps, B, noise[0].size), dtype=np.float32)
+            for i in range(start_index, num_steps - 1):
+                zs[i] = np.random.randn(*noise.shape).astype(np.float32).reshape(B, -1)
+            per_sample["tcd"] = np.ascontiguousarray(zs.transpose(1, 0, 2))
+        dev = getattr(self, "device", None) or self.diffusion_model.device
+        names = list(per_sample) + list(shared)
+
+        def local(c, u, z, *rest):
+            """This rank's slice of the batch: engine for b samples -> prepare -> loop -> decode; returns a device tensor."""
+            a = dict(zip(names, rest))
+            b = int(z.shape[0])
+            hint_b = a.get("hint")
+            ip = (a["encoded"], a["noise"], a["mask"]) if inpainting else None
+            tcd_z = a.get("tcd")
+            eng = self._engine(b, c.shape[1], u.shape[1], num_steps, g, phi, hint_b is not None, ip is not None)
+            eng.prepare(eng.contexts(u, c), z, self.scheduler, self.scheduler.timesteps, start_index, hint_b, ip, step_noise=tcd_z)
+            eng.run_steps(run_steps, callback)
+            if return_latent:
+                return eng.latent
+            if blend_pixels:   # pixel blend in fp32 before the uint8 cast
+                host = [np.asarray(a[k].cpu()) for k in ("picture", "pixel_mask")] if "picture" in a else []
+                return torch.from_numpy(finish(self.image_decoder.predict_on_batch(eng.latent), *host)).to(eng.latent.device)
+            return self.image_decoder.decode_to_uint8(eng.latent)
+
+        out = mdist.generate_sharded(local, context, unconditional_context, start_latent, dev,
+                                     per_sample=list(per_sample.values()), shared=list(shared.values()), shard=world > 1)
+        return out.cpu().numpy()
 
     def _engine(self, B, tc, tu, steps, g, phi, control, inpaint=False) -> DenoiseEngine:
         # the engine's plans (and captured hipGraphs) hold raw addresses of the packed weights: a set_weights() /
