@@ -36,10 +36,12 @@ extern "C" int msd_set_option(const char* key, int value) {
         return MSD_OK;
     }
     if (key && strcmp(key, "attn_qf") == 0) {     // 0 = automatic [default], 1 / 2 = 64 / 128 queries per workgroup
+        if (value < 0 || value > 2) MSD_FAIL(MSD_E_ARG, "set_option: attn_qf takes 0, 1 or 2");
         msd_set_attn_qf(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "xattn_nw") == 0) {    // 0 = automatic [default], 4 / 8 = 64 / 128 queries per fused cross-attention workgroup
+        if (value != 0 && value != 4 && value != 8) MSD_FAIL(MSD_E_ARG, "set_option: xattn_nw takes 0, 4 or 8");   // grid and kernel must agree on the tile
         msd_set_xattn_nw(value);
         return MSD_OK;
     }

@@ -416,7 +416,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.split_mode = q->split_mode; a.ns0 = q->ns0; a.ns1 = q->ns1; a.out1_ld = q->out1_ld; a.out2_ld = q->out2_ld;
     // 16-byte epilogue form (conv_common.h): every row it stores to / loads from starts on a 16-byte boundary, and in split
     // mode a 16-column block lies in one part
-    a.vec16 = (q->out_ld % 8 == 0) && (!q->residual || q->res_ld % 8 == 0) &&
+    // (N % 8: the form's residual load covers 8 channels; with N % 8 == 4 its last run would read 4 channels too far left)
+    a.vec16 = (q->N % 8 == 0) && (q->out_ld % 8 == 0) && (!q->residual || q->res_ld % 8 == 0) &&
               (!q->split_mode || ((q->ns0 % 16) == 0 && (q->ns1 % 16) == 0 && (q->ns1 == 0 || q->out1_ld % 8 == 0)));
 
     a.a2 = (const bf16_t*)q->a2; a.a3 = (const bf16_t*)q->a3; a.c2 = q->c2; a.nk_main = a.nk;

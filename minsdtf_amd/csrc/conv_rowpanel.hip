@@ -17,7 +17,13 @@
 // those of conv_gemm_dma_kernel / cg_epilogue, so the bits are the tile kernel's (tests/test_ops_gpu.py compares them).
 #include "conv_common.h"
 
-template <int KC, int MI>
+// RL = the residual / LayerNorm-producer form (proj_in, attn1.to_out, attn2.to_out of a transformer block: plain mode, no
+// activation, no LayerNorm-fold input): `residual` rows added in the 16-byte form, `ln_out` row-moment partials per 64-column
+// tile — the numerics class of these layers (tuning.numerics_class) — accumulated in registers over the two 32-column
+// steps of a tile in the tile kernel's canonical order.  At most RL_STEPS steps (128 columns) per workgroup: the residual
+// of all of them is loaded with the A rows, before the column loop, so that no load sits between the weight DMAs.
+constexpr int RL_STEPS = 4;
+template <int KC, int MI, bool RL = false>
 __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int wg_cols, int nsplits, uint32_t mg_nsplits) {
     constexpr int S = 3, NJ = 2, MP = MI / 2;
     constexpr int BM = 4 * MI * 16;
@@ -62,7 +68,28 @@ __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int
     for (int t = tid; t < wg_cols; t += 256) {
         const int n = min(n0 + t, p.N - 1);
         l_bias[t] = p.bias ? p.bias[n] : 0.f;
-        l_cs[t] = p.ln_in ? p.ln_colsum[n] : 0.f;
+        l_cs[t] = (!RL && p.ln_in) ? p.ln_colsum[n] : 0.f;
+    }
+    const int cgo = cg_col(g), cg8 = (g & 1) << 3;
+    const int rw = cg_wrow(r);
+    int msw[MP], bidx[MI];
+#pragma unroll
+    for (int ip = 0; ip < MP; ++ip) msw[ip] = m0 + (g < 2 ? 2 * ip : 2 * ip + 1) * 16 + r;
+    // RL: the residual runs of every step (lane = row msw[ip], 8 channels from n0 + 32 step + 16 j + cg8)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rres[RL ? RL_STEPS : 1][MP][NJ];
+    if (RL) {
+#pragma unroll
+        for (int st = 0; st < RL_STEPS; ++st)
+#pragma unroll
+            for (int ip = 0; ip < MP; ++ip)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    rres[st][ip][j] = (u32x4){0, 0, 0, 0};
+                    if (p.residual && st < nsteps)   // (wave-uniform)
+                        rres[st][ip][j] = *reinterpret_cast<const u32x4*>(p.residual + (size_t)min(msw[ip], p.M - 1) * p.res_ld +
+                                                                          min(n0 + st * 32 + j * 16 + cg8, p.N - 8));
+                }
     }
     // LayerNorm fold, consumer side: row moments from the producer's partials, summed exactly as cg_epilogue does
     // (lane group g takes slots g, g + 4, ...; then (g0 + g1) + (g2 + g3)) — once per row instead of once per tile
@@ -70,7 +97,7 @@ __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int
     float mean[MI], rstd[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) { mean[i] = 0.f; rstd[i] = 1.f; }
-    if (p.ln_in) {
+    if (!RL && p.ln_in) {
         float2 lnp[MI][LNS];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -92,13 +119,28 @@ __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int
         }
     }
     wait_vmcnt<0>();   // A rows, weight tiles 0 and 1
+    // The compiler does not see that wait (nor the DMAs): left alone it puts its OWN waits for the A-row loads on their
+    // first uses inside the column loop — s_waitcnt vmcnt(19) ... vmcnt(1) in front of the MFMAs of every step — and from the
+    // second step on those count the weight DMAs of tile step + 2 and the previous step's stores instead: every step then
+    // stalls until the tile it has just requested has landed, a ring of depth one.  Consuming the registers here retires the
+    // loads in the compiler's book-keeping before the loop.
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int ks = 0; ks < KC * 2; ++ks) asm volatile("" : "+v"(af[i][ks]));
+    if (RL) {
+#pragma unroll
+        for (int st = 0; st < RL_STEPS; ++st)
+#pragma unroll
+            for (int ip = 0; ip < MP; ++ip)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(rres[st][ip][j]));
+    }
     __syncthreads();   // ... and the bias / column-sum rows in LDS
 
-    const int cgo = cg_col(g), cg8 = (g & 1) << 3;
-    const int rw = cg_wrow(r);
-    int msw[MP], bidx[MI];
+    float lna[MP], lnq[MP];   // RL + ln_out: running moments of the lane's row over the 16-column blocks of the current 64-column tile
 #pragma unroll
-    for (int ip = 0; ip < MP; ++ip) msw[ip] = m0 + (g < 2 ? 2 * ip : 2 * ip + 1) * 16 + r;
+    for (int ip = 0; ip < MP; ++ip) { lna[ip] = 0.f; lnq[ip] = 0.f; }
 #pragma unroll
     for (int i = 0; i < MI; ++i) bidx[i] = p.split_mode ? udiv_magic(min(m0 + i * 16 + r, p.M - 1), p.hw_out, p.mg_hw) : 0;
     auto swap8 = [&](const float (&a)[4], const float (&b)[4], float (&v)[8]) {
@@ -153,7 +195,7 @@ __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int
             bv[j] = *reinterpret_cast<const float4*>(l_bias + step * 32 + j * 16 + cgo);
             cs[j] = *reinterpret_cast<const float4*>(l_cs + step * 32 + j * 16 + cgo);
         }
-        if (p.ln_in) {
+        if (!RL && p.ln_in) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -164,7 +206,58 @@ __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int
                     acc[j][i][3] = rstd[i] * (acc[j][i][3] - mean[i] * cs[j].w);
                 }
         }
-        if (p.act == MSD_ACT_GEGLU) {   // x columns nb + [0,16), gate nb + 16 + [0,16) -> output columns nb / 2 + [0,16)
+        if constexpr (RL) {
+            // cg_epilogue's compact 16-byte form, expression for expression: (acc + bias) + time-embedding row (absent: 0),
+            // half-wave exchange, + residual run (absent: zeros), round to bf16, store; moments of the ROUNDED values per 16-column
+            // block as (s[0..3] + s[4..7]) + (s[8..11] + s[12..15]), blocks of a 64-column tile added in ascending order from 0
+            const float zero = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[j][i][0] = (acc[j][i][0] + bv[j].x) + zero; acc[j][i][1] = (acc[j][i][1] + bv[j].y) + zero;
+                    acc[j][i][2] = (acc[j][i][2] + bv[j].z) + zero; acc[j][i][3] = (acc[j][i][3] + bv[j].w) + zero;
+                }
+            if ((step & 1) == 0) {
+#pragma unroll
+                for (int ip = 0; ip < MP; ++ip) { lna[ip] = 0.f; lnq[ip] = 0.f; }
+            }
+#pragma unroll
+            for (int ip = 0; ip < MP; ++ip)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    float a[4] = {acc[j][2 * ip][0], acc[j][2 * ip][1], acc[j][2 * ip][2], acc[j][2 * ip][3]};
+                    float b[4] = {acc[j][2 * ip + 1][0], acc[j][2 * ip + 1][1], acc[j][2 * ip + 1][2], acc[j][2 * ip + 1][3]};
+                    float v[8], q[8];
+                    swap8(a, b, v);
+                    // (the step index of the residual registers must be a compile-time constant: select, do not index)
+                    u32x4 rr = rres[0][ip][j];
+#pragma unroll
+                    for (int st = 1; st < RL_STEPS; ++st) if (step == st) rr = rres[st][ip][j];
+                    unpack8(make_uint4(rr.x, rr.y, rr.z, rr.w), q);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] + q[e];
+                    const uint4 o = pack8(v);
+                    const bool ok = msw[ip] < p.M;
+                    if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)msw[ip] * p.out_ld + nb + j * 16 + cg8) = o;
+                    if (p.ln_out) {   // (every lane takes part in the row swap: predicated values, no early exit)
+                        unpack8(o, q);
+                        float s1 = (ok ? (q[0] + q[1]) + (q[2] + q[3]) : 0.f) + (ok ? (q[4] + q[5]) + (q[6] + q[7]) : 0.f);
+                        float s2 = (ok ? (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]) : 0.f) +
+                                   (ok ? (q[4] * q[4] + q[5] * q[5]) + (q[6] * q[6] + q[7] * q[7]) : 0.f);
+                        auto t1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+                        auto t2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+                        lna[ip] += __uint_as_float(t1[0]) + __uint_as_float(t1[1]);   // the two 8-channel halves of the block
+                        lnq[ip] += __uint_as_float(t2[0]) + __uint_as_float(t2[1]);
+                    }
+                }
+            if (p.ln_out && (step & 1) && (g & 1) == 0) {   // tile (nb - 32) / 64 complete: lanes g = 0 / 2 hold rows of fragments 2 ip / 2 ip + 1
+#pragma unroll
+                for (int ip = 0; ip < MP; ++ip)
+                    if (msw[ip] < p.M)
+                        reinterpret_cast<float2*>(p.ln_out)[(size_t)msw[ip] * p.ln_out_slots + (nb >> 6)] = make_float2(lna[ip], lnq[ip]);
+            }
+        } else if (p.act == MSD_ACT_GEGLU) {   // x columns nb + [0,16), gate nb + 16 + [0,16) -> output columns nb / 2 + [0,16)
             auto gl4 = [&](int i, float (&v)[4]) {
                 v[0] = geglu_f(acc[0][i][0] + bv[0].x, acc[1][i][0] + bv[1].x);
                 v[1] = geglu_f(acc[0][i][1] + bv[0].y, acc[1][i][1] + bv[1].y);
@@ -239,6 +332,8 @@ int msd_conv_rowpanel_init() {
     if (g_rp_attr_done) return MSD_OK;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(5, RP_MAX_COLS));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<10, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(10, RP_MAX_COLS));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<5, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(5, 32 * RL_STEPS));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_rowpanel_kernel<10, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, rp_lds(10, 32 * RL_STEPS));
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_rowpanel): %s", hipGetErrorString(e));
     g_rp_attr_done = true;
     return MSD_OK;
@@ -246,9 +341,12 @@ int msd_conv_rowpanel_init() {
 
 // Whether a validated launch can run here: rows (256 or 128 per workgroup) and columns per workgroup as requested.
 bool msd_conv_rowpanel_eligible(const CGArgs& a, int rows, int wg_cols) {
+    const bool rl = a.residual || a.ln_out;   // the residual / LayerNorm-producer form: whole 64-column tiles, <= 128 columns per workgroup
     const bool shape = a.ksize == 1 && a.stride == 1 && !a.upsample && a.c1 == 0 && !a.a2 && (a.K == 320 || a.K == 640) && (a.N % 32) == 0 &&
-                       !a.residual && !a.rowvec && !a.out_f32 && !a.ln_out && a.nslices == 1 && a.vec16 &&
+                       !a.rowvec && !a.out_f32 && a.nslices == 1 && a.vec16 &&
                        (a.act == MSD_ACT_NONE || (a.act == MSD_ACT_GEGLU && a.split_mode == 0)) &&
+                       (!rl || (a.act == MSD_ACT_NONE && a.split_mode == 0 && !a.ln_in && (a.N % 64) == 0 && (wg_cols % 64) == 0 &&
+                                wg_cols <= 32 * RL_STEPS)) &&
                        (long long)a.M * a.c0 * 2 < (1ll << 32) - 4096;
     // (MI = 4, 256 rows per workgroup, was built for K = 320: 256 VGPRs, one wave per SIMD — slower than MI = 2 on every
     //  shape, 27.5 vs 24.5 us on the 64x64 GEGLU projection: with two workgroups per CU one's epilogue overlaps the other's MFMAs)
@@ -264,9 +362,13 @@ int msd_conv_rowpanel_launch(CGArgs a, int rows, int wg_cols, hipStream_t stream
     a.tiles_m = panels; a.tiles_n = nsplits;
     const dim3 grid(panels * nsplits);
     const uint32_t mg = udiv_magic_of(nsplits);
-    if (a.K == 320)
-        hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
-    else
-        hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2>), grid, dim3(256), rp_lds(10, wg_cols), stream, a, wg_cols, nsplits, mg);
+    const bool rl = a.residual || a.ln_out;
+    if (a.K == 320) {
+        if (rl) hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2, true>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
+        else hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
+    } else {
+        if (rl) hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2, true>), grid, dim3(256), rp_lds(10, wg_cols), stream, a, wg_cols, nsplits, mg);
+        else hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2>), grid, dim3(256), rp_lds(10, wg_cols), stream, a, wg_cols, nsplits, mg);
+    }
     return MSD_OK;
 }

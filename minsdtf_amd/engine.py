@@ -254,6 +254,12 @@ class Emitter:
         self.p, self.W, self.step_ptr = plan, W, step_ptr
         plan.keep.append(W)   # the calls hold raw addresses of these tensors: the plan owns a reference to them
 
+    def w_layout(self, key: str) -> int:
+        """Storage layout of weight matrix `key` as its owner recorded it (packing.PackedWeights); a plain mapping (the
+        tuner's shape walk) has no tensors and takes the default."""
+        lay = getattr(self.W, "layout", None)
+        return lay(key) if lay is not None else (1 if W_CHUNK_MAJOR else 0)
+
     # conv / dense on the MFMA path; x may be a single Act or a (Act, Act) channel concat
     def conv(self, x, name, N, ksize=1, stride=1, upsample=False, act=ops.ACT_NONE, residual: Optional[Act] = None,
              rowvec=None, out_dtype=ops.OUT_BF16, bias=True, wkey=None, split=None, out: Optional[Act] = None,
@@ -290,13 +296,13 @@ class Emitter:
                   residual=None if residual is None else residual.buf, res_ld=None if residual is None else residual.C,
                   workspace=p.ws if sk > 1 else None, workspace_floats=sk * M * N if sk > 1 else 0, splitk=sk,
                   tile_m=tile_m, tile_n=tile_n, stages=stages, pad=pad_lead, pad_end=pad_end,
-                  step_ptr=self.step_ptr if rowvec is not None else None, w_layout=1 if W_CHUNK_MAJOR else 0, name=name)
+                  step_ptr=self.step_ptr if rowvec is not None else None, w_layout=self.w_layout((wkey or name) + ".w"), name=name)
         if e0 is not None:
             kw.update(a2=e0.buf, c2=e0.C, a3=None if e1 is None else e1.buf, c3=0 if e1 is None else e1.C)
         if ln_in is not None:
             wn = wkey or name
             kw.update(w=self.W[wn + ".lnw"], bias=self.W[wn + ".lnb"], ln_in=ln_in[0], ln_in_slots=ln_in[1],
-                      ln_colsum=self.W[wn + ".lncs"], ln_eps=EPS)
+                      ln_colsum=self.W[wn + ".lncs"], ln_eps=EPS, w_layout=self.w_layout(wn + ".lnw"))
         if ln_out:
             slots = ops.conv_gemm_ln_slots(N=N, tile_n=tile_n, tile_m=tile_m, ksize=ksize, act=act)
             out.ln = (p.alloc(M * slots * 8), slots)
@@ -392,7 +398,7 @@ class Emitter:
             wn = tb + ".attn2.to_q"
             p.rec(ops.cross_attention_q, x=t1.buf, ln_in=t1.ln[0], ln_in_slots=t1.ln[1], wq=self.W[wn + ".lnw"],
                   ln_colsum=self.W[wn + ".lncs"], bias=self.W[wn + ".lnb"], k=kc, vt=vtc, out=a2.buf, batch=B, heads=heads,
-                  head_dim=d, s=S, t=ctx_len, k_ld=C, vt_ld=tp, o_ld=C, ln_eps=EPS, w_layout=1 if W_CHUNK_MAJOR else 0,
+                  head_dim=d, s=S, t=ctx_len, k_ld=C, vt_ld=tp, o_ld=C, ln_eps=EPS, w_layout=self.w_layout(wn + ".lnw"),
                   name=tb + ".attn2")
             p.free(t1.ln[0])
         else:

@@ -105,12 +105,12 @@ class HipModel:
             if tuple(a.shape) != tuple(s.shape):
                 raise ValueError(f"{self.name}: {s.name} has shape {a.shape}, expected {s.shape}")
             named[(s.name, s.kind)] = a
-        W = self._pack(named)
+        W = packing.PackedWeights(self._pack(named))
         if engine.W_CHUNK_MAJOR:
-            # every bf16 matrix of the packed set is a msd_conv_gemm weight: store it chunk-major (packing.chunk_major)
-            for k, t in W.items():
-                if t.dtype == torch.bfloat16 and t.dim() == 2 and k.endswith((".w", ".lnw")):
-                    W[k] = packing.chunk_major(t)
+            # the bf16 matrices the MFMA kernels read (msd_conv_gemm, msd_cross_attention_q: keys *.w / *.lnw) are stored
+            # chunk-major; W records which ones, and the emitters pass that per-key layout to the op (Emitter.conv)
+            for k in [k for k, t in W.items() if t.dtype == torch.bfloat16 and t.dim() == 2 and k.endswith((".w", ".lnw"))]:
+                W.to_chunk_major(k)
         self._W = W
         self.weights_version += 1
         self._plans.clear()
@@ -120,6 +120,8 @@ class HipModel:
         no second copy in HBM, no second packing pass."""
         if type(other) is not type(self) or other._W is None:
             raise ValueError(f"{self.name}: share_weights needs a loaded model of the same kind")
+        if other.device != self.device:   # the plans hold raw device addresses
+            raise ValueError(f"{self.name}: share_weights across devices ({other.device} -> {self.device})")
         self._W = other._W
         self.weights_version += 1
         self._plans.clear()

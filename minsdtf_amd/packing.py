@@ -20,6 +20,26 @@ def _dev_bf16(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(torch.bfloat16).contiguous().to(device)
 
 
+class PackedWeights(dict):
+    """name -> device tensor, plus the storage layout of every msd_conv_gemm / msd_cross_attention_q weight matrix in it:
+    ``layout(key)`` is the value for MsdConvGemm.w_layout (0: [N][K] rows, 1: chunk-major).  The layout is recorded per
+    key when the tensor is re-laid out, so an op can never be told a layout its operand does not have."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.chunk_major_keys = set()
+
+    def layout(self, key: str) -> int:
+        return 1 if key in self.chunk_major_keys else 0
+
+    def to_chunk_major(self, key: str) -> None:
+        t = self[key]
+        if key in self.chunk_major_keys or t.dim() != 2 or t.shape[1] % 64:
+            return   # (a K that is no multiple of 64 stays in rows: the kernels take either layout)
+        self[key] = chunk_major(t)
+        self.chunk_major_keys.add(key)
+
+
 def chunk_major(w_nk: torch.Tensor) -> torch.Tensor:
     """[N][K] -> [K/64][N][64] (MsdConvGemm.w_layout = 1): the 64-element K chunk of ALL output columns is one contiguous
     run, so the weight tile of a K step is a single block of HBM whatever the column tile.  Same values, same K order."""

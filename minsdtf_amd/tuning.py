@@ -31,7 +31,7 @@ HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (125
 # (rows per workgroup + 3000, columns per workgroup): row-panel Dense kernel (csrc/conv_rowpanel.hip) for the LayerNorm-
 # consumer GEMMs of the transformer blocks (K = 320 / 640, 128 rows per workgroup)
 ROWPANEL_ROWS = {320: (3128,), 640: (3128,)}
-ROWPANEL_COLS = (96, 160, 192, 320, 480, 640, 960)
+ROWPANEL_COLS = (64, 96, 128, 160, 192, 320, 480, 640, 960)
 
 
 def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=True, cx=0) -> str:
@@ -48,6 +48,13 @@ def _load() -> Dict[str, list]:
                 _table = json.load(f)
         except (OSError, ValueError):
             _table = {}
+        # A/B runs: $MSD_TUNE_OVERRIDE = JSON {shape key: [tile_m, tile_n, splitk, stages]} (or @file) laid over the table
+        ov = os.environ.get("MSD_TUNE_OVERRIDE")
+        if ov:
+            if ov.startswith("@"):
+                with open(ov[1:]) as f:
+                    ov = f.read()
+            _table.update({k: list(v) + [0.0] for k, v in json.loads(ov).items()})
         _families = {}
         for key, ent in _table.items():
             b, rest = key.split("x", 1)

@@ -19,7 +19,12 @@ def bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def close(got, ref, rtol=1e-2, atol=None, what=""):
+def close(got, ref, rtol=1e-2, atol=None, what="", rms=None):
+    """Element-wise: |got - ref| <= atol + rtol |ref| everywhere.  Aggregate: relative RMS error ||got - ref|| / ||ref|| <=
+    `rms`, by default 2^-7 for a bf16 result (its own rounding is 2^-9 relative per element) and 2^-12 for an fp32 result of
+    bf16 operands — the element-wise floor alone would let a dropped K chunk of one tap of a K = 2,304 contraction through;
+    the aggregate does not."""
+    is_f32 = got.dtype == torch.float32
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
     if atol is None:
@@ -28,6 +33,10 @@ def close(got, ref, rtol=1e-2, atol=None, what=""):
     err = (got - ref).abs()
     bad = err > (atol + rtol * ref.abs())
     assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {float(err.max()):.4g}, ref max {float(ref.abs().max()):.4g}"
+    if rms is None:
+        rms = 2.0 ** -12 if is_f32 else 2.0 ** -7
+    rel = float((got - ref).double().norm() / max(float(ref.double().norm()), 1e-30))
+    assert rel <= rms, f"{what}: relative RMS error {rel:.3g} > {rms:.3g}"
 
 
 def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
@@ -231,7 +240,13 @@ def test_conv_gemm_geglu(gpu):
     dict(M=520, C=320, tile=(128, 80, 0), mode="dense", ctile=(3128, 160, 0), csame=True),    # attn2.to_q
     dict(M=260, C=640, tile=(64, 64, 0), mode="dense", ctile=(3128, 320, 0), csame=True),
     dict(M=130, C=1280, tile=(64, 64, 14), mode="dense", ctile=(3128, 320, 0), csame=True),   # K = 1280: not eligible, runs on the 128x64 tile
-    dict(M=200, C=320, tile=(3128, 320, 0), mode="dense", ctile=(3128, 160, 0), csame=True),  # a producer (ln_out) asked for it too: 128x64 tile, 5 partials
+    dict(M=200, C=320, tile=(3128, 320, 0), mode="dense", ctile=(3128, 160, 0), csame=True),  # a producer (ln_out) asked for more than 128 columns per workgroup: 128x64 tile, 5 partials
+    # producer on the row-panel kernel's residual / LayerNorm-producer form (64 or 128 columns per workgroup); `psame`: output
+    # AND row-moment partials bit-identical to the 128x64 tile kernel's
+    dict(M=600, C=320, tile=(3128, 64, 0), mode="dense", ctile=(3128, 160, 0), csame=True, psame=True),    # attn1.to_out -> attn2.to_q
+    dict(M=300, C=320, tile=(3128, 128, 0), mode="geglu", ctile=(3128, 320, 0), csame=True, psame=True),   # 128 + 128 + 64 column shares; attn2.to_out -> GEGLU
+    dict(M=260, C=640, tile=(3128, 128, 0), mode="qkv", ctile=(3128, 480, 0), csame=True, psame=True),     # K = 640; proj_in -> q|k|v
+    dict(M=136, C=640, tile=(3128, 64, 0), mode="dense", psame=True, nores=True),                          # proj_in: no residual
 ])
 def test_conv_gemm_layer_norm_fold(gpu, case):
     """LayerNormalization folded into the GEMMs around it (diffusion_model.py:84-88 + Dense): the producer
@@ -246,6 +261,8 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
     ckw = dict(tile_m=ctm, tile_n=ctn, stages=cstg)
     x = bf(torch.randn(M, C))
     res = bf(torch.randn(M, C) * 2 + 0.5)                      # non-zero row means
+    if case.get("nores"):
+        res = torch.zeros(M, C)
     w0 = bf(torch.randn(C, C) / math.sqrt(C))
     b0 = torch.randn(C) * 0.1
     t = bf(x @ w0 + b0 + res)                                  # what the producer stores (bf16)
@@ -257,8 +274,16 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
     assert slots == -(-C // (64 if tm >= 3000 else tn))
     stats = torch.full((M, slots, 2), float("nan"), dtype=torch.float32, device=d)
     keep = [x.to(torch.bfloat16).to(d), packing.pack_dense(w0.numpy(), d), b0.to(d), res.to(torch.bfloat16).to(d)]   # (Calls hold raw pointers)
+    if case.get("nores"):
+        keep[3] = None
     prod = ops.conv_gemm(a0=keep[0], w=keep[1], out=tdev, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=keep[2], residual=keep[3],
                          tile_m=tm, tile_n=tn, stages=stg, ln_out=stats, ln_out_slots=slots)
+    if case.get("psame"):
+        tdev2, stats2 = torch.full_like(tdev, float("nan")), torch.full_like(stats, float("nan"))
+        run_calls([prod, ops.conv_gemm(a0=keep[0], w=keep[1], out=tdev2, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=keep[2], residual=keep[3],
+                                       tile_m=128, tile_n=64, ln_out=stats2, ln_out_slots=slots)])
+        assert torch.equal(tdev.view(torch.int16), tdev2.view(torch.int16)), "row-panel producer changed the output bits"
+        assert torch.equal(stats.view(torch.int32), stats2.view(torch.int32)), "row-panel producer changed the row-moment partials"
     mode = case["mode"]
     if mode == "geglu":
         w1 = bf(torch.randn(C, 8 * C) / math.sqrt(C))
@@ -512,6 +537,9 @@ def test_layer_norm(gpu, rows, c):
     dict(B=1, H=8, d=80, S=256, T=256, spike=True),  # forces online-softmax rescales
     dict(B=1, H=4, d=40, S=200, T=520, spike=True),  # ... with a ragged last tile, d = 40 (ones-row denominator)
     dict(B=1, H=2, d=160, S=64, T=320, spike=True, ramp=True),  # reference maximum creeps up below the threshold, then jumps
+    dict(B=1, H=2, d=40, S=4096, T=4096, spike=True),  # the 64x64 level's real size (the most expensive kernel of a step); late spikes
+    dict(B=1, H=1, d=40, S=9216, T=9216, spike=True),  # 768x768 (BASELINE config 4): 144 key tiles, reference moves late in the walk
+    dict(B=1, H=1, d=40, S=4090, T=4090),              # long walk ending in a ragged query tile AND a ragged key tile
 ])
 @pytest.mark.parametrize("qf", [2, 1])   # 128 / 64 queries per workgroup (the library picks by grid size; both forced here)
 @pytest.mark.parametrize("presc", [False, True])   # q carrying scale*log2(e) already (the UNet's projections) or not

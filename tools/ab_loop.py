@@ -8,6 +8,7 @@ is re-captured), and the rounds are interleaved (cdna_hip_programming.md rule 24
 min, and every round.
 """
 import argparse
+import json
 import os
 import statistics
 import sys
@@ -41,15 +42,24 @@ def main():
     noise = np.random.default_rng(0).standard_normal((B, h, h, 4)).astype(np.float32)
     sd.scheduler.set_timesteps(args.steps)
     variants = args.variant or ["base"]
-    keys = sorted({kv.split("=")[0] for v in variants if v != "base" for kv in v.split(",")})
+    keys = sorted({kv.split("=")[0] for v in variants if v != "base" for kv in v.split(",") if not kv.startswith("tune:")})
+    from minsdtf_amd import tuning
+
+    tuning._load()
+    pristine = dict(tuning._table)
     defaults = {}   # restore between variants: every key any variant touches gets its default back first
     times = {v: [] for v in variants}
     for rnd in range(args.rounds):
         for v in variants:
             for k in keys:
                 lib.msd_set_option(k.encode(), defaults.get(k, DEFAULTS.get(k, 0)))
+            tuning._table = dict(pristine)
             if v != "base":
                 for kv in v.split(","):
+                    if kv.startswith("tune:"):   # tune:FILE = JSON {shape key: [tile_m, tile_n, splitk, stages]} laid over the tuning table
+                        with open(kv[5:]) as f:
+                            tuning._table.update({k: list(e) + [0.0] for k, e in json.load(f).items()})
+                        continue
                     k, val = kv.split("=")
                     _lib.check(lib.msd_set_option(k.encode(), int(val)), kv)
             sd._engines = {}
