@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 7
+#define MSD_ABI_VERSION 8
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -183,7 +183,15 @@ int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
  *   partials: fp32 scratch for per-workgroup partial moments, >= batch * MSD_GN_MAX_CHUNKS * 64
  *             floats is always enough; summed in a fixed order (no atomics: results are
  *             bit-reproducible run to run)
+ *   sync:     NULL, or >= batch * MSD_GN_SYNC_WORDS_PER_SAMPLE 32-bit words, 8-byte aligned, ZERO when first used and
+ *             written by nothing but msd_group_norm launches of ONE stream at a time (launches that may run concurrently
+ *             need a block each).  With it, tensors of >= 2048 pixels per sample whose group slab fits in registers run as
+ *             ONE launch in which 2 / 4 / 8 workgroups share each (sample, group) and exchange their partial moments
+ *             through this block (ticket counters + {value, epoch} words; the parts are summed in part order:
+ *             bit-reproducible).  Word [8] of a 64-word slot is raised if a workgroup ever gave up waiting (never observed;
+ *             the launch then ends with wrong numbers instead of hanging).  Without it: statistics + apply launches.
  */
+#define MSD_GN_SYNC_WORDS_PER_SAMPLE (3 * 32 * 64)
 #define MSD_GN_MAX_CHUNKS 1024
 typedef struct MsdGroupNorm {
     const void* x0;
@@ -197,6 +205,8 @@ typedef struct MsdGroupNorm {
     int32_t batch, hw, c0, c1;
     int32_t silu; /* 0/1 */
     float eps;
+    uint32_t* sync;
+    int64_t sync_words;
 } MsdGroupNorm;
 
 int msd_group_norm(const MsdGroupNorm* p, msd_stream_t stream);

@@ -15,7 +15,7 @@ import weakref
 LIB_NAME = "libminsdtf_hip.so"
 # $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
 LIB_PATH = os.environ.get("MSD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -57,7 +57,7 @@ class MsdGroupNorm(C.Structure):
         ("x0", C.c_void_p), ("x1", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("stats", C.c_void_p),
         ("partials", C.c_void_p), ("partials_floats", C.c_int64),
         ("out", C.c_void_p), ("batch", C.c_int32), ("hw", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
-        ("silu", C.c_int32), ("eps", C.c_float),
+        ("silu", C.c_int32), ("eps", C.c_float), ("sync", C.c_void_p), ("sync_words", C.c_int64),
     ]
 
 

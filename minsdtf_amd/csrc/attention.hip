@@ -408,6 +408,327 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     }
 }
 
+// ---- the same attention on 32x32x16 MFMAs --------------------------------------------------------------------------------
+// The 16x16 form above is bound by instruction ISSUE, not by the matrix pipe (a v_mfma_f32_16x16x32_bf16 holds the SIMD's
+// issue port for 8 of its 16 cycles, and per 64-key tile a wave issues 28 of them beside 32 v_exp_f32, the packs and the
+// maximum chain: ~840 issue cycles per wave and tile).  A 32x32x16 MFMA does twice the work per issued instruction (8 of 32
+// cycles), and its k-dimension of 16 fits the head sizes without the 16x16x32 form's padding: d = 40 -> 48 instead of 64 in
+// QK^T.  (tools/mfma_rate.py: the older 16x16x16 shape, which would pad d = 40 to 48 as well, still takes 16 cycles on gfx950 — no
+// gain there.)  Per 64-key tile and wave: 6 + 8 MFMAs instead of 16 + 12 at d = 40, 10 + 12 instead of 24 + 20 at d = 80.
+//
+// A wave owns 32 queries = the 32 MFMA columns; lane (c = lane & 31, h = lane >> 5) works on query c and holds, of a 32-key
+// S^T block, the 16 keys (i & 3) + 8 (i >> 2) + 4 h, i = 0..15.  Everything said above about the transposed products holds:
+// the query's maximum / sum / rescale are lane-local, the row maximum needs ONE half-wave swap, and the S^T registers
+// 8 s' .. 8 s' + 7 ARE the B operand of O^T += V^T P^T for the 16 keys of step s' once packed to bf16 — in the k-slot order
+// {4h + b, 8 + 4h + b}, which the V^T tile is laid out for in LDS when it is staged (two 8-byte pieces per 16-byte chunk), so
+// that an A fragment is one ds_read_b128.  The maximum is checked per LANE first: only when some lane of the wave holds a score
+// above the threshold (or on tile 0) is the true row maximum formed across the two half-waves — the same decisions, the
+// cross-lane step only on the rare path.
+// NW = waves per workgroup (4: 128 queries; 2: 64 queries, for launches whose 128-query grid leaves CUs idle).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int D, int NBUF, int NW, bool PRESC>
+__global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
+    constexpr bool PIPE = NBUF == 2;
+    constexpr int NT = 64 * NW, QT = 32 * NW;
+    constexpr int KS = (D + 15) / 16;        // 16-channel k-steps of QK^T
+    constexpr int DPAD = KS * 16;
+    constexpr int DB = (D + 31) / 32;        // 32-row blocks of O^T
+    constexpr int KROW = DPAD * 2 + 16;      // bytes; an odd number of 16-byte slots -> conflict-free ds_read_b128 fragments
+    constexpr int VROW = 64 * 2 + 16;
+    constexpr int DCH = D / 8;               // 16-byte chunks per K row
+    constexpr int BUF_BYTES = 64 * KROW + DB * 32 * VROW;   // K tile [64][KROW] + V^T tile [DB*32][VROW] (keys permuted per 16)
+    constexpr bool ONES_ROW = (D % 32) != 0;  // a spare padding row of the V^T tile carries the softmax denominator
+    static_assert(((KROW / 16) & 1) == 1 && ((VROW / 16) & 1) == 1, "row strides must be odd multiples of 16 bytes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int qtiles = (p.s + QT - 1) / QT;
+    const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);
+    const int bh = udiv_magic(wi, qtiles, p.mg_qtiles);
+    const int b = udiv_magic(bh, p.heads, p.mg_heads), hd = bh - b * p.heads;
+    const int q0 = (wi - bh * qtiles) * QT + wave * 32;
+
+    for (int off = tid * 16; off < NBUF * BUF_BYTES; off += NT * 16)
+        *reinterpret_cast<uint4*>(smem + off) = make_uint4(0, 0, 0, 0);
+    if (ONES_ROW) {
+        __syncthreads();
+        if (tid < 16) {  // 64 keys x bf16(1.0) in row D of each V^T buffer (never overwritten: tiles write rows < D)
+#pragma unroll
+            for (int bufi = 0; bufi < NBUF; ++bufi)
+                *reinterpret_cast<uint2*>(smem + bufi * BUF_BYTES + 64 * KROW + D * VROW + tid * 8) = make_uint2(0x3F803F80u, 0x3F803F80u);
+        }
+    }
+
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+    float mref = 0.f, lrun = 0.f;
+    f32x16 negm;   // PRESC: {-m_ref x 16}, the C operand that starts every S^T accumulator chain
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+
+    const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + hd * D;
+    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + hd) * D * p.vt_ld;
+    const int ntiles = (p.t + 63) / 64;
+
+    constexpr int KCH = (64 * DCH + NT - 1) / NT, VCH = (D * 8 + NT - 1) / NT;
+    uint4 rk[KCH], rv[VCH];
+    const bf16_t* kptr[KCH];
+    const bf16_t* vptr[VCH];
+    int klds[KCH], vlds[VCH], krow[KCH], vkey[VCH];
+    bool kin[KCH], vin[VCH];
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int idx = tid + NT * i;
+        kin[i] = idx < 64 * DCH;
+        const int row = kin[i] ? idx / DCH : 0, ch = kin[i] ? idx - row * DCH : 0;
+        krow[i] = row;
+        kptr[i] = kbase + (size_t)row * p.k_ld + ch * 8;
+        klds[i] = row * KROW + ch * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int idx = tid + NT * i;
+        vin[i] = idx < D * 8;
+        const int d = vin[i] ? idx >> 3 : 0, ch = idx & 7;
+        vkey[i] = ch * 8;
+        vptr[i] = vbase + (size_t)d * p.vt_ld + ch * 8;
+        // keys 8 ch + {0..3} -> positions 16 (ch >> 1) + 4 (ch & 1) + {0..3}, keys 8 ch + 4 + {0..3} -> 8 further on
+        vlds[i] = d * VROW + ((ch >> 1) * 16 + (ch & 1) * 4) * 2;
+    }
+    auto gload = [&](int t0) {
+        const size_t koff = (size_t)t0 * p.k_ld;
+        if (t0 + 64 <= p.t) {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i)
+                if (kin[i]) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
+#pragma unroll
+            for (int i = 0; i < VCH; ++i)
+                if (vin[i]) rv[i] = *reinterpret_cast<const uint4*>(vptr[i] + t0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                rk[i] = make_uint4(0, 0, 0, 0);
+                if (kin[i] && t0 + krow[i] < p.t) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
+            }
+#pragma unroll
+            for (int i = 0; i < VCH; ++i) {
+                rv[i] = make_uint4(0, 0, 0, 0);
+                const int key0 = t0 + vkey[i];
+                if (vin[i] && key0 + 8 <= p.vt_ld && key0 < p.t) rv[i] = *reinterpret_cast<const uint4*>(vptr[i] + t0);
+            }
+        }
+    };
+    auto lstore = [&](char* dK, int t0) {
+        char* dV = dK + 64 * KROW;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i)
+            if (kin[i]) *reinterpret_cast<uint4*>(dK + klds[i]) = rk[i];
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            if (!vin[i]) continue;
+            uint4 v = rv[i];
+            if (t0 + 64 > p.t) {   // ragged last tile: keys >= t are padding of unspecified content, force them to 0
+                const int valid = p.t - (t0 + vkey[i]);
+                if (valid < 8) {
+                    uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (2 * j >= valid) u[j] = 0;
+                        else if (2 * j + 1 >= valid) u[j] &= 0xFFFFu;
+                    }
+                }
+            }
+            *reinterpret_cast<uint2*>(dV + vlds[i]) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(dV + vlds[i] + 16) = make_uint2(v.z, v.w);
+        }
+    };
+
+    if (PIPE) __syncthreads();
+    bf16x8 qf[KS];
+    {
+        int qrow = q0 + c;
+        if (qrow > p.s - 1) qrow = p.s - 1;
+        const bf16_t* qp = p.q + ((size_t)b * p.s + qrow) * p.q_ld + hd * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + 8 * h;
+            if (d0 < D) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + d0);
+            else qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    if (PIPE) {
+        gload(0);
+        lstore(smem, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // retire the Q loads before the tile loop (see above)
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int t0 = tile * 64;
+        char* sK = smem + (PIPE ? (tile & 1) : 0) * BUF_BYTES;
+        if (PIPE) {
+            __syncthreads();
+            if (tile + 1 < ntiles) gload(t0 + 64);
+        } else {
+            __syncthreads();
+            gload(t0);
+            lstore(sK, t0);
+            __syncthreads();
+        }
+        // ---- S^T = K Q^T [- m_ref]: two 32-key blocks
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + c) * KROW + ks * 32 + h * 16);
+                if (ks == 0) {
+                    if (PRESC) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[0], negm, 0, 0, 0);
+                    else {
+                        f32x16 z;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[0], z, 0, 0, 0);
+                    }
+                } else {
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], sacc[kb], 0, 0, 0);
+                }
+            }
+        // ---- masks (ragged key tail, causal): only the tiles that need them pay
+        if (t0 + 64 > p.t) {
+            int key0 = t0 + 4 * h;
+            asm volatile("" : "+v"(key0));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (key0 + kb * 32 + (i & 3) + 8 * (i >> 2) >= p.t) sacc[kb][i] = -1e30f;
+        }
+        if (p.causal) {
+            int key0 = t0 + 4 * h;
+            asm volatile("" : "+v"(key0));
+            const int qi = q0 + c;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (key0 + kb * 32 + (i & 3) + 8 * (i >> 2) > qi) sacc[kb][i] = -1e30f;
+        }
+        // ---- lane-local maximum; the row maximum and the (rare) move of the reference only when some lane asks for it
+        float m = fmaxf(sacc[0][0], sacc[0][1]);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) m = fmaxf(fmaxf(m, sacc[0][i]), sacc[0][i + 1]);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) m = fmaxf(fmaxf(m, sacc[1][i]), sacc[1][i + 1]);
+        const bool ask = tile == 0 || (PRESC ? (m > ATTN_THR) : ((m - mref) * p.sl2 > ATTN_THR));
+        if (__builtin_amdgcn_ballot_w64(ask) != 0) {
+            const uint32_t u = __float_as_uint(m);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            float mx;
+            asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(sw[0]), "v"(sw[1]));   // both half-waves: the query's maximum over the tile
+            const bool need = tile == 0 || (PRESC ? (mx > ATTN_THR) : ((mx - mref) * p.sl2 > ATTN_THR));
+            float alpha;
+            if (PRESC) {
+                const float delta = need ? mx : 0.f;
+                alpha = __builtin_amdgcn_exp2f(-delta);
+                mref += delta;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { negm[i] = -mref; sacc[0][i] -= delta; sacc[1][i] -= delta; }
+            } else {
+                const float mnew = need ? mx : mref;
+                alpha = __builtin_amdgcn_exp2f((mref - mnew) * p.sl2);
+                mref = mnew;
+            }
+            if (tile != 0) {
+                lrun *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+            }
+        }
+        // ---- exponentials in place
+        {
+            const float nm = -mref * p.sl2;
+            float ls = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(PRESC ? sacc[kb][i] : fmaf(sacc[kb][i], p.sl2, nm));
+                    sacc[kb][i] = pv;
+                    if (!ONES_ROW) ls += pv;
+                }
+            if (!ONES_ROW) lrun += ls;
+        }
+        // ---- O^T += V^T P^T, 16 keys per step
+        const char* sV = sK + 64 * KROW;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int kb = st >> 1, i0 = (st & 1) * 8;
+            union { bf16x8 v; uint32_t u[4]; } pk;
+            pk.u[0] = pack_bf2(sacc[kb][i0 + 0], sacc[kb][i0 + 1]);
+            pk.u[1] = pack_bf2(sacc[kb][i0 + 2], sacc[kb][i0 + 3]);
+            pk.u[2] = pack_bf2(sacc[kb][i0 + 4], sacc[kb][i0 + 5]);
+            pk.u[3] = pack_bf2(sacc[kb][i0 + 6], sacc[kb][i0 + 7]);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (db * 32 + c) * VROW + st * 32 + h * 16);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pk.v, oacc[db], 0, 0, 0);
+            }
+        }
+        if (PIPE && tile + 1 < ntiles) lstore(smem + ((tile & 1) ^ 1) * BUF_BYTES, t0 + 64);
+    }
+
+    // ---- normalise and store: lane (c, h) holds channels db*32 + 8 (i >> 2) + 4 h + (i & 3) of query q0 + c
+    float lt;
+    if (ONES_ROW) {   // row D of V^T is all ones: O^T[D][q] = sum_k P[k][q] (same bf16-rounded P as the numerator)
+        constexpr int rr = D % 32, h0 = (rr >> 2) & 1, i0 = (rr & 3) + 4 * (rr >> 3);
+        lt = __shfl(oacc[DB - 1][i0], c + 32 * h0);
+    } else {
+        lt = lrun + __shfl_xor(lrun, 32);
+    }
+    const float inv = 1.0f / lt;
+    const int qrow = q0 + c;
+    bf16_t* op = p.out + ((size_t)b * p.s + min(qrow, p.s - 1)) * p.o_ld + hd * D;
+    if ((p.o_ld & 7) == 0) {
+        // 16-byte stores: one half-wave swap per register turns (group 2j of this lane, group 2j of the other half) into 8
+        // consecutive channels — lower half: channels 16 j + 0..7, upper half: 16 j + 8..15 of the 32-channel block
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[db][8 * j + e] * inv), __float_as_uint(oacc[db][8 * j + 4 + e] * inv), false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
+                }
+                const int d = db * 32 + 16 * j + 8 * h;
+                if (d < D && qrow < p.s) *reinterpret_cast<uint4*>(op + d) = pack8(v);
+            }
+    } else {
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = db * 32 + 8 * g4 + 4 * h;
+                if (d < D && qrow < p.s) {
+                    uint2 o;
+                    o.x = pack_bf2(oacc[db][4 * g4 + 0] * inv, oacc[db][4 * g4 + 1] * inv);
+                    o.y = pack_bf2(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + d) = o;
+                }
+            }
+    }
+}
+
 // ---- cross-attention with its query projection inside (text context: T <= 96 keys) --------------------------------
 // CrossAttention over the text context (diffusion_model.py:102-127 with a context of 77 tokens): in the launch list the
 // query projection (LayerNorm-fold Dense, C -> C) and the attention over 77 keys are two latency-bound launches of ~12 us
@@ -815,9 +1136,22 @@ static constexpr int attn_lds_bytes() {
     return NBUF * (64 * (((D + 31) / 32) * 32 * 2 + 16) + ((D + 15) / 16) * 16 * (64 * 2 + 16));
 }
 
+// Which head sizes run on the 32x32x16 form.  In place in the UNet step (bench.py's per-call pass, batch 1): d = 40, S = 4096
+// 102.7 -> 73 us; d = 80, S = 1024 35.8 -> 27 us; d = 160, S = 256 15.6 -> 17.5 us (and its 77-key cross-attention 13.3 -> 15.2):
+// at d = 160 the form needs 260 registers (one wave per SIMD) for grids that are latency-bound anyway, so it stays on 16x16.
+// The choice follows the head size only — the two forms round differently, and a sample's bits must not depend on its batch.
+template <int D>
+static constexpr bool attn_form32() { return D == 40 || D == 80; }
+template <int D, int NBUF>
+static constexpr int attn32_lds_bytes() {
+    return NBUF * (64 * (((D + 15) / 16) * 16 * 2 + 16) + ((D + 31) / 32) * 32 * (64 * 2 + 16));
+}
+
 static bool g_attn_attr_done = false;
-static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = queries per wave / 16 forced (A/B runs)
+static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = 64 / 128 queries per workgroup forced (A/B runs)
 void msd_set_attn_qf(int v) { g_attn_qf = v; }
+static int g_attn_form = 1;   // 1 = 32x32x16 MFMA form (attention32_kernel) for head sizes 40 and 80 [default], 0 = 16x16x32 form everywhere (A/B runs)
+void msd_set_attn_form(int v) { g_attn_form = v; }
 static int g_xattn_nw = 0;    // 0 = automatic, 4 / 8 = waves (x 16 queries) per workgroup of the fused cross-attention (A/B runs)
 void msd_set_xattn_nw(int v) { g_xattn_nw = v; }
 
@@ -826,6 +1160,11 @@ static hipError_t attn_attr1() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D, NBUF, QF, PRESC>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds_bytes<D, NBUF>());
 }
+template <int D, int NBUF, int NW, bool PRESC>
+static hipError_t attn32_attr1() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&attention32_kernel<D, NBUF, NW, PRESC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, attn32_lds_bytes<D, NBUF>());
+}
 template <int D>
 static hipError_t attn_attr() {
     constexpr int NB = attn_nbuf<D>();
@@ -833,6 +1172,12 @@ static hipError_t attn_attr() {
     if (e == hipSuccess) e = attn_attr1<D, NB, 2, false>();
     if (e == hipSuccess) e = attn_attr1<D, NB, 1, true>();
     if (e == hipSuccess) e = attn_attr1<D, NB, 2, true>();
+    if constexpr (attn_form32<D>()) {
+        if (e == hipSuccess) e = attn32_attr1<D, NB, 2, false>();
+        if (e == hipSuccess) e = attn32_attr1<D, NB, 4, false>();
+        if (e == hipSuccess) e = attn32_attr1<D, NB, 2, true>();
+        if (e == hipSuccess) e = attn32_attr1<D, NB, 4, true>();
+    }
     return e;
 }
 int msd_attention_init() {
@@ -858,10 +1203,23 @@ static void attn_launch2(const AArgs& a, dim3 grid, hipStream_t stream) {
     if (a.presc) hipLaunchKernelGGL((attention_kernel<D, NBUF, QF, true>), grid, dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((attention_kernel<D, NBUF, QF, false>), grid, dim3(256), lds, stream, a);
 }
+template <int D, int NBUF, int NW>
+static void attn32_launch2(const AArgs& a, dim3 grid, hipStream_t stream) {
+    constexpr int lds = attn32_lds_bytes<D, NBUF>();
+    if (a.presc) hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, true>), grid, dim3(64 * NW), lds, stream, a);
+    else hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, false>), grid, dim3(64 * NW), lds, stream, a);
+}
 template <int D>
 static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
     const int qt = 64 * qf;
     const dim3 grid(((a.s + qt - 1) / qt) * a.heads * a.batch);
+    if constexpr (attn_form32<D>()) {
+        if (g_attn_form == 1) {
+            if (qf == 1) attn32_launch2<D, attn_nbuf<D>(), 2>(a, grid, stream);
+            else attn32_launch2<D, attn_nbuf<D>(), 4>(a, grid, stream);
+            return;
+        }
+    }
     if (qf == 1) attn_launch2<D, attn_nbuf<D>(), 1>(a, grid, stream);
     else attn_launch2<D, attn_nbuf<D>(), 2>(a, grid, stream);
 }

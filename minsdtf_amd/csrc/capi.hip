@@ -26,8 +26,10 @@ extern "C" int msd_init(void) {
 void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
+void msd_set_gn_cluster(int v);
 void msd_set_attn_qf(int v);
 void msd_set_xattn_nw(int v);
+void msd_set_attn_form(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "gn_impl" (1 = single-launch per-group
  * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
 extern "C" int msd_set_option(const char* key, int value) {
@@ -40,6 +42,11 @@ extern "C" int msd_set_option(const char* key, int value) {
         msd_set_attn_qf(value);
         return MSD_OK;
     }
+    if (key && strcmp(key, "attn_form") == 0) {   // 1 = attention on 32x32x16 MFMAs [default], 0 = on 16x16x32 MFMAs
+        if (value != 0 && value != 1) MSD_FAIL(MSD_E_ARG, "set_option: attn_form takes 0 or 1");
+        msd_set_attn_form(value);
+        return MSD_OK;
+    }
     if (key && strcmp(key, "xattn_nw") == 0) {    // 0 = automatic [default], 4 / 8 = 64 / 128 queries per fused cross-attention workgroup
         if (value != 0 && value != 4 && value != 8) MSD_FAIL(MSD_E_ARG, "set_option: xattn_nw takes 0, 4 or 8");   // grid and kernel must agree on the tile
         msd_set_xattn_nw(value);
@@ -47,6 +54,11 @@ extern "C" int msd_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "gn_wide") == 0) {   // 1 = 1024-thread GroupNorm workgroups for mid-sized tensors [default]
         msd_set_gn_wide(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "gn_cluster") == 0) {   // pixels per part of the cluster GroupNorm (P = pixels / this, a power of two <= 8) [default 256]; 0 = never
+        if (value != 0 && (value < 64 || value > (1 << 20))) MSD_FAIL(MSD_E_ARG, "set_option: gn_cluster takes 0 or 64 .. 2^20 pixels per part");
+        msd_set_gn_cluster(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "gn_impl") == 0) {

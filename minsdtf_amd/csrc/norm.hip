@@ -346,6 +346,152 @@ __global__ __launch_bounds__(1024) void gn_group_kernel(const GNArgs p, int upp,
     }
 }
 
+// ---- single-launch GroupNorm over a CLUSTER of workgroups per (sample, group) -------------------------------------------
+// The 64x64 level (and the VAE's 64x64 / 128x128 stages) used to take two launches — partial moments, then a second read to
+// normalise — because ONE workgroup per (sample, group) leaves 3/4 of the chip idle there (64 slabs of 80-250 KB at batch 1).
+// Here P = 2 / 4 / 8 workgroups share a slab by pixel range: each reads its part ONCE into registers, reduces it, publishes
+// its partial moments, collects the other parts', and normalises from registers: one read, one write, one launch, and
+// 32 x batch x P workgroups.  P depends on the sample's size only (the parts are summed in part order, so P is part of the
+// arithmetic: a sample's bits must not depend on the batch it runs in).
+//
+// The exchange (MI355X_MICROARCH.md, hand-off price list: data-tagged granules): every partial moment travels as ONE naturally
+// aligned 8-byte {value, epoch} word written by one agent-scope store and polled with agent-scope loads — the tag arrives
+// with the data, so no store -> flag ordering is needed.  The epoch comes from a per-(P, sample, group) ticket counter in the
+// caller's `sync` block (zero-initialised, used by nothing else, one block per stream): every launch adds exactly P to it, so
+// ticket / P + 1 is the same number in the P workgroups of a launch and differs from every earlier launch's.
+// Progress: the parts of a group are consecutive workgroup ids, so under in-order dispatch at most ONE group is ever partly
+// resident and every other resident group completes; should the dispatch ever be out of order the poll is BOUNDED (it gives
+// up, raises the block's error word and the launch finishes with wrong numbers instead of hanging the GPU).
+constexpr int GN_SYNC_WORDS_PER_SLOT = 64;   // [0] ticket, [8] error, [16..31] sum granules, [32..47] sum-of-squares granules
+constexpr int GN_POLL_LIMIT = 1 << 18;
+
+template <int NPT, int V>
+__global__ __launch_bounds__(1024) void gn_cluster_kernel(const GNArgs p, int upp, int ppp, uint32_t mg_upp, int pshift, int ppart,
+                                                          uint32_t* sync_region) {
+    typedef typename gn_vec<V>::type vec_t;
+    __shared__ float red[16][2];
+    __shared__ float s_stat[2];
+    const int t = threadIdx.x;
+    const int P = 1 << pshift;
+    const int part = blockIdx.x & (P - 1), slot = blockIdx.x >> pshift;   // slot = b * 32 + g
+    const int b = slot >> 5, g = slot & 31;
+    const int cpg = p.C / 32;
+    const int pl = udiv_magic(t, upp, mg_upp), u = t - pl * upp;   // my pixel lane, my unit inside the group's run
+    const bool active = pl < ppp;
+    const int px0 = part * ppart, px1 = min(p.hw, px0 + ppart);
+    const int c = g * cpg + u * 2 * V;          // first of my 2V channels
+    const size_t row0 = (size_t)b * p.hw;
+    const bool first = c < p.c0;
+    const int sstride = first ? p.c0 : p.c1;
+    const bf16_t* src = first ? p.x0 + row0 * p.c0 + c : p.x1 + row0 * p.c1 + (c - p.c0);
+
+    union { vec_t v; uint32_t w[V]; } x[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int px = px0 + pl + k * ppp;
+        if (active && px < px1) x[k].v = *reinterpret_cast<const vec_t*>(src + (size_t)px * sstride);
+        else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) x[k].w[e] = 0u;
+        }
+    }
+    float gm[2 * V], bt[2 * V];
+#pragma unroll
+    for (int e = 0; e < 2 * V; ++e) { gm[e] = p.gamma[c + e]; bt[e] = p.beta[c + e]; }
+
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float lo = bf_lo(x[k].w[e]), hi = bf_hi(x[k].w[e]);
+            s += lo + hi;
+            ss += lo * lo + hi * hi;
+        }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if ((t & 63) == 0) { red[t >> 6][0] = s; red[t >> 6][1] = ss; }
+    __syncthreads();
+    if (t < 64) {   // wave 0: publish this part's moments, collect all P parts (lane j polls part j), sum them in part order
+        // (slot-major, one 64-word block per P: where a block lies does not depend on the batch of the launch, so launches
+        //  of different batch sizes that share a sync block still keep one counter per (sample, group, P))
+        uint32_t* blk = sync_region + ((size_t)slot * 3 + (pshift - 1)) * GN_SYNC_WORDS_PER_SLOT;
+        unsigned long long* ga = reinterpret_cast<unsigned long long*>(blk + 16);
+        unsigned long long* gq = reinterpret_cast<unsigned long long*>(blk + 32);
+        uint32_t epoch = 0;
+        if (t == 0) {
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { a += red[w][0]; q += red[w][1]; }
+            const uint32_t ticket = __hip_atomic_fetch_add(blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            epoch = (ticket >> pshift) + 1u;
+            __hip_atomic_store(ga + part, ((unsigned long long)epoch << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gq + part, ((unsigned long long)epoch << 32) | __float_as_uint(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        epoch = __shfl(epoch, 0);
+        unsigned long long va = 0, vq = 0;
+        bool done = t >= P;
+        for (int it = 0; it < GN_POLL_LIMIT; ++it) {
+            if (!done) {
+                va = __hip_atomic_load(ga + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vq = __hip_atomic_load(gq + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                done = (uint32_t)(va >> 32) == epoch && (uint32_t)(vq >> 32) == epoch;
+            }
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) != 0 && t == 0) blk[8] = 1u;   // gave up (never under in-order dispatch): flag it
+        float a = 0.f, q = 0.f;
+        for (int j = 0; j < P; ++j) {   // fixed order: ((p0 + p1) + p2) + ...
+            a += __uint_as_float((uint32_t)__shfl(va, j));
+            q += __uint_as_float((uint32_t)__shfl(vq, j));
+        }
+        if (t == 0) {
+            const float cnt = (float)p.hw * (float)cpg;
+            const float mean = a / cnt;
+            const float var = fmaxf(q / cnt - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + p.eps);
+            s_stat[0] = mean; s_stat[1] = rstd;
+            if (part == 0) {
+                p.stats[((size_t)b * 32 + g) * 2 + 0] = mean;
+                p.stats[((size_t)b * 32 + g) * 2 + 1] = rstd;
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const float mean = s_stat[0], rstd = s_stat[1];
+#pragma unroll
+    for (int e = 0; e < 2 * V; ++e) { gm[e] *= rstd; bt[e] -= mean * gm[e]; }
+    bf16_t* dst = p.out + row0 * p.C + c;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int px = px0 + pl + k * ppp;
+        if (px < px1) {
+            union { vec_t v; uint32_t w[V]; } o;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float lo = bf_lo(x[k].w[e]) * gm[2 * e] + bt[2 * e];
+                float hi = bf_hi(x[k].w[e]) * gm[2 * e + 1] + bt[2 * e + 1];
+                if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
+                o.w[e] = pack_bf2(lo, hi);
+            }
+            *reinterpret_cast<vec_t*>(dst + (size_t)px * p.C) = o.v;
+        }
+    }
+}
+
+template <int V>
+static void gn_cluster_launch(const GNArgs& a, int upp, int npt, dim3 grid, int pshift, int ppart, uint32_t* region, hipStream_t stream) {
+    const dim3 block(1024);
+    const int ppp = 1024 / upp;
+    const uint32_t mg = udiv_magic_of(upp);
+    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region);
+    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region);
+    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region);
+}
+
 template <int V>
 static void gn_group_launch(const GNArgs& a, int upp, int npt, dim3 grid, hipStream_t stream) {
     const dim3 block(1024);
@@ -359,6 +505,9 @@ static void gn_group_launch(const GNArgs& a, int upp, int npt, dim3 grid, hipStr
 
 static int g_gn_impl = 1;  // 1 = single-launch per-group kernel where the group slab fits, 0 = always stats/finalize/apply
 static int g_gn_wide = 1;  // 1 = 1024-thread stats / apply workgroups for mid-sized tensors, 0 = always 256 (A/B runs)
+static int g_gn_cluster = 256;    // pixels per part the cluster kernel aims at: P = largest power of two <= pixels / this, at most 8
+                                  // (P = 1: the one-workgroup kernel); 0 = never the cluster kernel (A/B runs)
+void msd_set_gn_cluster(int v) { g_gn_cluster = v; }
 void msd_set_gn_impl(int v) { g_gn_impl = v; }
 void msd_set_gn_wide(int v) { g_gn_wide = v; }
 
@@ -393,6 +542,31 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
             const int dpp = cpg / 2;
             const int V = (dpp % 4 == 0) ? 4 : (dpp % 2 == 0) ? 2 : 1;
             const int upp = dpp / V, ppp = 1024 / upp;
+            // cluster form: P parts per (sample, group), from the SAMPLE's size only
+            int pshift = 0;
+            if (g_gn_cluster && q->sync) {
+                int P = q->hw / g_gn_cluster;
+                if (P > 8) P = 8;
+                while ((2 << pshift) <= P) ++pshift;
+            }
+            if (pshift > 0) {
+                const int P = 1 << pshift;
+                const int ppart = (q->hw + P - 1) / P;
+                const int nptc = (ppart + ppp - 1) / ppp;
+                const long long need = (long long)3 * q->batch * 32 * GN_SYNC_WORDS_PER_SLOT;
+                if (nptc <= (V == 4 ? 8 : 16) && (long long)q->batch * 32 * P < (1ll << 30)) {
+                    if (q->sync_words < need)
+                        MSD_FAIL(MSD_E_WORKSPACE, "group_norm: sync block too small (%lld < %lld words)", (long long)q->sync_words, need);
+                    if (((uintptr_t)q->sync) & 7u) MSD_FAIL(MSD_E_ALIGN, "group_norm: sync must be 8-byte aligned");
+                    uint32_t* region = q->sync;
+                    const dim3 grid(32 * q->batch * P);
+                    if (V == 4) gn_cluster_launch<4>(a, upp, nptc, grid, pshift, ppart, region, stream);
+                    else if (V == 2) gn_cluster_launch<2>(a, upp, nptc, grid, pshift, ppart, region, stream);
+                    else gn_cluster_launch<1>(a, upp, nptc, grid, pshift, ppart, region, stream);
+                    MSD_CHECK_LAUNCH();
+                    return MSD_OK;
+                }
+            }
             const int npt = (q->hw + ppp - 1) / ppp;
             // <= 32 data registers per thread.  Bigger slabs (the 64x64 level: 21+ units per thread) measured
             // SLOWER this way than stats + apply (22 vs 20 us at C=320, 33 vs 27 us at C=640): with 64

@@ -137,6 +137,7 @@ class Plan:
         self._ws_buf: Optional[Buf] = None
         self._stats_buf: Optional[Buf] = None
         self._gn_part_buf: Optional[Buf] = None
+        self._gn_sync_buf: Optional[Buf] = None   # ticket counters + granules of the cluster GroupNorm (zero at start, this plan's only)
         self.keep: list = []  # device tensors that must outlive the plan
 
     # -- memory
@@ -173,6 +174,10 @@ class Plan:
     def gn_partials(self):
         return _Lazy(lambda: self._gn_part_buf.ptr)
 
+    @property
+    def gn_sync(self):
+        return _Lazy(lambda: self._gn_sync_buf.ptr)
+
     def gn_stats_slot(self, batch: int):
         slot = self.gn_slots
         self.gn_slots += 1
@@ -187,6 +192,9 @@ class Plan:
         if self.gn_slots:
             self._stats_buf = self._alloc_tail(self.gn_slots * self.gn_batch * 64 * 4)
             self._gn_part_buf = self._alloc_tail(self.gn_batch * ops.GN_MAX_CHUNKS * 64 * 4)
+            # (the arena is allocated zeroed and this range is never recycled: the cluster kernel's counters start at 0 and
+            #  only its launches on this plan's stream ever touch them)
+            self._gn_sync_buf = self._alloc_tail(self.gn_batch * ops.GN_SYNC_WORDS_PER_SAMPLE * 4)
         self.arena.materialize(self.device, self.high_water)
         self.calls = [r() for r in self.recs]
         self.recs = []
@@ -322,7 +330,7 @@ class Emitter:
         out = p.act(x0.B, x0.H, x0.W, C)
         p.rec(ops.group_norm, x0=x0.buf, x1=None if x1 is None else x1.buf, c1=0 if x1 is None else x1.C,
               gamma=self.W[name + ".g"], beta=self.W[name + ".b"], stats=p.gn_stats_slot(x0.B), partials=p.gn_partials, out=out.buf, batch=x0.B,
-              hw=x0.H * x0.W, c0=x0.C, silu=silu, eps=EPS, name=name)
+              hw=x0.H * x0.W, c0=x0.C, silu=silu, eps=EPS, sync=p.gn_sync, name=name)
         return out
 
     def layer_norm(self, x: Act, name) -> Act:

@@ -113,14 +113,21 @@ def conv_direct(*, x, w, out, batch, h_in, w_in, c_in, c_out, ksize=3, stride=1,
 GN_MAX_CHUNKS = 1024
 
 
+GN_SYNC_WORDS_PER_SAMPLE = 3 * 32 * 64   # MSD_GN_SYNC_WORDS_PER_SAMPLE
+
+
 def group_norm(*, x0, gamma, beta, stats, partials, out, batch, hw, c0, x1=None, c1=0, silu=False, eps=1e-5,
-               partials_floats=None, name="group_norm") -> Call:
+               partials_floats=None, sync=None, sync_words=None, name="group_norm") -> Call:
+    """sync: zero-initialised uint32 block of >= batch * GN_SYNC_WORDS_PER_SAMPLE words owned by the calling stream (see
+    include/minsdtf_hip.h): enables the single-launch cluster form for the larger tensors."""
     lib = _lib.load()
     s = _lib.MsdGroupNorm()
     s.x0, s.x1, s.gamma, s.beta, s.stats, s.out = _p(x0), _p(x1), _p(gamma), _p(beta), _p(stats), _p(out)
     s.partials = _p(partials)
     s.partials_floats = batch * GN_MAX_CHUNKS * 64 if partials_floats is None else partials_floats
     s.batch, s.hw, s.c0, s.c1, s.silu, s.eps = batch, hw, c0, c1, int(bool(silu)), float(eps)
+    s.sync = _p(sync)
+    s.sync_words = 0 if sync is None else (batch * GN_SYNC_WORDS_PER_SAMPLE if sync_words is None else sync_words)
     return Call(lib.msd_group_norm, (C.byref(s),), name, keep=s)
 
 

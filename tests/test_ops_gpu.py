@@ -490,6 +490,76 @@ def test_group_norm(gpu, case):
         assert torch.equal(out.view(torch.int16), out2.view(torch.int16))   # bit-reproducible run to run
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=2, hw=4096, c0=320, silu=True),               # the UNet's 64x64 level: 4 parts, 4-byte units
+    dict(B=1, hw=4096, c0=640, c1=320, silu=True),       # C = 960: 16 units per thread, a group straddles x0 | x1
+    dict(B=1, hw=4100, c0=320, c1=320, silu=False),      # ragged last part, 8-byte units
+    dict(B=2, hw=9216, c0=320, silu=True),               # 768x768 (BASELINE config 4): 8 parts
+    dict(B=1, hw=16384, c0=512, silu=True),              # VAE 128x128 stage: 16-byte units, 8 parts
+    dict(B=3, hw=2048, c0=1280, silu=False),             # 2 parts
+    dict(B=2, hw=1024, c0=640, silu=True, opt=256),      # the 32x32 level on 4 parts (gn_cluster = 256 pixels per part)
+    dict(B=2, hw=256, c0=1280, silu=True, opt=128),      # ... and the 16x16 level on 2
+])
+def test_group_norm_cluster(gpu, case):
+    """GroupNorm as ONE launch in which 2 / 4 / 8 workgroups share a (sample, group) slab and exchange partial moments through the
+    caller's sync block (norm.hip gn_cluster_kernel): against fp32 group_norm; the same bits on every repetition (each launch
+    runs under a new epoch of the same counters), for a sample alone and inside a batch (with the SAME sync block, so the
+    block's layout may not depend on the batch), and with launches of another part count in between; no workgroup ever gave
+    up waiting (error words stay 0)."""
+    from minsdtf_amd import _lib, ops
+
+    torch.manual_seed(15)
+    B, hw, c0, c1 = case["B"], case["hw"], case["c0"], case.get("c1", 0)
+    C = c0 + c1
+    x0 = bf(torch.randn(B, hw, c0) * 2 + 0.7)
+    x1 = bf(torch.randn(B, hw, c1) - 0.3) if c1 else None
+    x = torch.cat([x0, x1], -1) if c1 else x0
+    gamma, beta = torch.randn(C) * 0.2 + 1, torch.randn(C) * 0.2
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-5).permute(0, 2, 1)
+    if case["silu"]:
+        ref = ref * torch.sigmoid(ref)
+    d = gpu
+    keep = [x0.to(torch.bfloat16).to(d), None if x1 is None else x1.to(torch.bfloat16).to(d), gamma.to(d), beta.to(d)]
+    stats = torch.full((B * 64,), float("nan"), dtype=torch.float32, device=d)
+    partials = torch.full((B * ops.GN_MAX_CHUNKS * 64,), float("nan"), dtype=torch.float32, device=d)
+    sync = torch.zeros(B * ops.GN_SYNC_WORDS_PER_SAMPLE, dtype=torch.int32, device=d)
+
+    def launch(out, b=B, xs=(keep[0], keep[1]), hw_=hw):
+        return ops.group_norm(partials=partials, x0=xs[0], x1=xs[1], gamma=keep[2], beta=keep[3], stats=stats, out=out, batch=b, hw=hw_,
+                              c0=c0, c1=c1, silu=case["silu"], sync=sync)
+
+    lib = _lib.load()
+    lib.msd_set_option(b"gn_cluster", case.get("opt", 256))
+    try:
+        outs = [torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=d) for _ in range(3)]
+        run_calls([launch(o) for o in outs])                       # three epochs back to back on one stream
+        counters = sync.view(-1, 64)[:, 0].clone()
+        assert int(counters.max()) > 0, "the cluster form did not run"     # (tickets were taken)
+        close(outs[0], ref, atol=2e-2, what=str(case))
+        for o in outs[1:]:
+            assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16))
+        xs = x.reshape(B, hw, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1)
+        st = stats.cpu().reshape(B, 32, 2)
+        np.testing.assert_allclose(st[..., 0].numpy(), xs.mean(-1).numpy(), rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(st[..., 1].numpy(), (xs.var(-1, unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-3)
+        # another part count on the same sync block in between (half the pixels -> half the parts where parts follow the size)
+        half = torch.full((B, hw // 2, C), float("nan"), dtype=torch.bfloat16, device=d)
+        x0h = keep[0][:, :hw // 2].contiguous()
+        x1h = None if keep[1] is None else keep[1][:, :hw // 2].contiguous()
+        one = torch.full((1, hw, C), float("nan"), dtype=torch.bfloat16, device=d)
+        again = torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=d)
+        last = B - 1   # the LAST sample alone: in a batch of one it uses sample 0's counters, at another epoch than sample 0's
+        x0l = keep[0][last:last + 1].contiguous()
+        x1l = None if keep[1] is None else keep[1][last:last + 1].contiguous()
+        run_calls([launch(half, xs=(x0h, x1h), hw_=hw // 2), launch(one, b=1, xs=(x0l, x1l)), launch(again)])
+        assert bool(torch.isfinite(half.float()).all())
+        assert torch.equal(one[0].view(torch.int16), outs[0][last].view(torch.int16)), "a sample's bits depend on its batch"
+        assert torch.equal(again.view(torch.int16), outs[0].view(torch.int16))
+        assert int(sync.view(-1, 64)[:, 8].max()) == 0, "a workgroup gave up waiting for its group's partial moments"
+    finally:
+        lib.msd_set_option(b"gn_cluster", 256)
+
+
 @pytest.mark.parametrize("B,S,spike", [(1, 4096, False), (2, 320, True), (1, 9216, False), (1, 64, False), (3, 200, False)])
 def test_attention_d512(gpu, B, S, spike):
     """VAE AttentionBlock (layers.py:28-59): single head, d = 512, softmax(q k^T / sqrt(512)) v with the scores kept on
@@ -543,7 +613,8 @@ def test_layer_norm(gpu, rows, c):
 ])
 @pytest.mark.parametrize("qf", [2, 1])   # 128 / 64 queries per workgroup (the library picks by grid size; both forced here)
 @pytest.mark.parametrize("presc", [False, True])   # q carrying scale*log2(e) already (the UNet's projections) or not
-def test_attention(gpu, case, qf, presc):
+@pytest.mark.parametrize("form", [1, 0])   # d = 40 / 80: the 32x32x16 MFMA kernel (default) or the 16x16x32 one; other head sizes: 16x16x32 either way
+def test_attention(gpu, case, qf, presc, form):
     """The lazy rescale (attention.hip ATTN_THR) is a rare data-dependent branch: the `spike` cases force it at chosen
     tiles (one key row scaled so the tile maximum jumps far past the threshold), `ramp` makes the maximum grow by
     less than the threshold over several tiles first (the deferred path), and the reference is the full fp32 softmax."""
@@ -580,14 +651,18 @@ def test_attention(gpu, case, qf, presc):
     kd = k.to(torch.bfloat16).to(gpu)
     call = ops.attention(q=qbuf.data_ptr() + 2 * C, k=kd, vt=vt, out=out, batch=B, heads=H,
                          head_dim=d, s=S, t=T, q_ld=3 * C, k_ld=C, vt_ld=Tp, o_ld=C, scale=scale, q_prescaled=presc)
+    if form == 0 and (d not in (40, 80) or S > 2048):
+        pytest.skip("the same kernel as form 1 (or a long CPU reference already spent on it)")
     _lib.load().msd_set_option(b"attn_qf", qf)
+    _lib.load().msd_set_option(b"attn_form", form)
     try:
         run_calls(call)
     finally:
         _lib.load().msd_set_option(b"attn_qf", 0)
+        _lib.load().msd_set_option(b"attn_form", 1)
     # P is rounded to bf16 before the PV product (relative 2^-9 per term): the error scales with the
     # magnitude of the summed terms, so the absolute floor is 1.5e-2 of max(1, max|O|)
-    close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"{case} qf={qf} presc={presc}")
+    close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"{case} qf={qf} presc={presc} form={form}")
 
 
 @pytest.mark.parametrize("case", [

@@ -30,12 +30,14 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--qf", type=int, default=0, help="0 = automatic, 1 / 2 = 64 / 128 queries per workgroup")
     ap.add_argument("--presc", type=int, default=1, help="1 = q carries scale*log2(e) (the UNet's projections), 0 = generic")
+    ap.add_argument("--form", type=int, default=1, help="1 = 32x32x16 MFMA kernel, 0 = 16x16x32 MFMA kernel")
     args = ap.parse_args()
     from minsdtf_amd import _lib, ops
 
     lib = _lib.load()
     lib.msd_init()
     lib.msd_set_option(b"attn_qf", args.qf)
+    _lib.check(lib.msd_set_option(b"attn_form", args.form), "attn_form")
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream()
     for idx, (name, B, H, d, S, T) in enumerate(SHAPES):

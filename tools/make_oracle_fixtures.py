@@ -8,6 +8,7 @@ run in the build container, the GPU box only reads the committed .npz files.
                                                      uint8 image (reference :483-486 conversion) + the float image on a stride-4 pixel grid
   c3        tests/golden/oracle_c3_b4_512_3.npz      C3 per-GPU shape: batch 4 at 512x512, 3 steps -> final latent (4,64,64,4)
   c4        tests/golden/oracle_c4_768_2.npz         C4 shape: 768x768 (latent 96x96, S = 9216), 2 steps -> final latent + uint8 image
+  c4_long   tests/golden/oracle_c4_768_8.npz         C4 shape over the complete 8-step schedule (error growth along a longer chain) -> final latent + uint8 image
   c5        tests/golden/oracle_c5_cn_512_2.npz      C5: ControlNet + HintNet at 512x512, 2 steps, batch 1 -> final latent
 
 Inputs are NOT stored; they are regenerated from the recorded numpy PCG64 seeds exactly as bench.py draws them:
@@ -98,6 +99,23 @@ def c4():
     print("wrote", out, os.path.getsize(out), "bytes,", f"{time.time() - t0:.0f}s", flush=True)
 
 
+def c4_long():
+    """C4 over a longer chain (error growth at 768x768): the complete 8-step schedule -> final latent + uint8 image."""
+    from oracle import sd_oracle as O
+
+    Wu = _weights("civitai_model")
+    ctx, unc, noise = _inputs(1, 96)
+    t0 = time.time()
+    lat, trace = _loop(Wu, ctx, unc, noise, 8, t0)
+    del Wu
+    Wv = _weights("decoder")
+    dec = O.decoder_forward(Wv, lat)
+    out = os.path.join(GOLD, "oracle_c4_768_8.npz")
+    np.savez_compressed(out, latent=lat, image_u8=O.to_uint8(dec), weight_seed=0, decoder_seed=0, context_seed=1234,
+                        noise_seed=0, guidance=7.5, guidance_rescale=0.7, size=768, steps=8)
+    print("wrote", out, os.path.getsize(out), "bytes,", f"{time.time() - t0:.0f}s", flush=True)
+
+
 def c5():
     from oracle import sd_oracle as O
 
@@ -117,7 +135,7 @@ def c5():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="+", choices=["c2_image", "c3", "c4", "c5"])
+    ap.add_argument("cases", nargs="+", choices=["c2_image", "c3", "c4", "c4_long", "c5"])
     for case in ap.parse_args().cases:
         print("==", case, flush=True)
         globals()[case]()
