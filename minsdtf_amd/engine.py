@@ -139,6 +139,7 @@ class Plan:
         self._gn_part_buf: Optional[Buf] = None
         self._gn_sync_buf: Optional[Buf] = None   # ticket counters + granules of the cluster GroupNorm (zero at start, this plan's only)
         self.keep: list = []  # device tensors that must outlive the plan
+        self.marks: Dict[str, int] = {}
 
     # -- memory
     def alloc(self, nbytes: int) -> Buf:
@@ -156,8 +157,12 @@ class Plan:
         for b in bufs:
             if isinstance(b, Act):
                 b = b.buf
-            if b is not None:
+            if b is not None and getattr(b, "arena", self.arena) is self.arena:   # (another plan's buffer is not ours to recycle)
                 self.arena.free(b)
+
+    def mark(self, name: str) -> None:
+        """Remember the position of the next recorded call under `name` (run_range: a plan split over two streams)."""
+        self.marks[name] = len(self.recs)
 
     def act(self, B, H, W, C) -> Act:
         return Act(self.alloc(B * H * W * C * 2), B, H, W, C)
@@ -201,6 +206,10 @@ class Plan:
 
     def run(self, stream: int) -> None:
         for c in self.calls:
+            c(stream)
+
+    def run_range(self, stream: int, lo: int, hi: Optional[int] = None) -> None:
+        for c in self.calls[lo:hi]:
             c(stream)
 
 
@@ -561,6 +570,7 @@ def emit_unet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w:
           out_dtype=ops.OUT_BF16, name="conv_in")
     outputs: List[Act] = [x]
     x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs)
+    p.mark("controls")   # everything above is independent of the ControlNet (its encoder may run beside it on another stream)
     if control_taps is not None:
         e_c, feats = control_taps
         assert len(outputs) == 12 and len(feats) == 13

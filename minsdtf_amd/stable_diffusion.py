@@ -38,6 +38,8 @@ from .models import (ControlNet, DiffusionModel, HintNet, ImageDecoder, ImageEnc
 from .scheduler import Scheduler
 
 MAX_PROMPT_LENGTH = 77
+# the ControlNet encoder on a side stream beside the UNet's down path (DenoiseEngine); "0": in line, in front of the UNet
+CONTROLNET_OVERLAP = os.environ.get("MSD_CONTROLNET_OVERLAP", "1") != "0"
 
 
 def get_timestep_embedding(timestep, batch_size, dim=320, max_period=10000):
@@ -143,6 +145,12 @@ class DenoiseEngine:
         cols_c = engine.temb_columns(True)
         self.branches = []
         step = None
+        # ControlNet beside the UNet's down path: its encoder reads the same latent and is independent of the UNet until the
+        # 13 residuals are added after the down path (diffusion_model.py:230-234), so with one fused pass it runs as its own
+        # plan (own arena, GroupNorm / split-K scratch) on a side stream: ONE fork after the sampler step, ONE join in front
+        # of the zero convs.  (Two passes — a negative prompt of another length — and the two-stream mode keep it in line.)
+        self.cn_plan = None
+        overlap = self.has_control and CONTROLNET_OVERLAP and len(passes) == 1 and not self.dual
         for (row0, nb, t, tag) in passes:
             if step is None or self.dual:
                 step = engine.Plan(dev)   # dual: each half owns its arena, the halves are live at the same time
@@ -153,7 +161,11 @@ class DenoiseEngine:
             if self.has_control:
                 # ControlNet encoder first; its 13 zero convs run inside the UNet plan, fused with the residual adds
                 hint_nb = engine.Act(hint_act.buf, nb, h, w, 320)  # first nb rows of the tiled hint
-                feats = engine.emit_controlnet_features(s_c, self.latent, B, nb, h, w, (table_c, total_c, 0, cols_c), ctx_kv_c[tag], t,
+                s_cf = s_c
+                if overlap:
+                    self.cn_plan = engine.Plan(dev)
+                    s_cf = engine.Emitter(self.cn_plan, control_net._W, step_ptr=self.step_ptr)
+                feats = engine.emit_controlnet_features(s_cf, self.latent, B, nb, h, w, (table_c, total_c, 0, cols_c), ctx_kv_c[tag], t,
                                                         hint_nb)
                 taps = (s_c, feats)
             eps_view = _Ptr(self.eps.data_ptr() + row0 * n * 4)
@@ -174,11 +186,15 @@ class DenoiseEngine:
                  num_steps=num_steps, guidance=guidance, guidance_rescale=guidance_rescale, advance=True,
                  inpaint_init=ip.get("init"), inpaint_noise=ip.get("noise"), inpaint_mask=ip.get("mask"),
                  step_noise=self.step_noise, noise_coef=self.noise_coef)
+        if self.cn_plan is not None:
+            self.cn_plan.finalize()   # (first: the main plan's zero convs record addresses of its feature maps)
+            self._join = step.marks["controls"]
         for pl in self.branches:
             pl.finalize()
         self.tail = tail if self.dual else None
         if self.dual:
             tail.finalize()
+        if self.dual or self.cn_plan is not None:
             self._side = torch.cuda.Stream(device=dev)
         self._step_graph: Optional[torch.cuda.CUDAGraph] = None
         self._loop_graph: Optional[torch.cuda.CUDAGraph] = None
@@ -195,6 +211,8 @@ class DenoiseEngine:
     def calls(self):
         """Every launch of one sampler step, in issue order (profiling / bench helpers)."""
         out = [c for pl in self.branches for c in pl.calls]
+        if self.cn_plan is not None:   # (listed in front of the UNet's calls, which is where they ran before the overlap)
+            out = self.cn_plan.calls + out
         return out + (self.tail.calls if self.tail is not None else [])
 
     def contexts(self, unconditional_context, context) -> dict:
@@ -211,6 +229,14 @@ class DenoiseEngine:
     def _one_step(self, main: "torch.cuda.Stream") -> None:
         """Issue one sampler step on `main` (dual: the cond half forks to the side stream and joins
         before the CFG / sampler kernel).  Works eagerly and under stream capture."""
+        if self.cn_plan is not None:
+            side = self._side
+            side.wait_stream(main)
+            self.cn_plan.run(side.cuda_stream)                          # ControlNet encoder ...
+            self.branches[0].run_range(main.cuda_stream, 0, self._join)   # ... beside conv_in + the UNet's down path + mid block
+            main.wait_stream(side)
+            self.branches[0].run_range(main.cuda_stream, self._join)      # zero convs (+ residual adds), up path, sampler step
+            return
         if not self.dual:
             self.branches[0].run(main.cuda_stream)
             return

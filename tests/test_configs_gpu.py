@@ -52,6 +52,26 @@ def test_controlnet_fused_loop_vs_oracle(gpu, nets):
     host = sd.generate_image(ctx[0], batch_size=1, num_steps=3, unconditional_guidance_scale=7.5, diffusion_noise=noise[0],
                              guidance_rescale=0.7, control_net_image=image, return_latent=True, host_loop=True)
     assert O.psnr(host, ref) >= PSNR_MIN
+    # the ControlNet encoder ran on a side stream beside the UNet's down path (one fork / join per step inside the captured
+    # loop): in line on one stream it gives the same bits, with and without the graph
+    from minsdtf_amd import stable_diffusion as SDm
+
+    assert sd._engine(1, 77, 77, 3, 7.5, 0.7, True).cn_plan is not None
+    try:
+        SDm.CONTROLNET_OVERLAP = False
+        sd._engines = {}
+        inline = sd.generate_image(ctx[0], batch_size=1, num_steps=3, unconditional_guidance_scale=7.5, diffusion_noise=noise[0],
+                                   guidance_rescale=0.7, control_net_image=image, return_latent=True)
+        assert sd._engine(1, 77, 77, 3, 7.5, 0.7, True).cn_plan is None
+    finally:
+        SDm.CONTROLNET_OVERLAP = True
+        sd._engines = {}
+    np.testing.assert_array_equal(got, inline)
+    calls = []
+    stepped = sd.generate_image(ctx[0], batch_size=1, num_steps=3, unconditional_guidance_scale=7.5, diffusion_noise=noise[0],
+                                guidance_rescale=0.7, control_net_image=image, return_latent=True, callback=calls.append)
+    assert calls == [1, 2, 3]
+    np.testing.assert_array_equal(got, stepped)   # per-step graph (fork / join inside each replay) == whole-loop graph
 
 
 def test_batch_equals_independent_samples(gpu, nets):

@@ -3,6 +3,7 @@ configurations (tests/test_baseline_configs_gpu.py).  Oracle only (fp32 torch-CP
 run in the build container, the GPU box only reads the committed .npz files.
 
     python tools/make_oracle_fixtures.py c2_image c3 c4 c5          (about 20 minutes on 8 cores)
+    python tools/make_oracle_fixtures.py c4_long:50 c5:25 c3:25     (the configurations' FULL chains: about 1.5 hours)
 
   c2_image  tests/golden/oracle_image_512_25.npz     VAE decode of the committed C2 oracle latent (oracle_latent_512_25.npz):
                                                      uint8 image (reference :483-486 conversion) + the float image on a stride-4 pixel grid
@@ -72,14 +73,14 @@ def c2_image():
     print("wrote", out, os.path.getsize(out), "bytes,", f"{time.time() - t0:.0f}s", flush=True)
 
 
-def c3():
+def c3(steps=3):
     Wu = _weights("civitai_model")
     ctx, unc, noise = _inputs(4, 64)
     t0 = time.time()
-    lat, trace = _loop(Wu, ctx, unc, noise, 3, t0)
-    out = os.path.join(GOLD, "oracle_c3_b4_512_3.npz")
+    lat, trace = _loop(Wu, ctx, unc, noise, steps, t0)
+    out = os.path.join(GOLD, f"oracle_c3_b4_512_{steps}.npz")
     np.savez_compressed(out, latent=lat, step0=trace[0], weight_seed=0, context_seed=1234, noise_seed=0, guidance=7.5,
-                        guidance_rescale=0.7, size=512, steps=3, batch=4)
+                        guidance_rescale=0.7, size=512, steps=steps, batch=4)
     print("wrote", out, os.path.getsize(out), "bytes,", f"{time.time() - t0:.0f}s", flush=True)
 
 
@@ -99,24 +100,25 @@ def c4():
     print("wrote", out, os.path.getsize(out), "bytes,", f"{time.time() - t0:.0f}s", flush=True)
 
 
-def c4_long():
-    """C4 over a longer chain (error growth at 768x768): the complete 8-step schedule -> final latent + uint8 image."""
+def c4_long(steps=8):
+    """C4 over a longer chain (error growth at 768x768): a complete `steps`-step schedule (8, or the configuration's own 50)
+    -> final latent + uint8 image."""
     from oracle import sd_oracle as O
 
     Wu = _weights("civitai_model")
     ctx, unc, noise = _inputs(1, 96)
     t0 = time.time()
-    lat, trace = _loop(Wu, ctx, unc, noise, 8, t0)
+    lat, trace = _loop(Wu, ctx, unc, noise, steps, t0)
     del Wu
     Wv = _weights("decoder")
     dec = O.decoder_forward(Wv, lat)
-    out = os.path.join(GOLD, "oracle_c4_768_8.npz")
+    out = os.path.join(GOLD, f"oracle_c4_768_{steps}.npz")
     np.savez_compressed(out, latent=lat, image_u8=O.to_uint8(dec), weight_seed=0, decoder_seed=0, context_seed=1234,
-                        noise_seed=0, guidance=7.5, guidance_rescale=0.7, size=768, steps=8)
+                        noise_seed=0, guidance=7.5, guidance_rescale=0.7, size=768, steps=steps)
     print("wrote", out, os.path.getsize(out), "bytes,", f"{time.time() - t0:.0f}s", flush=True)
 
 
-def c5():
+def c5(steps=2):
     from oracle import sd_oracle as O
 
     Wu = _weights("civitai_model")
@@ -126,16 +128,18 @@ def c5():
     image = np.random.default_rng(7).integers(0, 256, (1, 512, 512, 3)).astype(np.float32) / 255.0
     t0 = time.time()
     hint = O.hintnet_forward(Wh, image)
-    lat, trace = _loop(Wu, ctx, unc, noise, 2, t0, controlnet_fn=lambda l, t, c, h: O.controlnet_forward(Wc, l, t, c, h), hint=hint)
-    out = os.path.join(GOLD, "oracle_c5_cn_512_2.npz")
+    lat, trace = _loop(Wu, ctx, unc, noise, steps, t0, controlnet_fn=lambda l, t, c, h: O.controlnet_forward(Wc, l, t, c, h), hint=hint)
+    out = os.path.join(GOLD, f"oracle_c5_cn_512_{steps}.npz")
     np.savez_compressed(out, latent=lat, step0=trace[0], weight_seed=0, controlnet_seed=0, controlnet_bias_scale=0.05, context_seed=1234,
-                        noise_seed=0, hint_seed=7, guidance=7.5, guidance_rescale=0.7, size=512, steps=2)
+                        noise_seed=0, hint_seed=7, guidance=7.5, guidance_rescale=0.7, size=512, steps=steps)
     print("wrote", out, os.path.getsize(out), "bytes,", f"{time.time() - t0:.0f}s", flush=True)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="+", choices=["c2_image", "c3", "c4", "c4_long", "c5"])
+    ap.add_argument("cases", nargs="+", help="c2_image | c3[:steps] | c4 | c4_long[:steps] | c5[:steps]")
     for case in ap.parse_args().cases:
         print("==", case, flush=True)
-        globals()[case]()
+        name, _, n = case.partition(":")
+        assert name in ("c2_image", "c3", "c4", "c4_long", "c5"), name
+        globals()[name](*([int(n)] if n else []))
