@@ -311,7 +311,7 @@ def rank0_extras(out, args, sd, world, b, nsteps, size, ctx, unc, noise, hints, 
     out["ms_vae_decode"] = round(ev[1].elapsed_time(ev[2]), 3)
     out["launches_per_step"] = len(eng.calls)   # C-ABI calls of one sampler step (split-K reductions / second GroupNorm launches come on top)
     if not args.no_roofline:
-        out["roofline"], out["roofline_by_kernel"], extra = kernel_roofline(sd, b, nsteps, args.controlnet)
+        out["roofline"], out["roofline_by_kernel"], extra = kernel_roofline(sd, b, nsteps, args.controlnet, size)
         out["eager_ms_per_unet_step_by_entry_point"] = extra  # event-per-launch pass (includes ~1-2 us of event gap per call)
     if world == 1 and not args.controlnet:
         out["psnr_db_vs_oracle_golden"] = golden_psnr(sd, size, nsteps)
@@ -402,7 +402,12 @@ def algorithmic_tflop_per_image(size, nsteps, controlnet=False):
     return t
 
 
-def kernel_roofline(sd, b, nsteps, control=False):
+def config_tag(b, size, control):
+    """Suffix of the per-configuration files under profiles/ ("" = the headline configuration)."""
+    return ("_controlnet" if control else "") + (f"_{size}" if size != 512 else "") + (f"_b{b}" if b != 1 else "")
+
+
+def kernel_roofline(sd, b, nsteps, control=False, size=512):
     """Eager, event-timed pass over one denoise step: per-call durations on the launch stream."""
     import torch
 
@@ -505,7 +510,9 @@ def kernel_roofline(sd, b, nsteps, control=False):
     # HBM-side bytes per launch come from the PMC pass committed under profiles/ (rocprofv3 --pmc cannot run
     # inside this process); null when the file is missing
     traffic, traffic_src = None, None
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):   # newest committed PMC pass (tools/measure_round.sh)
+    tag = config_tag(b, size, control)
+    for rnd in range(9, 0, -1):   # newest committed PMC pass of THIS configuration (tools/measure_round.sh)
+        name = f"r{rnd}_pmc_traffic{tag}.json"
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pm = json.load(f)
@@ -514,7 +521,7 @@ def kernel_roofline(sd, b, nsteps, control=False):
             break
         except (OSError, ValueError):
             continue
-    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
+    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> / dense_rowpanel_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_src, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
             "gflop_per_launch": round(flop_per_launch / 1e9, 3)}

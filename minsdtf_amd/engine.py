@@ -205,12 +205,36 @@ class Plan:
         self.recs = []
 
     def run(self, stream: int) -> None:
-        for c in self.calls:
-            c(stream)
+        self.run_range(stream, 0, None)
 
     def run_range(self, stream: int, lo: int, hi: Optional[int] = None) -> None:
+        if not TRACE:
+            for c in self.calls[lo:hi]:
+                c(stream)
+            return
+        # $MSD_TRACE=1: a roctx range per network block (rocprofv3 --marker-trace attributes the kernel trace to
+        # down_blocks.0.resnets.0, ...attentions.1, mid_block, ...; eager runs — ranges are host-side, a replayed graph has none)
+        cur = None
         for c in self.calls[lo:hi]:
+            blk = _block_of(c.name)
+            if blk != cur:
+                if cur is not None:
+                    torch.cuda.nvtx.range_pop()
+                torch.cuda.nvtx.range_push(blk)
+                cur = blk
             c(stream)
+        if cur is not None:
+            torch.cuda.nvtx.range_pop()
+
+
+TRACE = os.environ.get("MSD_TRACE", "0") == "1"
+
+
+def _block_of(call_name: str) -> str:
+    """'down_blocks.0.attentions.1.transformer_blocks.0.attn1.qkv' -> 'down_blocks.0.attentions.1'."""
+    parts = call_name.split(".")
+    n = 4 if parts[0] in ("down_blocks", "up_blocks") else 3 if parts[0] == "mid_block" else 2 if parts[0] in ("decoder", "encoder") else 1
+    return ".".join(parts[:n])
 
 
 class _Lazy:

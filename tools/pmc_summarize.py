@@ -19,13 +19,13 @@ import sys
 def klass(name):
     if "splitk_finalize" in name:
         return "conv_gemm", False
-    if "conv_gemm" in name or "conv3x3_halo" in name:
+    if "conv_gemm" in name or "conv3x3_halo" in name or "dense_rowpanel" in name:
         return "conv_gemm", True
     if name.startswith("void gn_") or name.startswith("gn_"):
         return "group_norm", "stats" not in name and "finalize" not in name
     if "layer_norm" in name:
         return "layer_norm", True
-    if "attention_kernel" in name:
+    if "attention" in name or "xattn_q" in name:
         return "attention", True
     return "other", True
 
