@@ -280,7 +280,8 @@ struct TileCfg { int bm, bn, threads, lds, stages; };
     X(14, 128, 128, 2, 2, 3, 23) \
     X(15, 128, 128, 2, 2, 4, 24) \
     X(16, 128, 64, 2, 1, 4, 24)  \
-    X(17, 64, 128, 1, 2, 4, 24)
+    X(17, 64, 128, 1, 2, 4, 24)  \
+    X(18, 128, 160, 4, 1, 3, 3)
 // Last column = the `stages` request that selects the entry (the first entry of a tile size is its
 // default).  Codes 10 + depth are the same tile on 8 waves (32x16 / 32x32 per wave): two waves per SIMD
 // even when a launch puts one workgroup on a CU, so one wave's LDS-DMA issue and LDS latency overlap the
@@ -289,13 +290,16 @@ struct TileCfg { int bm, bn, threads, lds, stages; };
 // cores, bounds the K loop.
 // (128x80: for N = 320 / 640 at small batch — 64 x 4 = 256 workgroups at M = 8192, one per CU, where
 //  64-wide tiles make 320 and 128-wide ones 192; the 80 weight rows are staged as 96)
+// (128x160, four waves of 32 rows x 160 columns: for the 16x16-level GEGLU projection at batch 1 — M = 512, N = 10,240, K = 1,280
+//  — 4 x 64 = 256 workgroups, one per CU, each moving (128 + 160) rows per K step instead of 640 workgroups of 64x128 moving
+//  (64 + 128): the layer is bound by the L2 -> LDS bytes per CU, and this is the fewest for a grid that fills the chip once)
 constexpr int cfg_lds(int bm, int bn, int threads, int st) { return st * (bm + (bn + threads / 8 - 1) / (threads / 8) * (threads / 8)) * 128; }
 static const TileCfg g_cfgs[] = {
 #define X(id, bm, bn, wgm, wgn, st, code) {bm, bn, wgm * wgn * 64, cfg_lds(bm, bn, wgm * wgn * 64, st), code},
     MSD_TILE_CFGS(X)
 #undef X
 };
-constexpr int NUM_TILE_CFGS = 18;
+constexpr int NUM_TILE_CFGS = 19;
 
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream);
 bool msd_conv_rowpanel_eligible(const CGArgs& a, int rows, int wg_cols);

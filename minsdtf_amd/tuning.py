@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import json
 import os
+import re
 from typing import Dict, Optional, Tuple
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning.json")
@@ -22,7 +23,8 @@ _families: Optional[Dict[str, Dict[int, list]]] = None   # batch-agnostic key ->
 TILES = ((128, 128, 0), (128, 64, 0), (64, 64, 0), (64, 128, 0), (256, 128, 0),
          (128, 128, 4), (64, 64, 8), (64, 128, 5), (128, 64, 5), (128, 80, 0), (128, 80, 4),
          (64, 64, 14), (128, 64, 13), (64, 128, 13),   # stages 10 + depth: the tile on 8 waves
-         (128, 128, 23), (128, 128, 24), (128, 64, 24), (64, 128, 24))   # 20 + depth: 64x64 per wave (4 / 2 waves)
+         (128, 128, 23), (128, 128, 24), (128, 64, 24), (64, 128, 24),   # 20 + depth: 64x64 per wave (4 / 2 waves)
+         (128, 160, 0))
 HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (1256, 80, 0),
               (1128, 64, 8), (1128, 128, 6), (1128, 80, 8), (1256, 80, 5), (2128, 64, 0), (2128, 80, 0),
               (1128, 64, 33), (1128, 64, 34), (1128, 80, 33), (2128, 64, 33))   # 30 + depth: 3 taps (a filter row) per K step
@@ -96,10 +98,17 @@ def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_spli
     return heuristic(M // max(1, batch), N, nk, allow_split)
 
 
-def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int) -> Tuple[bool, int, int]:
+def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int, ln_producer: bool = True) -> Tuple[bool, int, int]:
     """The part of a launch configuration that decides the ORDER of the layer's fp32 sums: kernel family (halo-tile 3x3
-    kernel: chunk-major K walk), split-K slices, and for 1x1 / dense layers the column tile (grouping of the LayerNorm
-    fold's row-moment partials).  The table holds ONE class per layer shape for all batch sizes (tools/tune_conv.py)."""
+    kernel: chunk-major K walk), split-K slices, and for the 1x1 / dense layers that may PRODUCE LayerNorm-fold row moments
+    the column tile (how the moments are grouped into partials).  `ln_producer` = False for the shapes that never do — the
+    GEGLU and q|k|v projections, the keys ending in "n": their column tile orders nothing.  The table holds ONE class per
+    layer shape for all batch sizes (tools/tune_conv.py)."""
     if tile_m >= 3000:   # row-panel Dense kernel: the tile kernel's bits (a launch it cannot take runs on the 128x64 tile)
-        return (False, splitk, 64 if ksize == 1 else 0)
-    return (tile_m >= 1000, splitk, tile_n if ksize == 1 else 0)
+        return (False, splitk, 64 if (ksize == 1 and ln_producer) else 0)
+    return (tile_m >= 1000, splitk, tile_n if (ksize == 1 and ln_producer) else 0)
+
+
+def key_is_ln_producer(key: str) -> bool:
+    """Shape keys of the GEGLU / q|k|v projections carry an 'n' (no split-K: shape_key(allow_split=False))."""
+    return re.search(r"u[01]n(\+x\d+)?$", key) is None

@@ -61,6 +61,8 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=16, W=16, c0=64, N=128, ks=3, f32out=True, act="silu"),
     dict(B=2, H=12, W=20, c0=64, N=192, ks=3, tile_m=64, tile_n=64),     # every tile configuration, ragged edges
     dict(B=2, H=12, W=20, c0=128, N=192, ks=3, tile_m=64, tile_n=128),
+    dict(B=2, H=12, W=20, c0=128, N=400, ks=3, tile_m=128, tile_n=160),      # 128x160 tile: ragged M (480) and N (2.5 tiles)
+    dict(B=1, H=16, W=16, c0=320, N=320, ks=1, tile_m=128, tile_n=160),      # ... on the dense form
     dict(B=3, H=12, W=20, c0=64, N=192, ks=3, tile_m=256, tile_n=128),
     dict(B=1, H=8, W=8, c0=256, N=320, ks=3, tile_m=64, tile_n=64, splitk=3),
     dict(B=2, H=16, W=16, c0=128, c1=64, N=128, ks=3, tile_m=256, tile_n=128, upsample=True),
@@ -204,11 +206,12 @@ def test_conv_gemm_shortcut_operand(gpu, case):
     assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "weight layout changed the bits"
 
 
-def test_conv_gemm_geglu(gpu):
+@pytest.mark.parametrize("tile", [(0, 0), (128, 160), (64, 128), (3128, 320)])   # heuristic tile, the 128x160 tile (16x16 level), 64x128, row panels
+def test_conv_gemm_geglu(gpu, tile):
     from minsdtf_amd import ops, packing
 
     torch.manual_seed(2)
-    M, C = 192, 64
+    M, C = (192, 64) if tile[0] < 3000 else (200, 320)   # (the row-panel kernel takes K = 320 / 640)
     x = bf(torch.randn(M, C))
     w = bf(torch.randn(C, 8 * C) / math.sqrt(C))
     b = torch.randn(8 * C) * 0.1
@@ -218,9 +221,9 @@ def test_conv_gemm_geglu(gpu):
     wp, bp = packing.pack_geglu(w.numpy(), b.numpy(), gpu)
     out = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device=gpu)
     call = ops.conv_gemm(a0=x.to(torch.bfloat16).to(gpu), w=wp, out=out, batch=1, h_in=M, w_in=1, c0=C, N=8 * C, bias=bp,
-                         act=ops.ACT_GEGLU)
+                         act=ops.ACT_GEGLU, tile_m=tile[0], tile_n=tile[1])
     run_calls(call)
-    close(out, ref, what="geglu")
+    close(out, ref, what=f"geglu {tile}")
 
 
 @pytest.mark.parametrize("case", [
@@ -230,6 +233,7 @@ def test_conv_gemm_geglu(gpu):
     dict(M=130, C=1280, tile=(64, 64, 14), mode="dense"),      # 20 partials per row (the maximum), 8-wave producer
     dict(M=256, C=320, tile=(64, 128, 24), mode="dense"),      # one slab per tile
     dict(M=200, C=320, tile=(128, 80, 0), mode="geglu", ctile=(128, 128, 0)),     # consumer tiles chosen explicitly
+    dict(M=300, C=1280, tile=(64, 64, 0), mode="geglu", ctile=(128, 160, 0)),     # the 16x16 level's GEGLU projection on the 128x160 tile
     dict(M=136, C=640, tile=(64, 64, 0), mode="qkv", ctile=(64, 128, 13)),
     # consumer on the row-panel kernel (conv_rowpanel.hip: tile_m = 3000 + rows per workgroup, tile_n = columns per
     # workgroup); `csame`: the same bits as the tile kernel

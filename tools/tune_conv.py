@@ -135,6 +135,8 @@ def tune_one(shape, iters=10):
                 continue
             if bn == 80 and (N % 80 or not allow_split):   # (the 'n' shapes include GEGLU, which pairs fragments)
                 continue
+            if bn == 160 and (N % 160 or N < 1280):
+                continue
         sks = [1]
         if allow_split and bm < 3000:
             # candidates from the PER-SAMPLE shape, so every batch of a layer is measured on the same set of slice counts
@@ -171,7 +173,7 @@ def numerics_class(shape, bm, bn, sk):
     """What of a configuration changes the order of the fp32 sums (see the module docstring)."""
     from minsdtf_amd import tuning
 
-    return tuning.numerics_class(shape[5], bm, bn, sk)
+    return tuning.numerics_class(shape[5], bm, bn, sk, ln_producer=bool(shape[8]))   # (shape[8] = allow_split: False for GEGLU / q|k|v)
 
 
 def pin_classes(shapes, all_results):
