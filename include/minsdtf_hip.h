@@ -300,8 +300,9 @@ int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream);
  *           the last step (x' = x0).  TCD sampler (scheduler.py:286-307): the gamma-sampling coefficients,
  *           plus x' += noise_coef[step] * step_noise[step][b][:] when step_noise != NULL
  *           (step_noise fp32 [steps][batch][n] = the per-step N(0,1) draws, noise_coef fp32 [steps]).
- *   The row used is coef[*step_ptr]; after the update the kernel increments *step_ptr when
- *   advance != 0.
+ *   The row used is coef[*step_ptr]; after the update *step_ptr is incremented when advance != 0:
+ *   advance = 1 by a second one-thread launch; advance = 2 inside the launch, by the workgroup that finishes last — then
+ *   step_ptr points at TWO ints {step, ticket}, ticket zero when first used and touched by nothing else.
  *   Inpainting (stable_diffusion.py:469-475), when inpaint_mask != NULL: after the sampler step
  *   latent = origin * (1 - mask) + latent * mask with origin = signal_rate[t] * inpaint_init +
  *   noise_rate[t] * inpaint_noise at the CURRENT timestep t (the reference re-noises the encoded

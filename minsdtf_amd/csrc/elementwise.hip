@@ -4,11 +4,12 @@
 // rescale_noise_cfg, :304-315) with Scheduler.step's deterministic branch
 // (scheduler.py:272-285,308-312) so the latent never leaves HBM between UNet calls.  The
 // reference does this in numpy: float32 for CFG / std, float64 for the sampler coefficients;
-// here everything is fp32 except the four per-sample moments, which accumulate in fp64.
+// here everything is fp32; the four per-sample moments are taken about a shift inside the data (fp32 per wave, fp64 across waves).
 #include "common.h"
 
 struct CfgArgs {
-    const float* eps; float* latent; const float* coef; const int32_t* step_ptr;
+    const float* eps; float* latent; const float* coef; int32_t* step_ptr;
+    int advance_in_kernel;   // the workgroup that finishes last advances *step_ptr itself (ticket at step_ptr[1])
     int batch, n, num_steps;
     float guidance, rescale;
     const float* ip_init; const float* ip_noise; const float* ip_mask;
@@ -22,7 +23,8 @@ template <int NPT>
 __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
     __shared__ double red[16][4];
     const int b = blockIdx.x, t = threadIdx.x;
-    int step = p.step_ptr ? *p.step_ptr : 0;
+    const int step_raw = p.step_ptr ? *p.step_ptr : 0;
+    int step = step_raw;
     if (step > p.num_steps - 1) step = p.num_steps - 1;
     if (step < 0) step = 0;
     const float sr = p.coef[step * 4 + 0], nr = p.coef[step * 4 + 1];
@@ -43,10 +45,17 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
     }
     float factor = 1.0f;
     if (cfg && p.rescale > 0.0f) {
-        double m4[4] = {0, 0, 0, 0};   // s_c, q_c, s_g, q_g
+        // Moments about a per-sample shift (the first element of each tensor): s = sum(x - x0), q = sum((x - x0)^2) in fp32
+        // per thread (<= 36 terms) and per wave (fixed-order DPP / row-swap tree, no LDS round trips), then the 16 wave sums
+        // in fp64.  The variance is shift-invariant, and about a shift inside the data's range the fp32 sums lose nothing
+        // that matters: (q - s^2/n)/n has no large-number cancellation.  (Was: fp64 per element and six 64-bit
+        // ds_bpermute steps per moment: 48 LDS round trips on the step's critical path.)
+        const float c0 = c[0], g0 = u[0] + p.guidance * (c[0] - u[0]);
+        float f4[4] = {0.f, 0.f, 0.f, 0.f};   // s_c, q_c, s_g, q_g (shifted)
         auto acc = [&](float cu, float cc) {
             const float gq = cu + p.guidance * (cc - cu);
-            m4[0] += cc; m4[1] += (double)cc * cc; m4[2] += gq; m4[3] += (double)gq * gq;
+            const float dc = cc - c0, dg = gq - g0;
+            f4[0] += dc; f4[1] += dc * dc; f4[2] += dg; f4[3] += dg * dg;
         };
         if (NPT > 0) {
 #pragma unroll
@@ -55,12 +64,12 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
         } else {
             for (int i = t; i < p.n; i += 1024) acc(u[i], c[i]);
         }
+        double m4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            for (int o = 32; o >= 1; o >>= 1) m4[q] += __shfl_xor(m4[q], o);
+        for (int q = 0; q < 4; ++q) f4[q] = wave_sum(f4[q]);
         if ((t & 63) == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[t >> 6][q] = m4[q];
+            for (int q = 0; q < 4; ++q) red[t >> 6][q] = (double)f4[q];
         }
         __syncthreads();
 #pragma unroll
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
             m4[q] = s;
         }
         const double n = (double)p.n;
-        const double mc = m4[0] / n, mg = m4[2] / n;
+        const double mc = m4[0] / n, mg = m4[2] / n;   // (means of the shifted values: the shift drops out of the variance)
         const double vc = fmax(m4[1] / n - mc * mc, 0.0), vg = fmax(m4[3] / n - mg * mg, 0.0);
         const float std_text = (float)sqrt(vc);
         const float std_cfg = (float)sqrt(vg) + 1e-5f;
@@ -95,6 +104,15 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
     } else {
         for (int i = t; i < p.n; i += 1024) update(i, u[i], c[i], lat[i]);
     }
+    if (p.advance_in_kernel && t == 0) {
+        // every workgroup read *step_ptr at its start and takes its ticket here, at its end: the one that draws the last
+        // ticket knows that all of them have read the step, so it may move it (and clears the tickets for the next launch)
+        const int ticket = __hip_atomic_fetch_add(p.step_ptr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == p.batch - 1) {
+            __hip_atomic_store(p.step_ptr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.step_ptr, step_raw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 __global__ void step_advance_kernel(int32_t* step_ptr) { *step_ptr = *step_ptr + 1; }
@@ -104,8 +122,10 @@ extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
     if (!q || !q->eps || !q->latent || !q->coef) MSD_FAIL(MSD_E_ARG, "cfg_step: null pointer");
     if (q->batch <= 0 || q->n <= 0 || q->num_steps <= 0) MSD_FAIL(MSD_E_ARG, "cfg_step: bad dims");
     if (q->advance && !q->step_ptr) MSD_FAIL(MSD_E_ARG, "cfg_step: advance needs step_ptr");
+    if (q->advance < 0 || q->advance > 2) MSD_FAIL(MSD_E_ARG, "cfg_step: advance takes 0, 1 or 2");
     CfgArgs a;
     a.eps = q->eps; a.latent = q->latent; a.coef = q->coef; a.step_ptr = q->step_ptr;
+    a.advance_in_kernel = q->advance == 2 ? 1 : 0;
     a.batch = q->batch; a.n = q->n; a.num_steps = q->num_steps; a.guidance = q->guidance; a.rescale = q->guidance_rescale;
     a.ip_init = q->inpaint_init; a.ip_noise = q->inpaint_noise; a.ip_mask = q->inpaint_mask;
     if (a.ip_mask && (!a.ip_init || !a.ip_noise)) MSD_FAIL(MSD_E_ARG, "cfg_step: inpaint_mask needs inpaint_init and inpaint_noise");
@@ -115,7 +135,7 @@ extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
     else if (q->n <= 36 * 1024) hipLaunchKernelGGL(cfg_step_kernel<36>, dim3(q->batch), dim3(1024), 0, stream, a);   // 96x96
     else hipLaunchKernelGGL(cfg_step_kernel<0>, dim3(q->batch), dim3(1024), 0, stream, a);
     MSD_CHECK_LAUNCH();
-    if (q->advance) {
+    if (q->advance == 1) {
         hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, stream, q->step_ptr);
         MSD_CHECK_LAUNCH();
     }

@@ -173,7 +173,7 @@ def cfg_step(*, eps, latent, coef, step_ptr, batch, n, num_steps, guidance, guid
     s.inpaint_init, s.inpaint_noise, s.inpaint_mask = _p(inpaint_init), _p(inpaint_noise), _p(inpaint_mask)
     s.step_noise, s.noise_coef = _p(step_noise), _p(noise_coef)
     s.batch, s.n, s.num_steps = batch, n, num_steps
-    s.guidance, s.guidance_rescale, s.advance = float(guidance), float(guidance_rescale), int(bool(advance))
+    s.guidance, s.guidance_rescale, s.advance = float(guidance), float(guidance_rescale), int(advance)   # 2: in-kernel ({step, ticket})
     return Call(lib.msd_cfg_step, (C.byref(s),), name, keep=s)
 
 

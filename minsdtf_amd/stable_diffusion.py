@@ -100,7 +100,9 @@ class DenoiseEngine:
         # ---- per-call preparation plan: contexts -> K/V^T, time-embedding tables, hint --------
         prep = engine.Plan(dev)
         e_u = engine.Emitter(prep, unet._W)
-        self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_ptr = torch.zeros(2, dtype=torch.int32, device=dev)   # {step index, ticket of msd_cfg_step's in-kernel advance}
+        self._sched_key = None       # schedule whose coefficient / time-embedding tables are on the device
+        self._step_init: Dict[int, torch.Tensor] = {}
         self.latent = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
         self.coef = torch.zeros(num_steps, 4, dtype=torch.float32, device=dev)
         self.temb_in = torch.zeros(num_steps, 320, dtype=torch.float32, device=dev)
@@ -183,7 +185,7 @@ class DenoiseEngine:
         self.step_noise = torch.zeros(num_steps, B, n, dtype=torch.float32, device=dev) if tcd else None
         self.noise_coef = torch.zeros(num_steps, dtype=torch.float32, device=dev) if tcd else None
         tail.rec(ops.cfg_step, eps=self.eps, latent=self.latent, coef=self.coef, step_ptr=self.step_ptr, batch=B, n=n,
-                 num_steps=num_steps, guidance=guidance, guidance_rescale=guidance_rescale, advance=True,
+                 num_steps=num_steps, guidance=guidance, guidance_rescale=guidance_rescale, advance=2,
                  inpaint_init=ip.get("init"), inpaint_noise=ip.get("noise"), inpaint_mask=ip.get("mask"),
                  step_noise=self.step_noise, noise_coef=self.noise_coef)
         if self.cn_plan is not None:
@@ -324,10 +326,18 @@ class DenoiseEngine:
         for tag, arr in contexts.items():
             self.ctx_in[tag].copy_(_f32_tensor(arr))
         self.latent.copy_(_f32_tensor(noise))
-        self.coef.copy_(torch.from_numpy(scheduler.coefficient_table()))
-        temb = np.concatenate([get_timestep_embedding(int(t), 1) for t in scheduler.timesteps], axis=0)
-        self.temb_in.copy_(torch.from_numpy(np.ascontiguousarray(temb, dtype=np.float32)))
-        self.step_ptr.fill_(int(start_index))
+        # the schedule's tables: uploaded when the schedule changes, not per call (pageable host -> device copies make the
+        # host wait for the stream, which keeps it from queueing this job behind the previous one's last kernels)
+        sched_key = (tuple(int(t) for t in scheduler.timesteps), bool(getattr(scheduler, "active_tcd", False)))
+        if self._sched_key != sched_key:
+            self.coef.copy_(torch.from_numpy(scheduler.coefficient_table()))
+            temb = np.concatenate([get_timestep_embedding(int(t), 1) for t in scheduler.timesteps], axis=0)
+            self.temb_in.copy_(torch.from_numpy(np.ascontiguousarray(temb, dtype=np.float32)))
+            self._sched_key = sched_key
+        init = self._step_init.get(int(start_index))
+        if init is None:
+            init = self._step_init[int(start_index)] = torch.tensor([int(start_index), 0], dtype=torch.int32, device=self.step_ptr.device)
+        self.step_ptr.copy_(init)   # {first step, ticket 0}: device -> device
         if self.step_noise is not None:
             # scheduler.py:301 draws np.random.randn(*latent.shape) once per executed step except the last
             self.noise_coef.copy_(torch.from_numpy(scheduler.noise_coefficients()))

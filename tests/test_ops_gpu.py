@@ -745,8 +745,10 @@ def test_softmax_rows(gpu):
 
 
 @pytest.mark.parametrize("guidance,rescale", [(7.5, 0.7), (7.5, 0.0), (0.0, 0.0)])
-def test_cfg_step(gpu, guidance, rescale):
-    """CFG + rescale + sampler step against the oracle restatement, for every step of a 5-step run."""
+@pytest.mark.parametrize("advance", [2, 1])   # the step counter moved inside the launch (by the last workgroup), or by a second launch
+def test_cfg_step(gpu, guidance, rescale, advance):
+    """CFG + rescale + sampler step against the oracle restatement, for every step of a 5-step run (batch 3: three
+    workgroups race for the last ticket of the in-kernel advance)."""
     from minsdtf_amd import ops
     from minsdtf_amd.scheduler import Scheduler
     from oracle import sd_oracle as O
@@ -760,7 +762,7 @@ def test_cfg_step(gpu, guidance, rescale):
     osch.set_timesteps(steps)
     lat = rng.standard_normal((B, 8, 8, 4)).astype(np.float32)
     lat_d = torch.from_numpy(lat.reshape(B, n).copy()).to(gpu)
-    step = torch.zeros(1, dtype=torch.int32, device=gpu)
+    step = torch.zeros(2, dtype=torch.int32, device=gpu)   # {step, ticket}
     ref = lat.astype(np.float64)
     for i, t in enumerate(osch.timesteps):
         u = rng.standard_normal((B, 8, 8, 4)).astype(np.float32)
@@ -775,11 +777,11 @@ def test_cfg_step(gpu, guidance, rescale):
             eps_d = torch.from_numpy(c.reshape(B, n)).to(gpu)
         ref = osch.step(e, int(t), ref)
         run_calls(ops.cfg_step(eps=eps_d, latent=lat_d, coef=coef, step_ptr=step, batch=B, n=n, num_steps=steps,
-                               guidance=guidance, guidance_rescale=rescale, advance=True))
+                               guidance=guidance, guidance_rescale=rescale, advance=advance))
         got = lat_d.cpu().numpy().reshape(B, 8, 8, 4)
         # fp32 device math vs the reference's float64 numpy path
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max(), err_msg=f"step {i}")
-        assert int(step.item()) == i + 1
+        assert step.tolist() == [i + 1, 0]
 
 
 def test_elementwise(gpu):
