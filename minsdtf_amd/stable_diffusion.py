@@ -97,8 +97,11 @@ class DenoiseEngine:
         self.passes = passes
         self.has_control = control_net is not None
 
-        # ---- per-call preparation plan: contexts -> K/V^T, time-embedding tables, hint --------
+        # ---- preparation plans: per SCHEDULE the time-embedding tables (timestep -> MLP -> every ResBlock's projection: they do
+        #      not depend on the prompt, so they run when the schedule changes, not per call); per CALL contexts -> K/V^T, hint
+        prep_t = engine.Plan(dev)
         prep = engine.Plan(dev)
+        e_t = engine.Emitter(prep_t, unet._W)
         e_u = engine.Emitter(prep, unet._W)
         self.step_ptr = torch.zeros(2, dtype=torch.int32, device=dev)   # {step index, ticket of msd_cfg_step's in-kernel advance}
         self._sched_key = None       # schedule whose coefficient / time-embedding tables are on the device
@@ -107,8 +110,8 @@ class DenoiseEngine:
         self.coef = torch.zeros(num_steps, 4, dtype=torch.float32, device=dev)
         self.temb_in = torch.zeros(num_steps, 320, dtype=torch.float32, device=dev)
         total_u = sum(c for _, c in engine.resblock_names(False))
-        table_u = prep.alloc(num_steps * total_u * 4)
-        engine.emit_time_embedding(e_u, self.temb_in, num_steps, table_u, encoder_only=False)
+        table_u = prep_t.alloc(num_steps * total_u * 4)
+        engine.emit_time_embedding(e_t, self.temb_in, num_steps, table_u, encoder_only=False)
         self.ctx_in: Dict[str, torch.Tensor] = {}
         ctx_kv_u, ctx_kv_c = {}, {}
         e_c = None
@@ -118,8 +121,8 @@ class DenoiseEngine:
             hint_net._require_weights()
             e_c = engine.Emitter(prep, control_net._W)
             total_c = sum(c for _, c in engine.resblock_names(True))
-            table_c = prep.alloc(num_steps * total_c * 4)
-            engine.emit_time_embedding(e_c, self.temb_in, num_steps, table_c, encoder_only=True)
+            table_c = prep_t.alloc(num_steps * total_c * 4)
+            engine.emit_time_embedding(engine.Emitter(prep_t, control_net._W), self.temb_in, num_steps, table_c, encoder_only=True)
         for (_row0, nb, t, tag) in passes:
             st = torch.zeros(nb, t, 768, dtype=torch.float32, device=dev)
             self.ctx_in[tag] = st
@@ -137,8 +140,9 @@ class DenoiseEngine:
             e_h = engine.Emitter(prep, hint_net._W)
             hint_act = prep.act(nb_max, h, w, 320)
             engine.emit_hintnet(e_h, self.hint_img, B, 8 * h, 8 * w, hint_act, copies=nb_max // B)
+        prep_t.finalize()
         prep.finalize()
-        self.prep = prep
+        self.prep, self.prep_t = prep, prep_t
 
         # ---- per-step plans: one per stream (`branches`) + the sampler step (`tail`) ------------
         n = h * w * 4
@@ -333,6 +337,7 @@ class DenoiseEngine:
             self.coef.copy_(torch.from_numpy(scheduler.coefficient_table()))
             temb = np.concatenate([get_timestep_embedding(int(t), 1) for t in scheduler.timesteps], axis=0)
             self.temb_in.copy_(torch.from_numpy(np.ascontiguousarray(temb, dtype=np.float32)))
+            self.prep_t.run(torch.cuda.current_stream().cuda_stream)
             self._sched_key = sched_key
         init = self._step_init.get(int(start_index))
         if init is None:
