@@ -236,7 +236,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
 #endif
 }
 
-// split-K: sum the fp32 slabs in slice order, then the same epilogue (plain mode only)
+// split-K: sum the fp32 slabs in slice order, then the same epilogue (plain mode only).
+// SL = the slice count as a compile-time constant for the counts the tuner uses (every slab load in flight at once, none
+// redundant: the generic form keeps 8 clamped loads in flight, i.e. issues 8 loads for 3 slices); SL = 0: any count.
+template <int SL>
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, int slices, uint32_t mg_nq) {
     const int nq = p.N >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;   // (M * N / 4 < 2^31: checked on the host)
@@ -244,20 +247,39 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, in
     const int m = udiv_magic(idx, nq, mg_nq);         // (was a 64-bit division by a runtime value: ~100 instructions)
     const int n = (idx - m * nq) * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    // 8 slab loads in flight per thread (a one-load-per-iteration loop pays a full memory round trip per slice:
-    // 6 us for 12 slices of a 128 x 1280 layer); the adds keep the slice order, so the result is unchanged
     const float* src = p.ws + (size_t)m * p.N + n;
     const size_t zs = (size_t)p.M * p.N;
-    for (int z0 = 0; z0 < slices; z0 += 8) {
-        float4 t[8];
+    if constexpr (SL > 0) {
+        float4 t[SL];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)min(z0 + u, slices - 1) * zs);
+        for (int u = 0; u < SL; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)u * zs);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (z0 + u < slices) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
+        for (int u = 0; u < SL; ++u) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }   // slice order
+    } else {
+        // 8 slab loads in flight per thread (a one-load-per-iteration loop pays a full memory round trip per slice:
+        // 6 us for 12 slices of a 128 x 1280 layer); the adds keep the slice order, so the result is unchanged
+        for (int z0 = 0; z0 < slices; z0 += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)min(z0 + u, slices - 1) * zs);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (z0 + u < slices) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
+        }
     }
     const int step = p.step_ptr ? *p.step_ptr : 0;
     cg_store4(p, m, udiv_magic(m, p.hw_out, p.mg_hw), n, step, v);
+}
+static void launch_finalize(const CGArgs& a, int slices, hipStream_t stream) {
+    const long long quads = (long long)a.M * (a.N / 4);
+    const dim3 grid((unsigned)((quads + 255) / 256));
+    const uint32_t mg = udiv_magic_of(a.N / 4);
+    switch (slices) {
+#define F(SL) case SL: hipLaunchKernelGGL(splitk_finalize_kernel<SL>, grid, dim3(256), 0, stream, a, slices, mg); break;
+        F(2) F(3) F(4) F(6) F(8) F(12)
+#undef F
+        default: hipLaunchKernelGGL(splitk_finalize_kernel<0>, grid, dim3(256), 0, stream, a, slices, mg); break;
+    }
 }
 
 // ---- tile configurations of the LDS-DMA kernel ------------------------------------------------
@@ -501,8 +523,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
         if (slices > 1) {
-            const long long quads = (long long)a.M * (a.N / 4);
-            hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices, udiv_magic_of(a.N / 4));
+            launch_finalize(a, slices, stream);
             MSD_CHECK_LAUNCH();
         }
         return MSD_OK;
@@ -554,8 +575,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     }
     MSD_CHECK_LAUNCH();
     if (slices > 1) {
-        const long long quads = (long long)a.M * (a.N / 4);
-        hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, slices, udiv_magic_of(a.N / 4));
+        launch_finalize(a, slices, stream);
         MSD_CHECK_LAUNCH();
     }
     return MSD_OK;
