@@ -115,6 +115,21 @@ def test_c3_batch4_512(gpu, unet512, nsteps):
     assert min(per) >= PSNR_MIN
 
 
+@pytest.mark.parametrize("B", [3, 5])
+def test_unmeasured_batch_at_512(gpu, unet512, B):
+    """Batches the tuning table was not measured at (3 and 5 images = fused batches 6 and 10) at the REAL layer shapes: every
+    layer takes the entry of its nearest measured batch (tuning.lookup) — all of them must be launchable there, and because
+    every entry of a layer is in the layer's one numerics class, a sample's bits are those of the sample run alone."""
+    ctx, unc, noise = _inputs(B, 64)
+    sd = _pipeline(gpu, 512, unet512)
+    kw = dict(num_steps=2, unconditional_guidance_scale=7.5, guidance_rescale=0.7, return_latent=True)
+    both = sd.generate_image(ctx, negative_prompt=unc, batch_size=B, diffusion_noise=noise, **kw)
+    assert both.shape == (B, 64, 64, 4) and np.isfinite(both).all()
+    for i in (0, B - 1):
+        one = sd.generate_image(ctx[i], negative_prompt=unc[i], batch_size=1, diffusion_noise=noise[i], **kw)
+        np.testing.assert_array_equal(both[i:i + 1], one)
+
+
 @pytest.mark.parametrize("nsteps", [2, 8, 50])   # 50 = the configuration's own chain length (error growth along the chain)
 def test_c4_768(gpu, unet512, decoder, nsteps):
     """C4 shape: 768x768 -> latent 96x96 (S = 9216 at the top level, 2304 / 576 / 144 below; 96x96 = 9216-token VAE
