@@ -97,6 +97,35 @@ def main():
         print(f"   exit time after first entry          {pct(t[:, 4] - t0)}")
         print(f"   kernel span {us(t[:, 4].max() - t0):.2f} us; per K tile in the loop {us(np.median(t[:, 3] - t[:, 2])) / max(1, nk - 1):.3f} us",
               flush=True)
+        # the same launch back to back on the stream (dependent by stream order, weights rotating): wall time per launch minus
+        # the span above = what a launch boundary + dispatch ramp costs around this kernel
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record(st)
+        for _ in range(reps):
+            for c in calls:
+                c(st.cuda_stream)
+        e1.record(st)
+        torch.cuda.synchronize()
+        per = e0.elapsed_time(e1) * 1e3 / (reps * len(calls))
+        g = torch.cuda.CUDAGraph()
+        s2 = torch.cuda.Stream()
+        s2.wait_stream(st)
+        with torch.cuda.stream(s2):
+            with torch.cuda.graph(g, stream=s2):
+                for _ in range(4):
+                    for c in calls:
+                        c(torch.cuda.current_stream().cuda_stream)
+        st.wait_stream(s2)
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record(st)
+        for _ in range(5):
+            g.replay()
+        e1.record(st)
+        torch.cuda.synchronize()
+        perg = e0.elapsed_time(e1) * 1e3 / (5 * 4 * len(calls))
+        print(f"   back to back: {per:.2f} us per launch eager, {perg:.2f} us per launch in a replayed graph", flush=True)
 
 
 if __name__ == "__main__":
