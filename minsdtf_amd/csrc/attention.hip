@@ -20,6 +20,7 @@
 // (msd_conv_gemm split mode), so no transposing loads anywhere.
 // head_dim 40 / 80 are zero-padded to 64 / 96 in the QK^T k-dimension only (LDS pad columns stay 0).
 #include "common.h"
+#include <type_traits>
 
 struct AArgs {
     const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* out;
@@ -427,8 +428,50 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 // NW = waves per workgroup (4: 128 queries; 2: 64 queries, for launches whose 128-query grid leaves CUs idle).
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// In-kernel phase timeline of attention32_kernel (tools/attn_stamps.py; only in the `make stamps` library): wave 0 of every
+// workgroup sums, over its tiles, the shader-clock time between fixed points of the tile loop.  Each stamp is tied to a value
+// the phase before it produced (so it cannot move above that phase's last instruction) and is a compiler memory barrier.
+#ifdef MSD_STAMPS
+#ifndef MSD_ASTAMP_MASK
+#define MSD_ASTAMP_MASK 0xFF
+#endif
+#define MSD_ASTAMP_WAVES 1
+static __device__ unsigned long long g_astamps[16 * 4096];
+extern "C" int msd_debug_stamps_attn(unsigned long long* host_out, int count) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_astamps), sizeof(unsigned long long) * (size_t)count);
+}
+// (s_memtime returns through the scalar data cache: the stamps of a tile are only waited for — lgkmcnt — at the tile's end,
+// so that a stamp does not drain the wave's LDS queue in the middle of the code it measures)
+#define ASTAMP(i, x)                                                                                   \
+    do {                                                                                               \
+        if ((MSD_ASTAMP_MASK >> (i)) & 1) asm volatile("s_memtime %0" : "=s"(st_t[i]), "+v"(x) : : "memory"); \
+    } while (0)
+// ORDER: the stamps of one tile in program order, as a hex string of digits, e.g. 0x012345 (most significant first)
+#define ASTAMP_END(ORDER, N)                                                                           \
+    do {                                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(st_t[0]), "+s"(st_t[1]), "+s"(st_t[2]), "+s"(st_t[3]), "+s"(st_t[4]), "+s"(st_t[5]), "+s"(st_t[6]), "+s"(st_t[7]) : : "memory"); \
+        _Pragma("unroll") for (int k_ = (N) - 1; k_ >= 0; --k_) {                                      \
+            const int i_ = ((ORDER) >> (4 * k_)) & 15;                                                 \
+            if ((MSD_ASTAMP_MASK >> i_) & 1) { st_acc[i_] += st_t[i_] - st_prev; st_prev = st_t[i_]; }  \
+        }                                                                                              \
+    } while (0)
+#else
+#define ASTAMP(i, x)
+#define ASTAMP_END(ORDER, N)
+#endif
+
+// loader waves of the software-pipelined form (NBUF 4) beside its NW compute waves.  One wave gets an LDS-DMA instruction out
+// every 75-85 cycles whatever else it does (its priority, scalar lane masks instead of branches: no change), waves issue in
+// parallel; a tile is 13 DMAs at d = 40 and 23 at d = 80, and the compute waves are through one in 1000-1600 cycles.
+__host__ __device__ constexpr int attn32_loaders(int nbuf, int nw, int d) { return nbuf == 4 ? ((nw >= 8 || d > 64) ? 2 : 1) : 0; }
+
 template <int D, int NBUF, int NW, bool PRESC>
-__global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
+__global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void attention32_kernel(const AArgs p) {
+    constexpr bool SWP = NBUF == 4;          // software-pipelined tile loop (below)
+    // SWP, prescaled q, head size with a padded k-step (d = 40 -> 48): the reference maximum rides in the padding — channel
+    // D of every K row is 1, channel D of the query holds -m_ref (a bf16 value; any reference works as long as every use
+    // agrees) — instead of in 16 accumulator-start registers
+    constexpr bool PADREF = SWP && PRESC && (D % 16 == 8);
     constexpr bool PIPE = NBUF == 2;
     constexpr int NT = 64 * NW, QT = 32 * NW;
     constexpr int KS = (D + 15) / 16;        // 16-channel k-steps of QK^T
@@ -450,6 +493,26 @@ __global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
     const int b = udiv_magic(bh, p.heads, p.mg_heads), hd = bh - b * p.heads;
     const int q0 = (wi - bh * qtiles) * QT + wave * 32;
 
+    if constexpr (SWP) {
+        // The DMAs write every data slot of a tile image before it is read; only what they leave alone needs a value: the pad
+        // slots of the K rows (zeros; PADREF: 1.0 in channel D) and the V^T rows >= D (row D: ones, the denominator's row).
+        constexpr int KP = KROW / 16 - DCH;           // pad slots per K row (the last one is never read)
+        constexpr int VR = DB * 32 - D, VS = VROW / 16;
+        constexpr int PER = 64 * KP + VR * VS;        // 16-byte pieces per ring slot
+        const int nthreads = 64 * (NW + attn32_loaders(NBUF, NW, D));
+        for (int idx = tid; idx < NBUF * PER; idx += nthreads) {
+            const int bufi = idx / PER, r = idx - bufi * PER;
+            char* base = smem + bufi * BUF_BYTES;
+            if (r < 64 * KP) {
+                const int row = r / KP, sl = r - row * KP;
+                *reinterpret_cast<uint4*>(base + row * KROW + (DCH + sl) * 16) = make_uint4((PADREF && sl == 0) ? 0x3F80u : 0u, 0, 0, 0);
+            } else {
+                const int rr = r - 64 * KP, row = rr / VS, sl = rr - row * VS;
+                const uint32_t v = (ONES_ROW && row == 0) ? 0x3F803F80u : 0u;
+                *reinterpret_cast<uint4*>(base + 64 * KROW + (D + row) * VROW + sl * 16) = make_uint4(v, v, v, v);
+            }
+        }
+    } else {
     for (int off = tid * 16; off < NBUF * BUF_BYTES; off += NT * 16)
         *reinterpret_cast<uint4*>(smem + off) = make_uint4(0, 0, 0, 0);
     if (ONES_ROW) {
@@ -459,6 +522,7 @@ __global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
             for (int bufi = 0; bufi < NBUF; ++bufi)
                 *reinterpret_cast<uint2*>(smem + bufi * BUF_BYTES + 64 * KROW + D * VROW + tid * 8) = make_uint2(0x3F803F80u, 0x3F803F80u);
         }
+    }
     }
 
     f32x16 oacc[DB];
@@ -474,7 +538,6 @@ __global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
     const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + hd * D;
     const bf16_t* vbase = p.vt + ((size_t)b * p.heads + hd) * D * p.vt_ld;
     const int ntiles = (p.t + 63) / 64;
-
     constexpr int KCH = (64 * DCH + NT - 1) / NT, VCH = (D * 8 + NT - 1) / NT;
     uint4 rk[KCH], rv[VCH];
     const bf16_t* kptr[KCH];
@@ -567,12 +630,311 @@ __global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // retire the Q loads before the tile loop (see above)
+#ifdef MSD_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev, st_first;
+    const unsigned long long st_wall0 = wall_clock64();
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) : : "memory");
+    st_first = st_prev;
+#endif
 
+    if constexpr (SWP) {
+    // ---- software-pipelined loop on LDS-DMA staging.  The plain loop below runs QK^T(t) -> maximum -> exponentials -> PV(t)
+    // as one dependent chain per tile and stages the next tile through registers.  tools/attn_stamps.py on it (S = 4096,
+    // d = 40, two waves per SIMD): 2270 cycles per wave and tile against 448 cycles of matrix pipe; ~450 of them go to ISSUING
+    // the four ds_write of a tile (all waves of the CU store right after their barrier; the VGPR -> LDS path backs up) and
+    // ~700 to compiler-placed vmcnt(0) waits between the predicated blocks of the staging code.  Here
+    //   * K and V^T tiles go global -> LDS by DMA (global_load_lds_dwordx4: no staging registers, no ds_write, nothing
+    //     for the compiler's counter model to see); the 1 KiB pieces of a tile image are dealt round-robin to the waves,
+    //     lanes that fall on a row's pad slot are switched off (the pad keeps the zeros of the initial fill);
+    //   * a LOADER wave (the workgroup's last) issues them into a ring of four slots, two tiles ahead of the products;
+    //   * the products of tile t + 1 are ISSUED before the softmax of tile t (two score register sets, swapped by
+    //     unrolling twice): the matrix pipe works on S^T(t + 1) while the VALU takes the maximum of S^T(t);
+    //   * the K rows are fed to the MFMA in the order that makes a lane's 8 score registers of a PV step 8 CONSECUTIVE keys
+    //     (row index bits 2 and 3 swapped: register i of lane (c, h) is key (i & 7) + 8 h + 16 (i >> 3) of the 32-key block),
+    //     so the V^T image is the tensor's own layout and DMA can write it;
+    //   * the tiles that need masks (ragged tail, causal) run a second instance of the step: the common one is three
+    //     basic blocks, [QK^T(t + 1) + maximum(t)] [rare rescale] [exponentials(t) + PV(t)].
+    // A ragged last tile stages its V^T piece through registers (keys >= t are padding of unspecified content and must
+    // be stored as 0); its K rows >= t read the last valid row (finite; their scores are masked).
+    constexpr int KSL = KROW / 16, VSL = VROW / 16;       // 16-byte slots per image row (data + pad)
+    constexpr int KI = KSL, VI = (D * VSL + 63) / 64;     // DMA wave-instructions (1 KiB pieces) per K / V^T tile image
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // the initial fill of the ring is in place before any DMA may land on it
+    if (wave_u >= NW) {
+        // ---- the loader waves: nothing but the staging of every tile.  (Issued by the compute waves themselves, right after
+        // their barrier, the 13 DMAs of a d = 40 tile kept each of them 600 cycles at the issue port, and that is time
+        // their MFMAs do not get.)  Loader l takes the pieces l, l + NL, ... of each image.
+        constexpr int NL = attn32_loaders(NBUF, NW, D);
+        constexpr int NKL = (KI + NL - 1) / NL, NVL = (VI + NL - 1) / NL;
+        const int ldr = wave_u - NW;
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)(ldr * 1024);
+        uint32_t kvo[NKL], vvo[NVL];   // per-lane source byte offsets of the pieces
+        uint64_t kon[NKL], von[NVL];   // ... and their lane masks (off: pad slots, lanes past the image)
+#pragma unroll
+        for (int n = 0; n < NKL; ++n) {
+            const int q = ldr + NL * n;
+            const int sidx = 64 * q + lane, row = sidx / KSL, ch = sidx - row * KSL;
+            const bool on = q < KI && ch < DCH;
+            kvo[n] = on ? (uint32_t)(row * p.k_ld * 2 + ch * 16) : 0u;
+            kon[n] = __builtin_amdgcn_ballot_w64(on);
+        }
+#pragma unroll
+        for (int n = 0; n < NVL; ++n) {
+            const int q = ldr + NL * n;
+            const int sidx = 64 * q + lane, row = sidx / VSL, ch = sidx - row * VSL;
+            const bool on = q < VI && ch < 8 && row < D;
+            vvo[n] = on ? (uint32_t)(row * p.vt_ld * 2 + ch * 16) : 0u;
+            von[n] = __builtin_amdgcn_ballot_w64(on);
+        }
+        const size_t kstep = (size_t)p.k_ld * 128;          // bytes per 64-key tile
+        const char* kb_next = reinterpret_cast<const char*>(kbase);   // source of the next tile to stage
+        const char* vb_next = reinterpret_cast<const char*>(vbase);
+        int t0_next = 0;
+        auto stage = [&](int slot) {   // the next tile -> ring slot; returns with the DMAs in flight
+            const uint32_t dst0 = lds0 + (uint32_t)(slot * BUF_BYTES);
+            if (t0_next + 64 <= p.t) {
+#pragma unroll
+                for (int n = 0; n < NKL; ++n)
+                    if (kon[n]) dma16sm(kb_next, kvo[n], dst0 + (uint32_t)(n * NL * 1024), kon[n]);
+#pragma unroll
+                for (int n = 0; n < NVL; ++n)
+                    if (von[n]) dma16sm(vb_next, vvo[n], dst0 + (uint32_t)(64 * KROW + n * NL * 1024), von[n]);
+            } else {
+                const int t0 = t0_next;
+                const uint32_t klim = (uint32_t)(((p.t - 1 - t0) * p.k_ld + (D - 8)) * 2);
+#pragma unroll
+                for (int n = 0; n < NKL; ++n)
+                    if (kon[n]) dma16sm(kb_next, min(kvo[n], klim), dst0 + (uint32_t)(n * NL * 1024), kon[n]);
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+                char* dV = smem + slot * BUF_BYTES + 64 * KROW;
+                const uint32_t clim = (uint32_t)(((p.t - 1 - t0) >> 3) * 16);
+                for (int idx = ldr * 64 + lane; idx < D * 8; idx += 64 * NL) {
+                    const int d = idx >> 3, ch = idx & 7;
+                    u32x4_t v = *reinterpret_cast<const u32x4_t*>(vb_next + ((size_t)d * p.vt_ld * 2 + min((uint32_t)(ch * 16), clim)));
+                    const int valid = p.t - (t0 + ch * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (2 * j >= valid) v[j] = 0;
+                        else if (2 * j + 1 >= valid) v[j] &= 0xFFFFu;
+                    }
+                    *reinterpret_cast<u32x4_t*>(dV + d * VROW + ch * 16) = v;
+                }
+                wait_vmcnt<0>();
+            }
+            kb_next += kstep;
+            vb_next += 128;
+            t0_next += 64;
+        };
+        // Ring of 4 slots, two tiles ahead: tile + 3 is issued right after barrier `tile` (its slot held tile - 1, whose last
+        // reader passed that barrier), tile + 1 has to be in LDS by barrier `tile`: at that point only the pieces of tile + 2
+        // may still be in flight — a counted wait, exact because every piece of a full tile is one DMA instruction of this
+        // wave (a ragged tile is the last one and is waited for in full when it is staged).
+        auto wait_newest = [&]() {   // everything but the pieces of the tile staged last (a full one) has landed
+            if (NL == 1 || ldr == 0) wait_vmcnt<(KI + NL - 1) / NL + (VI + NL - 1) / NL>();
+            else wait_vmcnt<KI / NL + VI / NL>();   // (NL == 2: loader 1 has the odd pieces)
+        };
+        static_assert(NL <= 2, "wait_newest counts the pieces of loader 0 and loader 1");
+        stage(0);
+        if (ntiles > 1) stage(1);
+        if (ntiles > 2) stage(2);
+        if (ntiles > 2) wait_newest(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#ifdef MSD_STAMPS
+        unsigned long long lt[4] = {0, 0, 0, 0}, la[3] = {0, 0, 0};
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lt[0]) : : "memory");
+#define LSTAMP(i) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lt[(i) + 1]) : : "memory"); la[i] += lt[(i) + 1] - lt[i]; } while (0)
+#else
+#define LSTAMP(i)
+#endif
+        for (int tile = 0; tile < ntiles; ++tile) {
+            if (tile + 2 < ntiles) wait_newest(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            LSTAMP(0);
+            __builtin_amdgcn_s_barrier();
+            LSTAMP(1);
+            if (tile + 3 < ntiles) stage((tile + 3) & 3);
+            LSTAMP(2);
+#ifdef MSD_STAMPS
+            lt[0] = lt[3];
+#endif
+        }
+#ifdef MSD_STAMPS
+        if (lane == 0 && ldr == 0) {
+            unsigned long long* dst = g_astamps + (size_t)(blockIdx.x & 2047) * 16 + 12;
+            dst[0] = la[0]; dst[1] = la[1]; dst[2] = la[2];
+        }
+#endif
+        return;
+    }
+    const int cperm = (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1);   // K row this lane feeds to MFMA row c
+    auto qk = [&](f32x16 (&sc)[2], const char* sK) {
+        bf16x8 kfrag[2][KS];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                kfrag[kb][ks] = *reinterpret_cast<const bf16x8*>(sK + (kb * 32 + cperm) * KROW + ks * 32 + h * 16);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {   // (the two blocks' chains alternate: no MFMA waits for the one before it)
+                if (ks == 0) {
+                    if (PRESC && !PADREF) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag[kb][0], qf[0], negm, 0, 0, 0);
+                    else {
+                        f32x16 z;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag[kb][0], qf[0], z, 0, 0, 0);
+                    }
+                } else {
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag[kb][ks], qf[ks], sc[kb], 0, 0, 0);
+                }
+            }
+    };
+    // one tile: `cur` holds S^T(tile) (issued one step earlier), `nxt` receives S^T(tile + 1); slot = ring slot of `tile`
+    auto step = [&](auto masked_, f32x16 (&cur)[2], f32x16 (&nxt)[2], int tile, int slot) {
+        constexpr bool MASKED = decltype(masked_)::value;
+        const int t0 = tile * 64;
+        const int slot1 = (slot + 1) & 3;
+        __builtin_amdgcn_s_barrier();          // tile + 1 is in LDS (the loader waited for it); everybody is done with tile - 1
+        ASTAMP(0, mref);
+        qk(nxt, smem + slot1 * BUF_BYTES);   // (past the last tile: a slot of finite leftovers, the result is never used)
+        if (MASKED) {
+            if (t0 + 64 > p.t) {
+                int key0 = t0 + 8 * h;
+                asm volatile("" : "+v"(key0));
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (key0 + kb * 32 + (i & 7) + 16 * (i >> 3) >= p.t) cur[kb][i] = -1e30f;
+            }
+            if (p.causal) {
+                int key0 = t0 + 8 * h;
+                asm volatile("" : "+v"(key0));
+                const int qi = q0 + c;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (key0 + kb * 32 + (i & 7) + 16 * (i >> 3) > qi) cur[kb][i] = -1e30f;
+            }
+        }
+        // ---- lane-local maximum; the row maximum and the (rare) move of the reference only when some lane asks for it
+        float m = fmaxf(cur[0][0], cur[0][1]);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) m = fmaxf(fmaxf(m, cur[0][i]), cur[0][i + 1]);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) m = fmaxf(fmaxf(m, cur[1][i]), cur[1][i + 1]);
+        ASTAMP(2, m);
+        const bool ask = tile == 0 || (PRESC ? (m > ATTN_THR) : ((m - mref) * p.sl2 > ATTN_THR));
+        if (__builtin_amdgcn_ballot_w64(ask) != 0) {
+            const uint32_t u = __float_as_uint(m);
+            auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            float mx;
+            asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(sw[0]), "v"(sw[1]));   // both half-waves: the query's maximum over the tile
+            const bool need = tile == 0 || (PRESC ? (mx > ATTN_THR) : ((mx - mref) * p.sl2 > ATTN_THR));
+            float alpha;
+            if (PADREF) {
+                // the new reference is a bf16 value; the move actually applied is the difference of the two references
+                const uint32_t rb = pack_bf2(mref + (need ? mx : 0.f), 0.f) & 0xFFFFu;
+                const float rnew = __uint_as_float(rb << 16), delta = rnew - mref;
+                alpha = __builtin_amdgcn_exp2f(-delta);
+                mref = rnew;
+                if (h == 1) {   // channel D = k-slot 8 of the last k-step: element 0 of the upper half-wave's fragment
+                    union { bf16x8 v; uint32_t u[4]; } qq;
+                    qq.v = qf[KS - 1];
+                    qq.u[0] = (qq.u[0] & 0xFFFF0000u) | (rb ^ 0x8000u);
+                    qf[KS - 1] = qq.v;
+                }
+                // (S^T(tile + 1) is already under way against the old reference: it moves too)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { cur[0][i] -= delta; cur[1][i] -= delta; nxt[0][i] -= delta; nxt[1][i] -= delta; }
+            } else if (PRESC) {
+                const float delta = need ? mx : 0.f;
+                alpha = __builtin_amdgcn_exp2f(-delta);
+                mref += delta;
+                // (S^T(tile + 1) is already under way against the old reference: it moves too)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    negm[i] = -mref; cur[0][i] -= delta; cur[1][i] -= delta; nxt[0][i] -= delta; nxt[1][i] -= delta;
+                }
+            } else {
+                const float mnew = need ? mx : mref;
+                alpha = __builtin_amdgcn_exp2f((mref - mnew) * p.sl2);
+                mref = mnew;
+            }
+            if (tile != 0) {
+                lrun *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+            }
+        }
+        // ---- exponentials in place
+        {
+            const float nm = -mref * p.sl2;
+            float ls = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pv = __builtin_amdgcn_exp2f(PRESC ? cur[kb][i] : fmaf(cur[kb][i], p.sl2, nm));
+                    cur[kb][i] = pv;
+                    if (!ONES_ROW) ls += pv;
+                }
+            if (!ONES_ROW) lrun += ls;
+        }
+        ASTAMP(3, cur[1][15]);
+        // ---- O^T += V^T P^T, 16 keys per step: registers 8 (st & 1) .. + 7 of block st >> 1 are keys 16 st + 8 h + 0..7
+        const char* sV = smem + slot * BUF_BYTES + 64 * KROW;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int kb = st >> 1, i0 = (st & 1) * 8;
+            union { bf16x8 v; uint32_t u[4]; } pk;
+            pk.u[0] = pack_bf2(cur[kb][i0 + 0], cur[kb][i0 + 1]);
+            pk.u[1] = pack_bf2(cur[kb][i0 + 2], cur[kb][i0 + 3]);
+            pk.u[2] = pack_bf2(cur[kb][i0 + 4], cur[kb][i0 + 5]);
+            pk.u[3] = pack_bf2(cur[kb][i0 + 6], cur[kb][i0 + 7]);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (db * 32 + c) * VROW + st * 32 + h * 16);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pk.v, oacc[db], 0, 0, 0);
+            }
+        }
+        ASTAMP(4, oacc[DB - 1][0]);
+        ASTAMP_END(0x0234, 4);
+    };
+    f32x16 sA[2], sB[2];
+    __builtin_amdgcn_s_barrier();            // tiles 0 and 1 are in LDS
+    qk(sA, smem);
+    int tile = 0, slot = 0;
+    if (!p.causal) {
+        const int nfull = p.t >> 6;   // tiles without a ragged tail
+        for (; tile + 2 <= nfull; tile += 2) {
+            step(std::false_type{}, sA, sB, tile, slot);
+            slot = (slot + 1) & 3;
+            step(std::false_type{}, sB, sA, tile + 1, slot);
+            slot = (slot + 1) & 3;
+        }
+    }
+    for (; tile < ntiles; ++tile) {
+        step(std::true_type{}, sA, sB, tile, slot);
+        slot = (slot + 1) & 3;
+        sA[0] = sB[0];
+        sA[1] = sB[1];
+    }
+
+    } else {
     for (int tile = 0; tile < ntiles; ++tile) {
         const int t0 = tile * 64;
         char* sK = smem + (PIPE ? (tile & 1) : 0) * BUF_BYTES;
         if (PIPE) {
             __syncthreads();
+            ASTAMP(0, mref);
             if (tile + 1 < ntiles) gload(t0 + 64);
         } else {
             __syncthreads();
@@ -599,6 +961,7 @@ __global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], sacc[kb], 0, 0, 0);
                 }
             }
+        ASTAMP(1, sacc[1][0]);
         // ---- masks (ragged key tail, causal): only the tiles that need them pay
         if (t0 + 64 > p.t) {
             int key0 = t0 + 4 * h;
@@ -625,6 +988,7 @@ __global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
         for (int i = 2; i < 16; i += 2) m = fmaxf(fmaxf(m, sacc[0][i]), sacc[0][i + 1]);
 #pragma unroll
         for (int i = 0; i < 16; i += 2) m = fmaxf(fmaxf(m, sacc[1][i]), sacc[1][i + 1]);
+        ASTAMP(2, m);
         const bool ask = tile == 0 || (PRESC ? (m > ATTN_THR) : ((m - mref) * p.sl2 > ATTN_THR));
         if (__builtin_amdgcn_ballot_w64(ask) != 0) {
             const uint32_t u = __float_as_uint(m);
@@ -666,6 +1030,7 @@ __global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
                 }
             if (!ONES_ROW) lrun += ls;
         }
+        ASTAMP(3, sacc[1][15]);
         // ---- O^T += V^T P^T, 16 keys per step
         const char* sV = sK + 64 * KROW;
 #pragma unroll
@@ -682,8 +1047,24 @@ __global__ __launch_bounds__(64 * NW) void attention32_kernel(const AArgs p) {
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pk.v, oacc[db], 0, 0, 0);
             }
         }
+        ASTAMP(4, oacc[DB - 1][0]);
         if (PIPE && tile + 1 < ntiles) lstore(smem + ((tile & 1) ^ 1) * BUF_BYTES, t0 + 64);
+        ASTAMP(5, mref);
+        ASTAMP_END(0x012345, 6);
     }
+    }
+#ifdef MSD_STAMPS
+    if (lane == 0 && (wave == 0 || (MSD_ASTAMP_WAVES && blockIdx.x < 256))) {
+        // (MSD_ASTAMP_WAVES: rows 2048 + 8 block + wave hold every compute wave of the first 256 workgroups)
+        unsigned long long* dst = g_astamps + (wave == 0 ? (size_t)(blockIdx.x & 2047) : (size_t)(2048 + blockIdx.x * 8 + wave)) * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
+        dst[8] = st_prev - st_first;
+        dst[9] = wall_clock64() - st_wall0;
+        dst[10] = st_wall0;
+        dst[11] = (unsigned long long)ntiles;
+    }
+#endif
 
     // ---- normalise and store: lane (c, h) holds channels db*32 + 8 (i >> 2) + 4 h + (i & 3) of query q0 + c
     float lt;
@@ -1150,7 +1531,7 @@ static constexpr int attn32_lds_bytes() {
 static bool g_attn_attr_done = false;
 static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = 64 / 128 queries per workgroup forced (A/B runs)
 void msd_set_attn_qf(int v) { g_attn_qf = v; }
-static int g_attn_form = 1;   // 1 = 32x32x16 MFMA form (attention32_kernel) for head sizes 40 and 80 [default], 0 = 16x16x32 form everywhere (A/B runs)
+static int g_attn_form = 2;   // head sizes 40 and 80: 2 = 32x32x16 MFMA form, software-pipelined for long key walks [default], 1 = 32x32x16 plain loop, 0 = 16x16x32 form like the other head sizes (A/B runs)
 void msd_set_attn_form(int v) { g_attn_form = v; }
 static int g_xattn_nw = 0;    // 0 = automatic, 4 / 8 = waves (x 16 queries) per workgroup of the fused cross-attention (A/B runs)
 void msd_set_xattn_nw(int v) { g_xattn_nw = v; }
@@ -1177,6 +1558,12 @@ static hipError_t attn_attr() {
         if (e == hipSuccess) e = attn32_attr1<D, NB, 4, false>();
         if (e == hipSuccess) e = attn32_attr1<D, NB, 2, true>();
         if (e == hipSuccess) e = attn32_attr1<D, NB, 4, true>();
+        if (e == hipSuccess) e = attn32_attr1<D, 4, 2, false>();
+        if (e == hipSuccess) e = attn32_attr1<D, 4, 4, false>();
+        if (e == hipSuccess) e = attn32_attr1<D, 4, 2, true>();
+        if (e == hipSuccess) e = attn32_attr1<D, 4, 4, true>();
+        if (e == hipSuccess) e = attn32_attr1<D, 4, 8, false>();
+        if (e == hipSuccess) e = attn32_attr1<D, 4, 8, true>();
     }
     return e;
 }
@@ -1206,15 +1593,26 @@ static void attn_launch2(const AArgs& a, dim3 grid, hipStream_t stream) {
 template <int D, int NBUF, int NW>
 static void attn32_launch2(const AArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int lds = attn32_lds_bytes<D, NBUF>();
-    if (a.presc) hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, true>), grid, dim3(64 * NW), lds, stream, a);
-    else hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, false>), grid, dim3(64 * NW), lds, stream, a);
+    constexpr int threads = 64 * (NW + attn32_loaders(NBUF, NW, D));   // (NBUF 4: the software-pipelined form, NW compute waves + the loader wave)
+    if (a.presc) hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, true>), grid, dim3(threads), lds, stream, a);
+    else hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, false>), grid, dim3(threads), lds, stream, a);
 }
+// The software-pipelined form needs a walk long enough to pay for its longer prologue (three tiles staged before the first
+// product): key walks of 4 tiles and more.  A function of the head size and the key count only — the forms round differently.
+static bool attn_swp(const AArgs& a, int d) { return g_attn_form == 2 && (d == 40 || d == 80) && a.t >= 256 && !a.causal; }
+
 template <int D>
 static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
     const int qt = 64 * qf;
     const dim3 grid(((a.s + qt - 1) / qt) * a.heads * a.batch);
     if constexpr (attn_form32<D>()) {
-        if (g_attn_form == 1) {
+        if (attn_swp(a, D)) {
+            if (qf == 1) attn32_launch2<D, 4, 2>(a, grid, stream);
+            else if (qf == 2 || D != 40) attn32_launch2<D, 4, 4>(a, grid, stream);
+            else attn32_launch2<D, 4, 8>(a, grid, stream);
+            return;
+        }
+        if (g_attn_form >= 1) {
             if (qf == 1) attn32_launch2<D, attn_nbuf<D>(), 2>(a, grid, stream);
             else attn32_launch2<D, attn_nbuf<D>(), 4>(a, grid, stream);
             return;
@@ -1222,6 +1620,18 @@ static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
     }
     if (qf == 1) attn_launch2<D, attn_nbuf<D>(), 1>(a, grid, stream);
     else attn_launch2<D, attn_nbuf<D>(), 2>(a, grid, stream);
+}
+
+// (tools: workgroups of the software-pipelined form the runtime expects to fit on one CU)
+extern "C" int msd_debug_attn32_occupancy(int d, int nw, int presc) {
+    int n = -1;
+#define OCC(D_, NW_, P_)                                                                                            \
+    if (d == D_ && nw == NW_ && presc == P_)                                                                        \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&attention32_kernel<D_, 4, NW_, P_>), \
+                                                           64 * (NW_ + attn32_loaders(4, NW_, D_)), attn32_lds_bytes<D_, 4>());
+    OCC(40, 2, true) OCC(40, 4, true) OCC(40, 8, true) OCC(80, 2, true) OCC(80, 4, true) OCC(40, 4, false) OCC(80, 2, false)
+#undef OCC
+    return n;
 }
 
 extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
@@ -1248,9 +1658,17 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     // Workgroup size in queries: 128, or 64 when the 128-query grid has fewer workgroups than ~1.5 x the CUs (S = 1024
     // and below at batch 2: 128 / 32 / 8 workgroups).  Measured on one box (us, 128 vs 64 queries per workgroup): S=4096
     // d=40 116 / 125; S=1024 d=80 35 / 28; S=256 d=160 17 / 13; S=4096 T=77 8.8 / 9.8; S=9216 525 / 584.
+    // The software-pipelined form at d = 40 takes 256 queries (8 compute waves + 2 loaders: one workgroup per CU is all that
+    // fits beside the loaders' wave slots, so it had better be a big one) once that grid has >= 128 workgroups; at d = 80
+    // (201 registers: 8 wave slots per CU) 64 queries while the grid is small, 128 beyond.
     const long long wgs128 = (long long)((q->s + 127) / 128) * q->heads * q->batch;
     int qf = g_attn_qf ? g_attn_qf : (wgs128 < 384 ? 1 : 2);
-    if (qf != 1) qf = 2;
+    if (attn_swp(a, q->head_dim) && !g_attn_qf) {
+        if (q->head_dim == 40) qf = wgs128 >= 256 ? 4 : (wgs128 >= 128 ? 2 : 1);
+        else qf = wgs128 <= 256 ? 1 : 2;
+    }
+    if (qf == 4 && !(attn_swp(a, q->head_dim) && q->head_dim == 40)) qf = 2;
+    if (qf != 1 && qf != 4) qf = 2;
     a.mg_qtiles = udiv_magic_of((q->s + 64 * qf - 1) / (64 * qf));
     a.mg_heads = udiv_magic_of(q->heads);
     switch (q->head_dim) {

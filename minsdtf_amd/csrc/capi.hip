@@ -38,12 +38,12 @@ extern "C" int msd_set_option(const char* key, int value) {
         return MSD_OK;
     }
     if (key && strcmp(key, "attn_qf") == 0) {     // 0 = automatic [default], 1 / 2 = 64 / 128 queries per workgroup
-        if (value < 0 || value > 2) MSD_FAIL(MSD_E_ARG, "set_option: attn_qf takes 0, 1 or 2");
+        if (value < 0 || value > 4 || value == 3) MSD_FAIL(MSD_E_ARG, "set_option: attn_qf takes 0, 1, 2 or 4");
         msd_set_attn_qf(value);
         return MSD_OK;
     }
-    if (key && strcmp(key, "attn_form") == 0) {   // 1 = attention on 32x32x16 MFMAs [default], 0 = on 16x16x32 MFMAs
-        if (value != 0 && value != 1) MSD_FAIL(MSD_E_ARG, "set_option: attn_form takes 0 or 1");
+    if (key && strcmp(key, "attn_form") == 0) {   // d = 40 / 80: 2 = 32x32x16 MFMAs, software-pipelined on long key walks [default], 1 = 32x32x16 plain, 0 = 16x16x32
+        if (value < 0 || value > 2) MSD_FAIL(MSD_E_ARG, "set_option: attn_form takes 0, 1 or 2");
         msd_set_attn_form(value);
         return MSD_OK;
     }

@@ -123,6 +123,20 @@ __device__ __forceinline__ void dma16s(const void* sbase, uint32_t voff, uint32_
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
+// same under an explicit lane mask (the wave must be fully active at the call): lanes off write nothing
+__device__ __forceinline__ void dma16sm(const void* sbase, uint32_t voff, uint32_t lds_dst, uint64_t lanes) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b64 exec, %4\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(lanes)
+        : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

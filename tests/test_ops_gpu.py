@@ -615,9 +615,9 @@ def test_layer_norm(gpu, rows, c):
     dict(B=1, H=1, d=40, S=9216, T=9216, spike=True),  # 768x768 (BASELINE config 4): 144 key tiles, reference moves late in the walk
     dict(B=1, H=1, d=40, S=4090, T=4090),              # long walk ending in a ragged query tile AND a ragged key tile
 ])
-@pytest.mark.parametrize("qf", [2, 1])   # 128 / 64 queries per workgroup (the library picks by grid size; both forced here)
+@pytest.mark.parametrize("qf", [2, 1, 4])   # 128 / 64 / 256 queries per workgroup (the library picks by grid size; all forced here; 256: software-pipelined d = 40 only)
 @pytest.mark.parametrize("presc", [False, True])   # q carrying scale*log2(e) already (the UNet's projections) or not
-@pytest.mark.parametrize("form", [1, 0])   # d = 40 / 80: the 32x32x16 MFMA kernel (default) or the 16x16x32 one; other head sizes: 16x16x32 either way
+@pytest.mark.parametrize("form", [2, 1, 0])   # d = 40 / 80: the 32x32x16 MFMA kernel, software-pipelined (2) or plain (1), or the 16x16x32 one (0); other head sizes: 16x16x32 either way
 def test_attention(gpu, case, qf, presc, form):
     """The lazy rescale (attention.hip ATTN_THR) is a rare data-dependent branch: the `spike` cases force it at chosen
     tiles (one key row scaled so the tile maximum jumps far past the threshold), `ramp` makes the maximum grow by
@@ -655,15 +655,17 @@ def test_attention(gpu, case, qf, presc, form):
     kd = k.to(torch.bfloat16).to(gpu)
     call = ops.attention(q=qbuf.data_ptr() + 2 * C, k=kd, vt=vt, out=out, batch=B, heads=H,
                          head_dim=d, s=S, t=T, q_ld=3 * C, k_ld=C, vt_ld=Tp, o_ld=C, scale=scale, q_prescaled=presc)
-    if form == 0 and (d not in (40, 80) or S > 2048):
+    if form != 1 and (d not in (40, 80) or (form == 0 and S > 2048)):
         pytest.skip("the same kernel as form 1 (or a long CPU reference already spent on it)")
+    if qf == 4 and not (form == 2 and d == 40 and T >= 256):
+        pytest.skip("256 queries per workgroup exist in the software-pipelined d = 40 form only (key walks of 4 tiles and more)")
     _lib.load().msd_set_option(b"attn_qf", qf)
     _lib.load().msd_set_option(b"attn_form", form)
     try:
         run_calls(call)
     finally:
         _lib.load().msd_set_option(b"attn_qf", 0)
-        _lib.load().msd_set_option(b"attn_form", 1)
+        _lib.load().msd_set_option(b"attn_form", 2)
     # P is rounded to bf16 before the PV product (relative 2^-9 per term): the error scales with the
     # magnitude of the summed terms, so the absolute floor is 1.5e-2 of max(1, max|O|)
     close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"{case} qf={qf} presc={presc} form={form}")

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--qf", type=int, default=0, help="0 = automatic, 1 / 2 = 64 / 128 queries per workgroup")
     ap.add_argument("--presc", type=int, default=1, help="1 = q carries scale*log2(e) (the UNet's projections), 0 = generic")
-    ap.add_argument("--form", type=int, default=1, help="1 = 32x32x16 MFMA kernel, 0 = 16x16x32 MFMA kernel")
+    ap.add_argument("--form", type=int, default=2, help="2 = 32x32x16 MFMA kernel, software-pipelined, 1 = 32x32x16 plain, 0 = 16x16x32 MFMA kernel")
     args = ap.parse_args()
     from minsdtf_amd import _lib, ops
 
