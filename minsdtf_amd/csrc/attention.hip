@@ -735,10 +735,20 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
             else wait_vmcnt<KI / NL + VI / NL>();   // (NL == 2: loader 1 has the odd pieces)
         };
         static_assert(NL <= 2, "wait_newest counts the pieces of loader 0 and loader 1");
+#ifdef MSD_STAMPS
+        unsigned long long pt0, pt1, pt2;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt0) : : "memory");
+#endif
         stage(0);
         if (ntiles > 1) stage(1);
         if (ntiles > 2) stage(2);
+#ifdef MSD_STAMPS
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt1) : : "memory");
+#endif
         if (ntiles > 2) wait_newest(); else wait_vmcnt<0>();
+#ifdef MSD_STAMPS
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pt2) : : "memory");
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #ifdef MSD_STAMPS
@@ -763,7 +773,7 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
 #ifdef MSD_STAMPS
         if (lane == 0 && ldr == 0) {
             unsigned long long* dst = g_astamps + (size_t)(blockIdx.x & 2047) * 16 + 12;
-            dst[0] = la[0]; dst[1] = la[1]; dst[2] = la[2];
+            dst[0] = la[0]; dst[1] = la[1]; dst[2] = la[2]; dst[3] = ((pt1 - pt0) << 32) | (pt2 - pt1);
         }
 #endif
         return;

@@ -136,9 +136,10 @@ def test_conv_gemm(gpu, case):
     out = torch.full((M, N), float("nan"), dtype=torch.float32 if f32out else torch.bfloat16, device=d)
     ws = torch.empty(max(1, splitk * M * N), dtype=torch.float32, device=d)
     step = torch.tensor([2], dtype=torch.int32, device=d)
+    biasd, tembd, residd = bias.to(d), temb.to(d), resid.to(torch.bfloat16).to(d)   # (a Call holds addresses, not tensors)
     call = ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=wp, out=out, batch=B, h_in=H, w_in=W, c0=c0, N=N, ksize=ks, stride=stride,
-                         upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N, rv_batch_stride=N,
-                         step_ptr=step, residual=resid.to(torch.bfloat16).to(d), act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
+                         upsample=ups, bias=biasd, rowvec=tembd, rv_step_stride=B * N, rv_batch_stride=N,
+                         step_ptr=step, residual=residd, act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
                          out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, workspace=ws, workspace_floats=ws.numel(),
                          splitk=splitk, tile_n=case.get("tile_n", 0), tile_m=case.get("tile_m", 0), stages=case.get("stages", 0),
                          **(dict(pad=0, pad_end=1) if asym else {}))
@@ -148,15 +149,15 @@ def test_conv_gemm(gpu, case):
         tm, tn, stg = case["same_as"]
         out2 = torch.full_like(out, float("nan"))
         run_calls(ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=wp, out=out2, batch=B, h_in=H, w_in=W, c0=c0, N=N, ksize=ks, stride=stride,
-                                upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N, rv_batch_stride=N, step_ptr=step,
-                                residual=resid.to(torch.bfloat16).to(d), act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
+                                upsample=ups, bias=biasd, rowvec=tembd, rv_step_stride=B * N, rv_batch_stride=N, step_ptr=step,
+                                residual=residd, act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
                                 out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, tile_n=tn, tile_m=tm, stages=stg))
         assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "tile shape changed the bits"
     # chunk-major weights [K/64][N][64] (w_layout = 1, the form the models keep): storage order only, the same bits
     out3 = torch.full_like(out, float("nan"))
     run_calls(ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=packing.chunk_major(wp), w_layout=1, out=out3, batch=B, h_in=H, w_in=W, c0=c0, N=N,
-                            ksize=ks, stride=stride, upsample=ups, bias=bias.to(d), rowvec=temb.to(d), rv_step_stride=B * N,
-                            rv_batch_stride=N, step_ptr=step, residual=resid.to(torch.bfloat16).to(d),
+                            ksize=ks, stride=stride, upsample=ups, bias=biasd, rowvec=tembd, rv_step_stride=B * N,
+                            rv_batch_stride=N, step_ptr=step, residual=residd,
                             act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE, out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16,
                             workspace=ws, workspace_floats=ws.numel(), splitk=splitk, tile_n=case.get("tile_n", 0),
                             tile_m=case.get("tile_m", 0), stages=case.get("stages", 0), **(dict(pad=0, pad_end=1) if asym else {})))

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--lib", default=os.path.join(ROOT, "tools", "_build", "libminsdtf_hip_stamps.so"))
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--form", type=int, default=1, help="1 = plain loop, 2 = software-pipelined loop (stamps: 0 barrier, 1 next tile stored + loads issued, "
+    ap.add_argument("--form", type=int, default=2, help="1 = plain loop, 2 = software-pipelined loop (stamps: 0 barrier, 1 next tile stored + loads issued, "
                     "2 QK^T(t+1) issued + maximum of tile t, 3 exponentials, 4 PV issued)")
     ap.add_argument("--qf", type=int, default=0, help="0 = automatic, 1 / 2 / 4 = 64 / 128 / 256 queries per workgroup")
     args = ap.parse_args()
@@ -85,6 +85,9 @@ def main():
             rw = allr[2048 + np.arange(min(nwg, 256)) * 8 + w]
             if rw[:, 11].min() > 0:
                 print(f"    wave {w}: " + "  ".join(f"{(rw[:, i] / rw[:, 11]).mean():7.1f}" for i in (0, 2, 3, 4)) + "   (barrier, QK + max, exp, PV)")
+        if args.form == 2:
+            raw = buf.reshape(4096, 16)[:nwg, 15]
+            print(f"    loader 0 prologue: issue of tiles 0-2 {(raw >> np.uint64(32)).astype(np.float64).mean():.0f} ticks, then {(raw & np.uint64(0xFFFFFFFF)).astype(np.float64).mean():.0f} until tiles 0-1 have landed")
         w0 = rows[:, 10]
         print(f"    workgroup entry spread {(w0.max() - w0.min()) / 100:.2f} us")
 
