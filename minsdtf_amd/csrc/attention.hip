@@ -1632,7 +1632,8 @@ static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
     else attn_launch2<D, attn_nbuf<D>(), 2>(a, grid, stream);
 }
 
-// (tools: workgroups of the software-pipelined form the runtime expects to fit on one CU)
+#ifdef MSD_STAMPS
+// (tools, `make stamps` library only: workgroups of the software-pipelined form the runtime expects to fit on one CU)
 extern "C" int msd_debug_attn32_occupancy(int d, int nw, int presc) {
     int n = -1;
 #define OCC(D_, NW_, P_)                                                                                            \
@@ -1643,6 +1644,7 @@ extern "C" int msd_debug_attn32_occupancy(int d, int nw, int presc) {
 #undef OCC
     return n;
 }
+#endif
 
 extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
