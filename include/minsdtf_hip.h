@@ -41,7 +41,7 @@ int msd_abi_version(void);
 const char* msd_last_error(void);
 /* One-time per-process set-up (raises the dynamic-LDS limits of the kernels). Idempotent. */
 int msd_init(void);
-/* Tuning / A-B switches, e.g. ("conv_dense", 0|1), ("attn_qf", 0|1|2). Returns MSD_E_ARG for an unknown key. */
+/* Tuning / A-B switches, e.g. ("conv_dense", 0|1), ("attn_qf", 0|1|2|4), ("attn_form", 0|1|2). Returns MSD_E_ARG for an unknown key. */
 int msd_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------
