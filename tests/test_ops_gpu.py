@@ -615,6 +615,8 @@ def test_layer_norm(gpu, rows, c):
     dict(B=1, H=2, d=40, S=4096, T=4096, spike=True),  # the 64x64 level's real size (the most expensive kernel of a step); late spikes
     dict(B=1, H=1, d=40, S=9216, T=9216, spike=True),  # 768x768 (BASELINE config 4): 144 key tiles, reference moves late in the walk
     dict(B=1, H=1, d=40, S=4090, T=4090),              # long walk ending in a ragged query tile AND a ragged key tile
+    dict(B=1, H=2, d=80, S=64, T=257, spike=True),     # software-pipelined form: shortest walk it takes + a 1-key ragged tile; one busy wave
+    dict(B=3, H=3, d=40, S=300, T=256),                # ... exactly four tiles (the ring's depth), odd batch x heads, ragged queries
 ])
 @pytest.mark.parametrize("qf", [2, 1, 4])   # 128 / 64 / 256 queries per workgroup (the library picks by grid size; all forced here; 256: software-pipelined d = 40 only)
 @pytest.mark.parametrize("presc", [False, True])   # q carrying scale*log2(e) already (the UNet's projections) or not
