@@ -29,6 +29,7 @@ struct AArgs {
     int causal; // key index > query index is masked (CLIP text encoder, text_encoder.py:75-78)
     int presc;  // q already carries scale * log2(e) (folded into the projection that produced it)
     uint32_t mg_qtiles, mg_heads;   // floor(2^32 / d) for the workgroup-id decomposition (udiv_magic)
+    int q_begin, q_count;           // attention32_kernel: the launch covers queries [q_begin, q_begin + q_count) of every sample (mg_qtiles: of that range)
 };
 
 // Maximum over the 4 lanes {l, l^16, l^32, l^48} (the four 16-lane rows of the wave), result on every lane: two
@@ -487,11 +488,12 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int qtiles = (p.s + QT - 1) / QT;
+    const int qtiles = (p.q_count + QT - 1) / QT;
+    const int q_end = p.q_begin + p.q_count;   // (<= p.s)
     const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);
     const int bh = udiv_magic(wi, qtiles, p.mg_qtiles);
     const int b = udiv_magic(bh, p.heads, p.mg_heads), hd = bh - b * p.heads;
-    const int q0 = (wi - bh * qtiles) * QT + wave * 32;
+    const int q0 = p.q_begin + (wi - bh * qtiles) * QT + wave * 32;
 
     if constexpr (SWP) {
         // The DMAs write every data slot of a tile image before it is read; only what they leave alone needs a value: the pad
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
                     v[4 + e] = __uint_as_float(sw[1]);
                 }
                 const int d = db * 32 + 16 * j + 8 * h;
-                if (d < D && qrow < p.s) *reinterpret_cast<uint4*>(op + d) = pack8(v);
+                if (d < D && qrow < q_end) *reinterpret_cast<uint4*>(op + d) = pack8(v);
             }
     } else {
 #pragma unroll
@@ -1110,7 +1112,7 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = db * 32 + 8 * g4 + 4 * h;
-                if (d < D && qrow < p.s) {
+                if (d < D && qrow < q_end) {
                     uint2 o;
                     o.x = pack_bf2(oacc[db][4 * g4 + 0] * inv, oacc[db][4 * g4 + 1] * inv);
                     o.y = pack_bf2(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
@@ -1614,7 +1616,7 @@ static bool attn_swp(const AArgs& a, int d) { return g_attn_form == 2 && (d == 4
 template <int D>
 static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
     const int qt = 64 * qf;
-    const dim3 grid(((a.s + qt - 1) / qt) * a.heads * a.batch);
+    const dim3 grid(((a.q_count + qt - 1) / qt) * a.heads * a.batch);
     if constexpr (attn_form32<D>()) {
         if (attn_swp(a, D)) {
             if (qf == 1) attn32_launch2<D, 4, 2>(a, grid, stream);
@@ -1681,8 +1683,38 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     }
     if (qf == 4 && !(attn_swp(a, q->head_dim) && q->head_dim == 40)) qf = 2;
     if (qf != 1 && qf != 4) qf = 2;
+    a.q_begin = 0;
+    a.q_count = q->s;
     a.mg_qtiles = udiv_magic_of((q->s + 64 * qf - 1) / (64 * qf));
     a.mg_heads = udiv_magic_of(q->heads);
+    // 256-query workgroups whose last round of the chip is at most half full (768x768: 576 of them on 256 CUs = 2.25 rounds):
+    // the queries of that round go to a second launch of 64-query workgroups, which fills every CU — a quarter of the work takes a
+    // shorter round instead of a full one.  Scheduling only: the workgroup size changes no value.
+    if (qf == 4 && !g_attn_qf) {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            if (cus <= 0) cus = 256;
+        }
+        const long long bh = (long long)q->heads * q->batch, qt4 = (q->s + 255) / 256, tiles = qt4 * bh, rem = tiles % cus;
+        const long long tail_qt = (rem + bh - 1) / bh;   // 256-query tiles per (batch, head) that make up the partial round
+        if (tiles > cus && rem > 0 && 2 * rem <= cus && tail_qt < qt4 && q->head_dim == 40) {
+            a.q_count = (int)((qt4 - tail_qt) * 256);
+            a.mg_qtiles = udiv_magic_of((int)(qt4 - tail_qt));
+            attn_launch<40>(a, 4, stream);
+            MSD_CHECK_LAUNCH();
+            a.q_begin = a.q_count;
+            a.q_count = q->s - a.q_begin;
+            const long long w64 = (long long)((a.q_count + 63) / 64) * bh;
+            const int tqf = w64 <= 2ll * cus ? 1 : 2;
+            a.mg_qtiles = udiv_magic_of((a.q_count + 64 * tqf - 1) / (64 * tqf));
+            attn_launch<40>(a, tqf, stream);
+            MSD_CHECK_LAUNCH();
+            return MSD_OK;
+        }
+    }
     switch (q->head_dim) {
         case 40: attn_launch<40>(a, qf, stream); break;
         case 80: attn_launch<80>(a, qf, stream); break;

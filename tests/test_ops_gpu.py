@@ -602,6 +602,40 @@ def test_layer_norm(gpu, rows, c):
     close(out, ref, atol=2e-2, what=f"ln {rows}x{c}")
 
 
+def test_attention_partial_round_split(gpu):
+    """256-query workgroups whose last round would be at most half full hand that round's queries to a second launch of
+    64-query workgroups (attention.hip, msd_attention): scheduling only — the bits of the one-launch form, and the fp32 answer."""
+    from minsdtf_amd import _lib, ops
+
+    torch.manual_seed(11)
+    B, H, d, S, T = 8, 8, 40, 1280, 1280     # 5 x 64 = 320 workgroups of 256 queries on 256 CUs: 64 in the second round
+    C = H * d
+    scale = d ** -0.5
+    q = bf(torch.randn(B, S, C) * (scale * 1.4426950408889634))
+    k, v = bf(torch.randn(B, T, C)), bf(torch.randn(B, T, C))
+    k[:, T - 7] *= 10.0   # a late reference-maximum move inside the tail range's walk too
+    k = bf(k)
+    qh = q.view(B, S, H, d).permute(0, 2, 1, 3)
+    kh = k.view(B, T, H, d).permute(0, 2, 1, 3)
+    vh = v.view(B, T, H, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax((qh @ kh.transpose(-1, -2)) * math.log(2.0), -1) @ vh).permute(0, 2, 1, 3).reshape(B, S, C)
+    qd, kd = q.to(torch.bfloat16).to(gpu), k.to(torch.bfloat16).to(gpu)
+    vt = v.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(gpu)
+    outs = []
+    for qf in (0, 4):   # automatic (splits the partial round) / 256 queries forced (one launch)
+        out = torch.full((B, S, C), float("nan"), dtype=torch.bfloat16, device=gpu)
+        call = ops.attention(q=qd, k=kd, vt=vt, out=out, batch=B, heads=H, head_dim=d, s=S, t=T, q_ld=C, k_ld=C, vt_ld=T, o_ld=C,
+                             scale=scale, q_prescaled=True)
+        _lib.load().msd_set_option(b"attn_qf", qf)
+        try:
+            run_calls(call)
+        finally:
+            _lib.load().msd_set_option(b"attn_qf", 0)
+        outs.append(out)
+    close(outs[0], ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what="partial-round split")
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "the two-launch form changed the bits"
+
+
 @pytest.mark.parametrize("case", [
     dict(B=2, H=8, d=40, S=256, T=256),
     dict(B=1, H=8, d=40, S=1024, T=1024),
