@@ -1541,6 +1541,7 @@ static constexpr int attn32_lds_bytes() {
 }
 
 static bool g_attn_attr_done = false;
+static int g_attn_cus = 256;   // compute units of the device (msd_attention_init)
 static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = 64 / 128 queries per workgroup forced (A/B runs)
 void msd_set_attn_qf(int v) { g_attn_qf = v; }
 static int g_attn_form = 2;   // head sizes 40 and 80: 2 = 32x32x16 MFMA form, software-pipelined for long key walks [default], 1 = 32x32x16 plain loop, 0 = 16x16x32 form like the other head sizes (A/B runs)
@@ -1592,6 +1593,12 @@ int msd_attention_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<80, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<80>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<80, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<80>());
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            g_attn_cus = prop.multiProcessorCount;
+    }
     g_attn_attr_done = true;
     return MSD_OK;
 }
@@ -1691,13 +1698,7 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     // the queries of that round go to a second launch of 64-query workgroups, which fills every CU — a quarter of the work takes a
     // shorter round instead of a full one.  Scheduling only: the workgroup size changes no value.
     if (qf == 4 && !g_attn_qf) {
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-            if (cus <= 0) cus = 256;
-        }
+        const int cus = g_attn_cus;
         const long long bh = (long long)q->heads * q->batch, qt4 = (q->s + 255) / 256, tiles = qt4 * bh, rem = tiles % cus;
         const long long tail_qt = (rem + bh - 1) / bh;   // 256-query tiles per (batch, head) that make up the partial round
         if (tiles > cus && rem > 0 && 2 * rem <= cus && tail_qt < qt4 && q->head_dim == 40) {
