@@ -116,7 +116,7 @@ typedef struct MsdConvGemm {
                             10 + depth = the tile on 8 waves (two per SIMD): 64x64:14 128x64:13 64x128:13;
                             20 + depth = 64x64 per wave: 128x128:23/24 128x64:24 64x128:24;
                             30 + depth = halo tiles with 3 filter taps (one filter row) per K step: 1128x64:33/34 1128x80:33
-                            2128x64:33 */
+                            2128x64:33; 60 + depth = the same with two loader waves that do all the staging: 1128x64:63 1128x80:63 */
     const float* ln_in;      /* float2 [M][ln_in_slots] row-moment partials of the input rows, or NULL */
     const float* ln_colsum;  /* [N]: sum_k W[n][k] of the gamma-folded bf16 weights (with ln_in) */
     float* ln_out;           /* float2 [M][ln_out_slots] row-moment partials of the stored output, or NULL */

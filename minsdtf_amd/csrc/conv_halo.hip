@@ -43,10 +43,13 @@ __device__ __forceinline__ void halo_wait(int later, bool halo) {
 // and the previous tap's MFMAs (a 1-tap step measured 0.59 us for 0.16 us of MFMA work on the 8x16x80 tile: 0.32 us
 // issuing fragment reads + DMAs, 0.16 us wait + barrier).  The taps of a chunk are still walked in the order 0..8, so the
 // bits do not change.
-template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGArgs p) {
+// NL = loader waves behind the WGM x WGN compute waves (0: every wave stages its share of each tile, the form above).  With
+// NL > 0 the compute waves' K step is barrier -> fragment reads -> MFMAs and nothing else; the loaders run the same DMA program
+// (counted waits, the barrier, the issues) over a row distribution of their own and leave before the epilogue.
+template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1, int NL = 0>
+__global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(const CGArgs p) {
     constexpr int TW = 16, BM = TH * TW;
-    constexpr int NW = WGM * WGN, NT = NW * 64;
+    constexpr int NW = WGM * WGN, NT = (NL ? NL : NW) * 64;   // NT = threads that stage
     constexpr int WMT = BM / WGM, WNT = BN / WGN;
     constexpr int MI = WMT / 16, NJ = WNT / 16;           // MI = tile rows per wave
     constexpr int HW_ = TW + 2;                            // halo width (18)
@@ -64,9 +67,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int tid0 = threadIdx.x, lane = tid0 & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const bool loader = NL > 0 && wave0 >= NW;            // (wave-uniform)
+    const bool computes = NL == 0 || !loader;
+    const int tid = NL ? tid0 - NW * 64 : tid0;           // staging thread index (loaders only when NL > 0)
+    const int wave = NL ? wave0 - NW : wave0;             // ... and staging wave index
+    const int wm = wave0 / WGN, wn = wave0 % WGN;
     const int r = lane & 15, g = lane >> 4;
     MSD_STAMP(0);
 
@@ -151,7 +158,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
     // W(it+S-1).  With one workgroup per CU (batch 1-2) a K step costs (L2 latency) / (tiles in flight):
     // S = 3 measured ~0.7 us per step against ~0.13 us of MFMA work, hence the deeper rings.
     static_assert(S >= 3 && S - 1 <= SPC, "ring depth");
-    if (nkt > 0) {
+    const bool stages_tiles = NL == 0 || loader;   // this wave issues DMAs (and waits for them)
+    if (nkt > 0 && stages_tiles) {
         issue_halo(c_begin, 0);
 #pragma unroll
         for (int s = 0; s < S - 1; ++s)
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         const bool probe = it == 20 || (nkt <= 20 && it == nkt - 2);   // one K step under the microscope (slots 10..15)
         if (probe) MSD_STAMP(10);
 #endif
-        halo_wait<BR, HR, S - 2>(min(S - 2, nkt - 1 - it), since_halo <= S - 2);
+        if (stages_tiles) halo_wait<BR, HR, S - 2>(min(S - 2, nkt - 1 - it), since_halo <= S - 2);
 #ifdef MSD_STAMPS
         if (probe) MSD_STAMP(11);
 #endif
@@ -211,12 +219,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
                         acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
         };
         bf16x8 af[2][MI], wf[2][NJ];
-        read_tap(0, af, wf);
-        if (tap == 0 && c + 1 < c_end) { issue_halo(c + 1, hbuf ^ 1); since_halo = 0; }
-        if (it + S - 1 < nkt) {
-            issue_w(cw, tw, sw);
-            if (++tw == SPC) { tw = 0; ++cw; }
-            if (++sw == S) sw = 0;
+        if (computes) read_tap(0, af, wf);
+        if (stages_tiles) {
+            if (tap == 0 && c + 1 < c_end) { issue_halo(c + 1, hbuf ^ 1); since_halo = 0; }
+            if (it + S - 1 < nkt) {
+                issue_w(cw, tw, sw);
+                if (++tw == SPC) { tw = 0; ++cw; }
+                if (++sw == S) sw = 0;
+            }
         }
         ++since_halo;
 #ifdef MSD_STAMPS
@@ -226,15 +236,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
             MSD_STAMP(14);                                           // fragments in registers
         }
 #endif
-        if constexpr (TAPS == 1) {
-            mfma_tap(af, wf);
-        } else {
-            bf16x8 af2[2][MI], wf2[2][NJ];
-            read_tap(1, af2, wf2);
-            mfma_tap(af, wf);
-            read_tap(2, af, wf);
-            mfma_tap(af2, wf2);
-            mfma_tap(af, wf);
+        if (computes) {
+            if constexpr (TAPS == 1) {
+                mfma_tap(af, wf);
+            } else {
+                bf16x8 af2[2][MI], wf2[2][NJ];
+                read_tap(1, af2, wf2);
+                mfma_tap(af, wf);
+                read_tap(2, af, wf);
+                mfma_tap(af2, wf2);
+                mfma_tap(af, wf);
+            }
         }
 #ifdef MSD_STAMPS
         if (probe) {
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
         if (++tap == SPC) { tap = 0; ++c; hbuf ^= 1; }
     }
     MSD_STAMP(3);
+    if (NL > 0 && loader) return;
     int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) mrow[i] = (b * p.h_in + ty0 + wm * MI + i) * p.w_in + tx0;
@@ -268,26 +281,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_halo_kernel(const CGAr
 // `stages` 30 + depth: 3 taps (one filter row) per K step with a ring of `depth` rows (8x16 tiles x 64 / 80 channels: the
 // ring holds depth x 3 weight tiles).
 #define MSD_HALO_CFGS(X)      \
-    X(8, 64, 2, 2, 3, 0, 1)   \
-    X(8, 128, 2, 4, 3, 0, 1)  \
-    X(16, 128, 4, 2, 3, 0, 1) \
-    X(8, 80, 4, 1, 3, 0, 1)   \
-    X(16, 80, 4, 1, 3, 0, 1)  \
-    X(8, 64, 2, 2, 8, 0, 1)   \
-    X(8, 128, 2, 4, 6, 0, 1)  \
-    X(8, 80, 4, 1, 8, 0, 1)   \
-    X(16, 80, 4, 1, 5, 0, 1)  \
-    X(8, 64, 4, 2, 3, 1, 1)   \
-    X(8, 80, 8, 1, 3, 1, 1)   \
-    X(8, 64, 2, 2, 33, 0, 3)  \
-    X(8, 64, 2, 2, 34, 0, 3)  \
-    X(8, 80, 4, 1, 33, 0, 3)  \
-    X(8, 64, 4, 2, 33, 1, 3)
+    X(8, 64, 2, 2, 3, 0, 1, 0)   \
+    X(8, 128, 2, 4, 3, 0, 1, 0)  \
+    X(16, 128, 4, 2, 3, 0, 1, 0) \
+    X(8, 80, 4, 1, 3, 0, 1, 0)   \
+    X(16, 80, 4, 1, 3, 0, 1, 0)  \
+    X(8, 64, 2, 2, 8, 0, 1, 0)   \
+    X(8, 128, 2, 4, 6, 0, 1, 0)  \
+    X(8, 80, 4, 1, 8, 0, 1, 0)   \
+    X(16, 80, 4, 1, 5, 0, 1, 0)  \
+    X(8, 64, 4, 2, 3, 1, 1, 0)   \
+    X(8, 80, 8, 1, 3, 1, 1, 0)   \
+    X(8, 64, 2, 2, 33, 0, 3, 0)  \
+    X(8, 64, 2, 2, 34, 0, 3, 0)  \
+    X(8, 80, 4, 1, 33, 0, 3, 0)  \
+    X(8, 64, 4, 2, 33, 1, 3, 0)  \
+    X(8, 80, 4, 1, 63, 0, 3, 2)  \
+    X(8, 64, 2, 2, 63, 0, 3, 2)
 
-template <int TH, int BN, int WGM, int WGN, int SC, int TAPS>
+template <int TH, int BN, int WGM, int WGN, int SC, int TAPS, int NL>
 static constexpr int halo_lds() {
-    constexpr int S = SC % 30;   // (SC = stages code: 30 + depth for the 3-taps-per-step form)
-    constexpr int NT = WGM * WGN * 64, RPP = NT / 8, HROWS = (TH + 2) * 18, HR = (HROWS + RPP - 1) / RPP;
+    constexpr int S = SC % 30;   // (SC = stages code: 30 + depth for the 3-taps-per-step form, 60 + depth: the same with 2 loader waves)
+    constexpr int NT = (NL ? NL : WGM * WGN) * 64, RPP = NT / 8, HROWS = (TH + 2) * 18, HR = (HROWS + RPP - 1) / RPP;
     constexpr int BNP = (BN + RPP - 1) / RPP * RPP;
     constexpr int bytes = 2 * HR * RPP * 128 + S * TAPS * BNP * 128;
     static_assert(bytes <= 160 * 1024, "LDS budget");
@@ -298,10 +313,10 @@ static bool g_halo_attr_done = false;
 int msd_conv_halo_init() {
     if (g_halo_attr_done) return MSD_OK;
     hipError_t e = hipSuccess;
-#define X(th, bn, wgm, wgn, st, var, taps)                                                                             \
+#define X(th, bn, wgm, wgn, st, var, taps, nl)                                                                         \
     if (e == hipSuccess)                                                                                              \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st % 30, taps>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st, taps>());
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st % 30, taps, nl>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st, taps, nl>());
     MSD_HALO_CFGS(X)
 #undef X
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_halo): %s", hipGetErrorString(e));
@@ -317,21 +332,21 @@ int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int varian
     dim3 grid(tiles, slices);
     // `stages` picks the ring depth if that variant is built, otherwise the tile's default (3)
     bool have = false;
-#define X(th_, bn_, wgm, wgn, st, var, taps) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
+#define X(th_, bn_, wgm, wgn, st, var, taps, nl) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
     MSD_HALO_CFGS(X)
 #undef X
     if (!have) {   // unknown ring depth -> the tile's default; unknown 8-wave variant -> the 4-wave tile
         stages = 3;
         have = false;
-#define X(th_, bn_, wgm, wgn, st, var, taps) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
+#define X(th_, bn_, wgm, wgn, st, var, taps, nl) have = have || (th == th_ && bn == bn_ && stages == st && variant == var);
         MSD_HALO_CFGS(X)
 #undef X
         if (!have) variant = 0;
     }
-#define X(th_, bn_, wgm, wgn, st, var, taps)                                                                              \
+#define X(th_, bn_, wgm, wgn, st, var, taps, nl)                                                                          \
     if (th == th_ && bn == bn_ && stages == st && variant == var) {                                                       \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps>), grid, dim3(wgm * wgn * 64),          \
-                           (halo_lds<th_, bn_, wgm, wgn, st, taps>()), stream, a);                                        \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps, nl>), grid, dim3((wgm * wgn + nl) * 64), \
+                           (halo_lds<th_, bn_, wgm, wgn, st, taps, nl>()), stream, a);                                    \
         return MSD_OK;                                                                                                    \
     }
     MSD_HALO_CFGS(X)

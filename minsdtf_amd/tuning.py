@@ -27,7 +27,8 @@ TILES = ((128, 128, 0), (128, 64, 0), (64, 64, 0), (64, 128, 0), (256, 128, 0),
          (128, 160, 0))
 HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (1256, 80, 0),
               (1128, 64, 8), (1128, 128, 6), (1128, 80, 8), (1256, 80, 5), (2128, 64, 0), (2128, 80, 0),
-              (1128, 64, 33), (1128, 64, 34), (1128, 80, 33), (2128, 64, 33))   # 30 + depth: 3 taps (a filter row) per K step
+              (1128, 64, 33), (1128, 64, 34), (1128, 80, 33), (2128, 64, 33),   # 30 + depth: 3 taps (a filter row) per K step
+              (1128, 64, 63), (1128, 80, 63))   # 60 + depth: ... staged by two loader waves behind the compute waves
 
 
 # (rows per workgroup + 3000, columns per workgroup): row-panel Dense kernel (csrc/conv_rowpanel.hip) for the LayerNorm-

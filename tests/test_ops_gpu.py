@@ -98,6 +98,10 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=8, W=16, c0=320, N=320, ks=3, tile_m=1128, tile_n=80, stages=33, same_as=(1128, 80, 0)),
     dict(B=2, H=16, W=16, c0=128, N=192, ks=3, tile_m=2128, tile_n=64, stages=33, same_as=(1128, 64, 0)),
     dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, stages=33, splitk=2),       # + split over chunks
+    # ... with two loader waves behind the compute waves (stages 60 + depth): a different DMA row distribution, the same bits
+    dict(B=2, H=8, W=16, c0=320, N=320, ks=3, tile_m=1128, tile_n=80, stages=63, same_as=(1128, 80, 0)),
+    dict(B=1, H=16, W=32, c0=64, c1=64, N=100, ks=3, tile_m=1128, tile_n=64, stages=63, same_as=(1128, 64, 0)),
+    dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, stages=63, splitk=2),
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing
