@@ -62,6 +62,9 @@ def parse_args(argv=None):
                     help="library A/B switch passed to msd_set_option (same-box comparisons), e.g. --opt attn_swp=0")
     ap.add_argument("--streams", type=int, default=0, help="1: cond+uncond as one batch-2B forward; 2: two HIP streams; 0: automatic")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (the measured path); gloo: launcher self-test on CPU")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the packed broadcast and the all-gather through torch.distributed even at world size 1 (a one-rank "
+                         "RCCL process group): exercises the multi-GPU exchange path on a one-GPU box")
     ap.add_argument("--stub-local", action="store_true",
                     help="replace the GPU pipeline by a trivial per-sample generator (launcher / sharding self-test; the "
                          "line is marked stub and is not a measurement)")
@@ -99,26 +102,63 @@ def launch_ranks(n: int, argv) -> int:
     line = None
     pending = set(range(n))
     out0 = []
+    import signal
     import threading
 
     def pump():   # rank 0's stdout must be drained while we poll, or a full pipe would stall it
         for ln in procs[0].stdout:
             out0.append(ln.decode(errors="replace"))
 
+    def stop_all(grace=10.0):
+        """End every rank still running — exact PIDs, terminate, then kill after `grace` seconds — and reap them: a rank left
+        alone would sit in an RCCL collective for ever and keep its GPU."""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            p.terminate()
+        t_end = time.time() + grace
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Stop(signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    deadline = time.time() + float(os.environ.get("MSD_BENCH_LAUNCHER_DEADLINE_S", "3300"))
     th = threading.Thread(target=pump, daemon=True)
     th.start()
-    while pending:
-        for r in sorted(pending):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            pending.discard(r)
-            if code != 0:
-                log(f"launcher: rank {r} exited with code {code}")
-                rc = rc or code
-                for q in pending:   # the other ranks would wait for it in a collective forever
-                    procs[q].terminate()
-        time.sleep(0.05)
+    try:
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    log(f"launcher: rank {r} exited with code {code}")
+                    rc = rc or code
+                    stop_all()   # the other ranks would wait for it in a collective forever
+                    pending.clear()
+                    break
+            if pending and time.time() > deadline:
+                log("launcher: deadline passed, ending the ranks")
+                rc = rc or 124
+                stop_all()
+                pending.clear()
+            time.sleep(0.05)
+    except _Stop as e:
+        log(f"launcher: signal {e.args[0]}, ending the ranks")
+        rc = 128 + int(e.args[0])
+    finally:
+        stop_all()   # (no-op when every rank has exited)
+        for sg, h in old.items():
+            signal.signal(sg, h)
     th.join(timeout=10)
     for ln in out0:
         if ln.lstrip().startswith("{"):
@@ -192,7 +232,13 @@ def main(argv=None):
         if not stub:
             raise SystemExit("--backend gloo is the CPU self-test of the launcher / sharding path: it needs --stub-local")
         dev = torch.device("cpu")
-    mdist.init(args.backend)
+    if args.force_collectives:
+        mdist.FORCE_COLLECTIVES = True
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (as launch_ranks sets it for its children)
+        if world == 1:   # a one-rank group needs its own rendezvous: a free local port, nothing inherited
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    mdist.init(args.backend, force=args.force_collectives)
     n_ranks_seen = mdist.world_size()
     assert n_ranks_seen == world, (n_ranks_seen, world)
 
@@ -258,6 +304,8 @@ def main(argv=None):
         return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases, per_sample=hints)
 
     elapsed, img = timed_jobs(one_job, args.steps, args.warmup, dev)   # (returns after a device synchronise: img has landed)
+    if not stub:
+        check_job_flags()
     assert tuple(img.shape) == out_shape and img.dtype == torch.uint8 and (rank != 0 or img.device.type == "cpu")
 
     images = gb * args.steps
@@ -275,6 +323,8 @@ def main(argv=None):
         "launcher": os.environ.get("MSD_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "external" if world > 1 else "none"),
         "rank_devices": rank_devices(dev, world),
     }
+    if args.force_collectives:
+        out["collectives_forced"] = True   # broadcast + all-gather ran through the process group at every job, also at world 1
     if stub:
         # a self-test of launcher + broadcast + slicing + gather: NOT a measurement, and it says so in every field a reader uses
         out.update(metric="STUB launcher self-test (no GPU work; not a measurement)", dtype="none", data="stub", stub=True,
@@ -290,7 +340,7 @@ def main(argv=None):
         if args.sync_phases and phase.wall_ms:   # (profiling runs: host wall time per phase, device drained at each end)
             log("phase wall ms per job: " + ", ".join(f"{k} {v[0] / v[1]:.3f}" for k, v in phase.wall_ms.items()))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -365,7 +415,7 @@ def sharded_job(local, ctx, unc, noise, dev, sync_phases=False, per_sample=()):
         return to_host(img) if rank == 0 else img
 
 
-_host_out = {"bufs": [None, None], "i": 0}
+_host_out = {"bufs": [None, None], "i": 0, "flags": None}
 
 
 def to_host(img):
@@ -382,7 +432,26 @@ def to_host(img):
     if buf is None or buf.shape != img.shape:
         buf = _host_out["bufs"][k] = torch.empty(img.shape, dtype=img.dtype, pin_memory=True)
     buf.copy_(img, non_blocking=True)
+    # the cluster GroupNorm's give-up words (one 4-byte word per launch plan) are folded into a device accumulator behind
+    # every job and read ONCE, after the clock has stopped (check_job_flags): a job that ended with abandoned GroupNorm
+    # moments fails the run instead of being counted
+    from minsdtf_amd import engine
+
+    flags = engine.gn_sync_flags(img.device)
+    if flags is not None:
+        acc = _host_out["flags"]
+        if acc is None or acc.shape != flags.shape:
+            acc = _host_out["flags"] = torch.zeros_like(flags)
+        acc.bitwise_or_(flags)
     return buf
+
+
+def check_job_flags():
+    """After the timed region: raise if any job's cluster GroupNorm gave up (see to_host)."""
+    from minsdtf_amd import engine
+
+    if _host_out.get("flags") is not None:
+        engine.check_gn_sync(_host_out["flags"].cpu())
 
 
 def timed_jobs(one_job, steps, warmup, dev):

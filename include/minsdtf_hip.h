@@ -37,12 +37,20 @@ extern "C" {
 
 typedef void* msd_stream_t; /* hipStream_t */
 
-int msd_abi_version(void);
-const char* msd_last_error(void);
+/* The library is built with -fvisibility=hidden: the functions marked MSD_API below are its WHOLE dynamic symbol
+ * table (tests/test_host_cpu.py compares `nm -D --defined-only` with this header). */
+#if defined(__GNUC__) || defined(__clang__)
+#define MSD_API __attribute__((visibility("default")))
+#else
+#define MSD_API
+#endif
+
+MSD_API int msd_abi_version(void);
+MSD_API const char* msd_last_error(void);
 /* One-time per-process set-up (raises the dynamic-LDS limits of the kernels). Idempotent. */
-int msd_init(void);
+MSD_API int msd_init(void);
 /* Tuning / A-B switches, e.g. ("conv_dense", 0|1), ("attn_qf", 0|1|2|4), ("attn_form", 0|1|2). Returns MSD_E_ARG for an unknown key. */
-int msd_set_option(const char* key, int value);
+MSD_API int msd_set_option(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------
  * msd_conv_gemm — implicit-GEMM convolution / dense layer on MFMA (bf16 in, fp32 accumulate).
@@ -139,9 +147,9 @@ typedef struct MsdConvGemm {
 
 /* Number of row-moment partials per row a launch with these parameters writes to `ln_out`
  * (= its number of column tiles), or a negative MSD_E_* code. */
-int msd_conv_gemm_ln_slots(const MsdConvGemm* p);
+MSD_API int msd_conv_gemm_ln_slots(const MsdConvGemm* p);
 
-int msd_conv_gemm(const MsdConvGemm* p, msd_stream_t stream);
+MSD_API int msd_conv_gemm(const MsdConvGemm* p, msd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * msd_conv_direct — small-channel direct convolution / dense on vector FMAs (fp32 weights).
@@ -171,7 +179,7 @@ typedef struct MsdConvDirect {
     float in_scale;        /* input multiplier (VAE Rescaling 1/0.18215, image_decoder.py:27) */
 } MsdConvDirect;
 
-int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
+MSD_API int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * msd_group_norm — GroupNormalization(groups=32, eps) [+ swish], NHWC, fp32 statistics.
@@ -188,8 +196,12 @@ int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
  *             need a block each).  With it, tensors of >= 2048 pixels per sample whose group slab fits in registers run as
  *             ONE launch in which 2 / 4 / 8 workgroups share each (sample, group) and exchange their partial moments
  *             through this block (ticket counters + {value, epoch} words; the parts are summed in part order:
- *             bit-reproducible).  Word [8] of a 64-word slot is raised if a workgroup ever gave up waiting (never observed;
- *             the launch then ends with wrong numbers instead of hanging).  Without it: statistics + apply launches.
+ *             bit-reproducible).  GIVE-UP FLAG: the exchange poll is bounded (so that an out-of-order dispatch can never hang
+ *             the GPU); a workgroup that gives up sets word [8] of its 64-word slot AND word [8] of the block (sync[8]) to 1
+ *             and the launch ends with WRONG numbers in that group.  The return code cannot report it (the launch is
+ *             asynchronous), so the CALLER must read sync[8] once per job, after the work has completed, and treat a
+ *             non-zero word as a failed job (minsdtf_amd/engine.py: check_gn_sync raises HipExtensionError).  Never observed
+ *             under in-order dispatch.  Without `sync`: statistics + apply launches, no exchange, no flag.
  */
 #define MSD_GN_SYNC_WORDS_PER_SAMPLE (3 * 32 * 64)
 #define MSD_GN_MAX_CHUNKS 1024
@@ -209,11 +221,11 @@ typedef struct MsdGroupNorm {
     int64_t sync_words;
 } MsdGroupNorm;
 
-int msd_group_norm(const MsdGroupNorm* p, msd_stream_t stream);
+MSD_API int msd_group_norm(const MsdGroupNorm* p, msd_stream_t stream);
 
 /* msd_layer_norm — LayerNormalization(eps) over the last axis (diffusion_model.py:84-88).
  * x, out: bf16 [rows][c], c % 8 == 0, c <= 2048. */
-int msd_layer_norm(const void* x, const float* gamma, const float* beta, void* out, int32_t rows, int32_t c,
+MSD_API int msd_layer_norm(const void* x, const float* gamma, const float* beta, void* out, int32_t rows, int32_t c,
                    float eps, msd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -244,7 +256,7 @@ typedef struct MsdAttention {
                             not applied again.  0: softmax(scale * q k^T) as written above. */
 } MsdAttention;
 
-int msd_attention(const MsdAttention* p, msd_stream_t stream);
+MSD_API int msd_attention(const MsdAttention* p, msd_stream_t stream);
 
 /* msd_cross_attention_q — cross-attention over a short context with its query projection inside: the `attn2.to_q` Dense
  * (with the LayerNormalization in front of it folded in, as MsdConvGemm.ln_in does) and the attention over the text
@@ -270,23 +282,23 @@ typedef struct MsdCrossAttnQ {
     int32_t w_layout;        /* 0: [c][c] rows, 1: chunk-major [c/64][c][64] (MsdConvGemm.w_layout) */
 } MsdCrossAttnQ;
 
-int msd_cross_attention_q(const MsdCrossAttnQ* p, msd_stream_t stream);
+MSD_API int msd_cross_attention_q(const MsdCrossAttnQ* p, msd_stream_t stream);
 
 /* msd_softmax_rows — out[r, :cols] = softmax(scale * x[r, :cols]); x fp32 [rows][ld_in], out bf16
  * [rows][ld_out] (VAE single-head attention, layers.py:48-50). cols % 8 == 0. */
-int msd_softmax_rows(const float* x, void* out, int64_t rows, int32_t cols, int32_t ld_in, int32_t ld_out, float scale,
+MSD_API int msd_softmax_rows(const float* x, void* out, int64_t rows, int32_t cols, int32_t ld_in, int32_t ld_out, float scale,
                      msd_stream_t stream);
 
 /* msd_embedding_sum — out[r, :] = bf16(tok_table[tokens[r], :] + pos_table[positions[r], :]).
  * Replaces CLIPEmbedding.call (text_encoder.py:22-33): two Embedding lookups and their sum.
  * tables fp32 [vocab][dim] / [max_len][dim], tokens / positions int32 [rows], dim % 4 == 0; ids outside
  * their table are an argument error reported through `status` (device int32, set to 1; may be NULL). */
-int msd_embedding_sum(const int32_t* tokens, const int32_t* positions, const float* tok_table, const float* pos_table,
+MSD_API int msd_embedding_sum(const int32_t* tokens, const int32_t* positions, const float* tok_table, const float* pos_table,
                       void* out, int32_t rows, int32_t dim, int32_t vocab, int32_t max_len, int32_t* status,
                       msd_stream_t stream);
 
 /* msd_memset_zero — stream-ordered hipMemsetAsync(ptr, 0, bytes) (GroupNorm statistic slots). */
-int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream);
+MSD_API int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * msd_cfg_step — classifier-free guidance + guidance rescale + sampler step, fp32, one launch.
@@ -324,19 +336,19 @@ typedef struct MsdCfgStep {
     const float* noise_coef;
 } MsdCfgStep;
 
-int msd_cfg_step(const MsdCfgStep* p, msd_stream_t stream);
+MSD_API int msd_cfg_step(const MsdCfgStep* p, msd_stream_t stream);
 
 /* msd_add_bf16 — out = a + b elementwise on bf16. n % 8 == 0. */
-int msd_add_bf16(const void* a, const void* b, void* out, int64_t n, msd_stream_t stream);
+MSD_API int msd_add_bf16(const void* a, const void* b, void* out, int64_t n, msd_stream_t stream);
 /* msd_add_f32_bf16 — out = bf16(a + b), a / out bf16, b fp32, summed in fp32 (may run in place, out == a).  The ControlNet
  * residual adds of diffusion_model.py:230-234 when the 13 residuals arrive over the model boundary as fp32 arrays
  * (DiffusionModel.predict_on_batch); the fused device loop has no such launch: there the adds are the epilogue residual of
  * the ControlNet's own 1x1 "zero" convs (msd_conv_gemm with residual == out). n % 8 == 0. */
-int msd_add_f32_bf16(const void* a, const float* b, void* out, int64_t n, msd_stream_t stream);
+MSD_API int msd_add_f32_bf16(const void* a, const float* b, void* out, int64_t n, msd_stream_t stream);
 
 /* msd_cast_f32_to_bf16 / msd_cast_bf16_to_f32 — dtype conversion of a contiguous buffer. */
-int msd_cast_f32_to_bf16(const float* in, void* out, int64_t n, msd_stream_t stream);
-int msd_cast_bf16_to_f32(const void* in, float* out, int64_t n, msd_stream_t stream);
+MSD_API int msd_cast_f32_to_bf16(const float* in, void* out, int64_t n, msd_stream_t stream);
+MSD_API int msd_cast_bf16_to_f32(const void* in, float* out, int64_t n, msd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -438,7 +438,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #endif
 #define MSD_ASTAMP_WAVES 1
 static __device__ unsigned long long g_astamps[16 * 4096];
-extern "C" int msd_debug_stamps_attn(unsigned long long* host_out, int count) {
+extern "C" MSD_API int msd_debug_stamps_attn(unsigned long long* host_out, int count) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_astamps), sizeof(unsigned long long) * (size_t)count);
 }
 // (s_memtime returns through the scalar data cache: the stamps of a tile are only waited for — lgkmcnt — at the tile's end,
@@ -1643,7 +1643,7 @@ static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
 
 #ifdef MSD_STAMPS
 // (tools, `make stamps` library only: workgroups of the software-pipelined form the runtime expects to fit on one CU)
-extern "C" int msd_debug_attn32_occupancy(int d, int nw, int presc) {
+extern "C" MSD_API int msd_debug_attn32_occupancy(int d, int nw, int presc) {
     int n = -1;
 #define OCC(D_, NW_, P_)                                                                                            \
     if (d == D_ && nw == NW_ && presc == P_)                                                                        \

@@ -27,6 +27,7 @@ void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
 void msd_set_gn_cluster(int v);
+void msd_set_gn_poll_limit(int v);
 void msd_set_attn_qf(int v);
 void msd_set_xattn_nw(int v);
 void msd_set_attn_form(int v);
@@ -59,6 +60,11 @@ extern "C" int msd_set_option(const char* key, int value) {
     if (key && strcmp(key, "gn_cluster") == 0) {   // pixels per part of the cluster GroupNorm (P = pixels / this, a power of two <= 8) [default 256]; 0 = never
         if (value != 0 && (value < 64 || value > (1 << 20))) MSD_FAIL(MSD_E_ARG, "set_option: gn_cluster takes 0 or 64 .. 2^20 pixels per part");
         msd_set_gn_cluster(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "gn_poll_limit") == 0) {   // bound of the cluster GroupNorm's exchange poll [default 2^18]; tests of the give-up path shorten it
+        if (value < 1) MSD_FAIL(MSD_E_ARG, "set_option: gn_poll_limit takes a positive count");
+        msd_set_gn_poll_limit(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "gn_impl") == 0) {

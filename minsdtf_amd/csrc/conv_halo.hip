@@ -18,7 +18,7 @@
 #include "conv_common.h"
 
 #ifdef MSD_STAMPS
-extern "C" int msd_debug_stamps_halo(unsigned long long* host_out, int count) {
+extern "C" MSD_API int msd_debug_stamps_halo(unsigned long long* host_out, int count) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count);
 }
 #endif

@@ -363,11 +363,11 @@ __global__ __launch_bounds__(1024) void gn_group_kernel(const GNArgs p, int upp,
 // resident and every other resident group completes; should the dispatch ever be out of order the poll is BOUNDED (it gives
 // up, raises the block's error word and the launch finishes with wrong numbers instead of hanging the GPU).
 constexpr int GN_SYNC_WORDS_PER_SLOT = 64;   // [0] ticket, [8] error, [16..31] sum granules, [32..47] sum-of-squares granules
-constexpr int GN_POLL_LIMIT = 1 << 18;
+constexpr int GN_POLL_LIMIT = 1 << 18;   // default bound of the exchange poll (set_option "gn_poll_limit": tests shorten it)
 
 template <int NPT, int V>
 __global__ __launch_bounds__(1024) void gn_cluster_kernel(const GNArgs p, int upp, int ppp, uint32_t mg_upp, int pshift, int ppart,
-                                                          uint32_t* sync_region) {
+                                                          uint32_t* sync_region, int poll_limit) {
     typedef typename gn_vec<V>::type vec_t;
     __shared__ float red[16][2];
     __shared__ float s_stat[2];
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(const GNArgs p, int up
         epoch = __shfl(epoch, 0);
         unsigned long long va = 0, vq = 0;
         bool done = t >= P;
-        for (int it = 0; it < GN_POLL_LIMIT; ++it) {
+        for (int it = 0; it < poll_limit; ++it) {
             if (!done) {
                 va = __hip_atomic_load(ga + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 vq = __hip_atomic_load(gq + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -440,7 +440,9 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(const GNArgs p, int up
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        if (__builtin_amdgcn_ballot_w64(!done) != 0 && t == 0) blk[8] = 1u;   // gave up (never under in-order dispatch): flag it
+        // gave up (never under in-order dispatch): flag the slot AND word [8] of the whole block (= slot 0's error word), which is
+        // the ONE word a caller reads per job (minsdtf_amd/engine.py check_gn_sync raises HipExtensionError on it)
+        if (__builtin_amdgcn_ballot_w64(!done) != 0 && t == 0) { blk[8] = 1u; sync_region[8] = 1u; }
         float a = 0.f, q = 0.f;
         for (int j = 0; j < P; ++j) {   // fixed order: ((p0 + p1) + p2) + ...
             a += __uint_as_float((uint32_t)__shfl(va, j));
@@ -481,15 +483,18 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(const GNArgs p, int up
     }
 }
 
+static int g_gn_poll_limit = GN_POLL_LIMIT;
+void msd_set_gn_poll_limit(int v) { g_gn_poll_limit = v; }
+
 template <int V>
 static void gn_cluster_launch(const GNArgs& a, int upp, int npt, dim3 grid, int pshift, int ppart, uint32_t* region, hipStream_t stream) {
     const dim3 block(1024);
     const int ppp = 1024 / upp;
     const uint32_t mg = udiv_magic_of(upp);
-    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region);
-    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region);
-    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region);
-    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region);
+    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region, g_gn_poll_limit);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region, g_gn_poll_limit);
+    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region, g_gn_poll_limit);
+    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region, g_gn_poll_limit);
 }
 
 template <int V>

@@ -22,14 +22,22 @@ import torch
 import torch.distributed as dist
 
 
+# True: a process group of ONE rank still goes through the real collectives (packed device broadcast, all_gather_into_tensor)
+# instead of the single-process short cuts.  That is how the RCCL path is exercised on a one-GPU box (bench.py
+# --force-collectives, tests/test_rccl_gpu.py): library loading, dtype support and stream ordering against the captured
+# graph's stream are the same code at world 1 as at world 8.  $MSD_FORCE_COLLECTIVES=1 sets it at import.
+FORCE_COLLECTIVES = os.environ.get("MSD_FORCE_COLLECTIVES", "0") == "1"
+
+
 def env_rank() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend: Optional[str] = None) -> Tuple[int, int]:
-    """Initialise the default process group from the torchrun environment (no-op for 1 rank)."""
+def init(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int]:
+    """Initialise the default process group from the torchrun environment (no-op for 1 rank unless `force` /
+    FORCE_COLLECTIVES: then a one-rank group is created and the collectives below really run)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force or FORCE_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -43,7 +51,9 @@ def init(backend: Optional[str] = None) -> Tuple[int, int]:
 def shard_bounds(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous split; the global batch must divide evenly (weak scaling: fixed work per GPU)."""
     if global_batch % world:
-        raise ValueError(f"global batch {global_batch} is not divisible by {world} ranks")
+        raise ValueError(f"global batch {global_batch} is not divisible by the {world} ranks of the initialised torch.distributed "
+                         "process group: under a process group `batch_size` is the GLOBAL batch, sharded over the ranks; for "
+                         "independent replicas per rank set `shard_batch = False` on the StableDiffusion object")
     per = global_batch // world
     return rank * per, (rank + 1) * per
 
@@ -57,19 +67,27 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def collectives_on() -> bool:
+    """Whether the exchanges below go through torch.distributed: more than one rank, or one rank with FORCE_COLLECTIVES."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def broadcast_inputs(arrays, device, src: int = 0):
     """ONE broadcast from `src` of a list of fp32 arrays (same shapes on every rank; contents only matter on `src`),
     packed into a single flat device buffer; returns device-resident views of it, one per array — nothing comes back to
     the host (the denoise engine copies device -> device).  Single process: host inputs come back as fp32 numpy arrays,
     tensors as they are (so a caller sees the same kinds of object at world = 1 and world > 1: something with
     ``.shape`` that slices along the batch)."""
-    if world_size() == 1:
+    if not collectives_on():
         return [a if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float32) for a in arrays]
     shapes = [tuple(np.shape(a)) for a in arrays]
     sizes = [int(np.prod(sh)) for sh in shapes]
     if dist.get_rank() == src:
-        flat = np.concatenate([_host_f32(a).reshape(-1) for a in arrays])
-        buf = torch.from_numpy(flat).to(device)
+        if all(isinstance(a, torch.Tensor) and a.device == torch.device(device) for a in arrays):
+            buf = torch.cat([a.detach().reshape(-1).to(torch.float32) for a in arrays])   # already resident: packed on the device
+        else:
+            flat = np.concatenate([_host_f32(a).reshape(-1) for a in arrays])
+            buf = torch.from_numpy(flat).to(device)
     else:
         buf = torch.empty(sum(sizes), dtype=torch.float32, device=device)
     dist.broadcast(buf, src=src)
@@ -88,7 +106,7 @@ def _host_f32(a) -> np.ndarray:
 
 def all_gather_images(local: torch.Tensor) -> torch.Tensor:
     """[b, ...] per rank (uint8 images, or fp32 latents) -> [world*b, ...] on every rank, rank order = batch order."""
-    if world_size() == 1:
+    if not collectives_on():
         return local
     world = dist.get_world_size()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -111,7 +129,7 @@ def generate_sharded(generate_local: Callable[..., torch.Tensor], context, uncon
     r, world = (rank(), world_size()) if shard else (0, 1)
     n_ps = len(per_sample)
     arrays = [context, uncond_context, noise, *per_sample, *shared]
-    if world == 1:
+    if world == 1 and not (shard and collectives_on()):
         got = [a if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float32) for a in arrays]
         return generate_local(*got)
     got = broadcast_inputs(arrays, device)

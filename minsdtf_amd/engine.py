@@ -16,13 +16,14 @@ Topology sources (reference, paths relative to stable_diffusion/):
 from __future__ import annotations
 
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
-from . import ops, packing, tuning
+from . import _lib, ops, packing, tuning
 from . import weights as wtab
 
 EPS = 1e-5  # every normalisation layer of the reference uses epsilon=1e-5
@@ -201,6 +202,8 @@ class Plan:
             #  only its launches on this plan's stream ever touch them)
             self._gn_sync_buf = self._alloc_tail(self.gn_batch * ops.GN_SYNC_WORDS_PER_SAMPLE * 4)
         self.arena.materialize(self.device, self.high_water)
+        if self._gn_sync_buf is not None and torch.device(self.device).type == "cuda":
+            _gn_sync_plans.add(self)   # check_gn_sync() reads this plan's give-up word once per job
         self.calls = [r() for r in self.recs]
         self.recs = []
 
@@ -228,6 +231,43 @@ class Plan:
 
 
 TRACE = os.environ.get("MSD_TRACE", "0") == "1"
+
+# ---- give-up flag of the cluster GroupNorm (include/minsdtf_hip.h, msd_group_norm) --------------------------------------
+# A workgroup of gn_cluster_kernel that stops waiting for its group's partial moments sets word [8] of the plan's sync block
+# and the launch ends with wrong numbers.  A launch cannot return that, so every live plan's word is read ONCE PER JOB, after
+# the job's work has completed (one 4-byte word per plan, gathered by one tiny copy kernel, outside any captured graph), and
+# a non-zero word raises: the pipeline never returns an image computed from abandoned moments with a clean return code.
+_gn_sync_plans: "weakref.WeakSet[Plan]" = weakref.WeakSet()
+GN_GIVE_UP_WORD = 8
+
+
+def gn_sync_flags(device=None) -> Optional[torch.Tensor]:
+    """Device int32 tensor with the give-up word of every live plan on `device` that owns a cluster-GroupNorm sync block
+    (None when there is none).  Stream-ordered: queue it behind the job, copy it with the job's D2H, hand it to
+    check_gn_sync() once the copy has landed."""
+    plans = [p for p in _gn_sync_plans if device is None or torch.device(p.device) == torch.device(device)]
+    if not plans:
+        return None
+    words = [p._gn_sync_buf.tensor(torch.int32, (GN_GIVE_UP_WORD + 1,))[GN_GIVE_UP_WORD:] for p in plans]
+    return torch.cat(words)
+
+
+def check_gn_sync(flags=None, device=None) -> None:
+    """Raise HipExtensionError if any cluster GroupNorm launch since the last check gave up (`flags`: the HOST copy of a
+    gn_sync_flags() tensor; None = read them now, synchronously).  The words are cleared when they are reported."""
+    if flags is None:
+        dev_flags = gn_sync_flags(device)
+        if dev_flags is None:
+            return
+        flags = dev_flags.cpu()
+    if int(flags.max()) == 0:
+        return
+    for p in list(_gn_sync_plans):
+        p._gn_sync_buf.tensor(torch.int32, (GN_GIVE_UP_WORD + 1,))[GN_GIVE_UP_WORD].zero_()
+    raise _lib.HipExtensionError(
+        "msd_group_norm: a workgroup of the cluster GroupNorm gave up waiting for its group's partial moments (sync word [8] "
+        "set): this job's result is wrong and has been discarded.  The one-workgroup-per-group path has no exchange: "
+        "msd_set_option('gn_cluster', 0)")
 
 
 def _block_of(call_name: str) -> str:

@@ -292,6 +292,18 @@ class _BoundPlan:
             self.graph = g
         self.graph.replay()
 
+    def host(self, name):
+        """Boundary tensor `name` (or a list of names) as host array(s) — the duck type's D2H — followed by this plan's
+        cluster-GroupNorm give-up word (engine.check_gn_sync: 4 more bytes on a stream the copy has just drained); raises
+        instead of returning a result computed from abandoned moments."""
+        names = [name] if isinstance(name, str) else list(name)
+        out = [self.io[n].cpu().numpy() for n in names]
+        buf = self.plan._gn_sync_buf
+        if buf is not None and self.io[names[0]].device.type == "cuda":
+            word = buf.tensor(torch.int32, (engine.GN_GIVE_UP_WORD + 1,))[engine.GN_GIVE_UP_WORD:]
+            engine.check_gn_sync(word.cpu())
+        return out[0] if isinstance(name, str) else out
+
 
 def _np32(x) -> np.ndarray:
     if isinstance(x, torch.Tensor):
@@ -362,7 +374,7 @@ class DiffusionModel(HipModel):
         for i, c in enumerate(controls):
             bp.io[f"control.{i}"].copy_(torch.from_numpy(c))
         bp.run()
-        return bp.io["eps"].cpu().numpy()
+        return bp.host("eps")
 
     __call__ = predict_on_batch
 
@@ -399,7 +411,7 @@ class ImageDecoder(HipModel):
         bp = self._bound((B, h, w, False), lambda: self._build(B, h, w, False))
         bp.io["latent"].copy_(torch.from_numpy(latent))
         bp.run()
-        return bp.io["image"].cpu().numpy()
+        return bp.host("image")
 
     def decode_to_uint8(self, latent_dev: torch.Tensor) -> torch.Tensor:
         """Device-resident variant used by the fused pipeline: fp32 latent tensor on the GPU ->
@@ -460,7 +472,7 @@ class ControlNet(HipModel):
         for k, v in (("latent", latent), ("t_emb", t_emb), ("context", context), ("hint", hint)):
             bp.io[k].copy_(torch.from_numpy(v))
         bp.run()
-        return [bp.io[f"out.{i}"].cpu().numpy() for i in range(13)]
+        return bp.host([f"out.{i}" for i in range(13)])
 
     __call__ = predict_on_batch
 
@@ -494,7 +506,7 @@ class HintNet(HipModel):
         bp = self._bound((B,), lambda: self._build(B))
         bp.io["image"].copy_(torch.from_numpy(img))
         bp.run()
-        return bp.io["hint"].cpu().numpy()
+        return bp.host("hint")
 
     __call__ = predict_on_batch
 
@@ -540,7 +552,7 @@ class ImageEncoder(HipModel):
         bp = self._bound((B, H, Wd), lambda: self._build(B, H, Wd))
         bp.io["image"].copy_(torch.from_numpy(img))
         bp.run()
-        return bp.io["latent"].cpu().numpy()
+        return bp.host("latent")
 
     __call__ = predict_on_batch
 
@@ -590,7 +602,7 @@ class TextClipEmbedding(HipModel):
         if int(bp.io["status"].item()):
             bp.io["status"].zero_()
             raise ValueError("token / position id outside the embedding table")
-        return bp.io["emb"].cpu().numpy()
+        return bp.host("emb")
 
     __call__ = predict_on_batch
 
@@ -641,6 +653,6 @@ class TextEncoder(HipModel):
         bp = self._bound((B, T), lambda: self._build(B, T))
         bp.io["emb"].copy_(torch.from_numpy(emb))
         bp.run()
-        return bp.io["context"].cpu().numpy()
+        return bp.host("context")
 
     __call__ = predict_on_batch

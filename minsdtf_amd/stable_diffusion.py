@@ -228,7 +228,8 @@ class DenoiseEngine:
         if len(self.passes) == 1:
             if isinstance(context, torch.Tensor) or isinstance(unconditional_context, torch.Tensor):
                 u, c = _f32_tensor(unconditional_context), _f32_tensor(context)
-                return {"both": torch.cat([u.to(c.device) if isinstance(context, torch.Tensor) else u, c.to(u.device)], dim=0)}
+                dev = c.device if isinstance(context, torch.Tensor) else u.device   # ONE target: the tensor argument's device
+                return {"both": torch.cat([u.to(dev), c.to(dev)], dim=0)}
             return {"both": np.concatenate([unconditional_context, context], axis=0)}
         return {"uncond": unconditional_context, "cond": context}
 
@@ -332,9 +333,11 @@ class DenoiseEngine:
         self.latent.copy_(_f32_tensor(noise))
         # the schedule's tables: uploaded when the schedule changes, not per call (pageable host -> device copies make the
         # host wait for the stream, which keeps it from queueing this job behind the previous one's last kernels)
-        sched_key = (tuple(int(t) for t in scheduler.timesteps), bool(getattr(scheduler, "active_tcd", False)))
+        # (keyed by the table's VALUES: a scheduler with other betas / final alpha / eta on the same timesteps is another schedule)
+        coef = scheduler.coefficient_table()
+        sched_key = (tuple(int(t) for t in scheduler.timesteps), bool(getattr(scheduler, "active_tcd", False)), coef.tobytes())
         if self._sched_key != sched_key:
-            self.coef.copy_(torch.from_numpy(scheduler.coefficient_table()))
+            self.coef.copy_(torch.from_numpy(coef))
             temb = np.concatenate([get_timestep_embedding(int(t), 1) for t in scheduler.timesteps], axis=0)
             self.temb_in.copy_(torch.from_numpy(np.ascontiguousarray(temb, dtype=np.float32)))
             self.prep_t.run(torch.cuda.current_stream().cuda_stream)
@@ -729,7 +732,11 @@ class StableDiffusionBase:
 
         out = mdist.generate_sharded(local, context, unconditional_context, start_latent, dev,
                                      per_sample=list(per_sample.values()), shared=list(shared.values()), shard=world > 1)
-        return out.cpu().numpy()
+        flags = engine.gn_sync_flags(dev) if out.device.type == "cuda" else None   # queued behind the job, read with its D2H
+        host = out.cpu().numpy()
+        if flags is not None:
+            engine.check_gn_sync(flags.cpu())   # a cluster GroupNorm that gave up: raise, never return that image
+        return host
 
     def _engine(self, B, tc, tu, steps, g, phi, control, inpaint=False) -> DenoiseEngine:
         # the engine's plans (and captured hipGraphs) hold raw addresses of the packed weights: a set_weights() /

@@ -315,3 +315,17 @@ def test_bench_launcher_reports_a_failed_rank():
     r = _run_bench("--gpus", "2", "--steps", "1")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+
+
+@pytest.mark.timeout(120)
+def test_forced_collectives_world1_gloo():
+    """The one-rank process group with its exchanges forced through torch.distributed (dist.FORCE_COLLECTIVES): the CPU twin
+    (gloo) of tests/test_rccl_gpu.py — the same child script, minus the GPU pipeline."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "_collectives_world1_child.py"), "gloo"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=110)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert any(ln.startswith("OK ") for ln in p.stdout.splitlines())

@@ -376,6 +376,25 @@ def test_tuning_table_pins_one_numerics_class_per_layer():
     assert h1[1:3] == h5[1:3]
 
 
+def test_engine_contexts_accept_mixed_host_and_device_inputs():
+    """DenoiseEngine.contexts: `context` a device tensor and `unconditional_context` a host array (or the reverse) end up as
+    ONE concat on the tensor's device (the "meta" device stands in for the GPU: nothing can be copied OUT of it, which is
+    what the earlier form tried)."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from minsdtf_amd.stable_diffusion import DenoiseEngine
+
+    eng = SimpleNamespace(cfg=True, passes=[None])
+    host = np.zeros((1, 77, 768), dtype=np.float32)
+    on_dev = torch.empty(1, 77, 768, device="meta")
+    for u, c in ((host, on_dev), (on_dev, host), (on_dev, on_dev)):
+        both = DenoiseEngine.contexts(eng, u, c)["both"]
+        assert both.device.type == "meta" and tuple(both.shape) == (2, 77, 768)
+    assert isinstance(DenoiseEngine.contexts(eng, host, host)["both"], np.ndarray)
+
+
 # ------------------------------------------------------------------ the C ABI
 def test_library_exports_every_declared_symbol():
     """libminsdtf_hip.so loads and exports exactly what include/minsdtf_hip.h declares."""
@@ -383,8 +402,15 @@ def test_library_exports_every_declared_symbol():
 
     assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
     header = open(os.path.join(ROOT, "include", "minsdtf_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(msd_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^MSD_API\s+(?:int|const char\*)\s+(msd_\w+)\s*\(", header, flags=re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert not re.search(r"^(?:int|const char\*)\s+msd_\w+\s*\(", header, flags=re.M), "a declaration without MSD_API"
+    # the dynamic symbol table is the header and nothing else (built with -fvisibility=hidden + csrc/exports.map: no mangled
+    # C++ internals, no kernel handles)
+    import subprocess
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)

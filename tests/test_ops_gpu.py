@@ -569,6 +569,49 @@ def test_group_norm_cluster(gpu, case):
         lib.msd_set_option(b"gn_cluster", 256)
 
 
+def test_group_norm_cluster_give_up_is_loud(gpu):
+    """The cluster GroupNorm's bounded poll (norm.hip gn_cluster_kernel) must never end in a silently wrong image: a ticket
+    counter knocked off its multiple-of-P phase makes one workgroup of a group wait for an epoch nobody publishes; it gives
+    up (poll bound shortened through set_option so the test takes milliseconds), raises word [8] of the sync block, and the
+    engine's once-per-job check (engine.check_gn_sync) turns that into HipExtensionError and clears the word."""
+    from minsdtf_amd import _lib, engine, ops
+
+    lib = _lib.load()
+    B, H, W, C = 1, 64, 64, 320
+    plan = engine.Plan(gpu)
+    e = engine.Emitter(plan, {"n.g": torch.ones(C, device=gpu), "n.b": torch.zeros(C, device=gpu)})
+    x = plan.act(B, H, W, C)
+    y = e.group_norm(x, "n", True)
+    plan.finalize()
+    x.buf.tensor(torch.bfloat16, (B, H * W, C)).copy_(torch.randn(B, H * W, C, device=gpu).to(torch.bfloat16))
+    st = torch.cuda.current_stream().cuda_stream
+    plan.run(st)
+    torch.cuda.synchronize()
+    engine.check_gn_sync(device=gpu)                     # a healthy launch: nothing raised
+    good = y.buf.tensor(torch.bfloat16, (B, H * W, C)).clone()
+    words = plan._gn_sync_buf.tensor(torch.int32, (B * ops.GN_SYNC_WORDS_PER_SAMPLE,)).view(-1, 64)
+    used = torch.nonzero(words[:, 0]).flatten()
+    assert used.numel() == 32, "the cluster form did not run (one ticket counter per group expected)"
+    P = int(words[used[5], 0])                           # one launch added exactly P to the counter
+    assert P in (2, 4, 8)
+    words[used[5], 0] += 1                               # group 5: the P tickets of the next launch straddle two epochs
+    lib.msd_set_option(b"gn_poll_limit", 256)
+    try:
+        plan.run(st)
+        torch.cuda.synchronize()
+        assert int(words[0, engine.GN_GIVE_UP_WORD]) == 1 and int(words[used[5], engine.GN_GIVE_UP_WORD]) == 1
+        with pytest.raises(_lib.HipExtensionError, match="gave up"):
+            engine.check_gn_sync(device=gpu)
+        assert int(words[0, engine.GN_GIVE_UP_WORD]) == 0        # reported once, then cleared
+        engine.check_gn_sync(device=gpu)
+        # the groups that were not disturbed still carry the right numbers
+        got = y.buf.tensor(torch.bfloat16, (B, H * W, C))
+        assert torch.equal(got[..., :50].view(torch.int16), good[..., :50].view(torch.int16))
+    finally:
+        lib.msd_set_option(b"gn_poll_limit", 1 << 18)
+        words[used[5], 0] += P - 1                       # back on a multiple of P (the plan dies with the test anyway)
+
+
 @pytest.mark.parametrize("B,S,spike", [(1, 4096, False), (2, 320, True), (1, 9216, False), (1, 64, False), (3, 200, False)])
 def test_attention_d512(gpu, B, S, spike):
     """VAE AttentionBlock (layers.py:28-59): single head, d = 512, softmax(q k^T / sqrt(512)) v with the scores kept on
@@ -640,7 +683,7 @@ def test_attention_partial_round_split(gpu):
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "the two-launch form changed the bits"
 
 
-@pytest.mark.parametrize("case", [
+ATTENTION_CASES = [
     dict(B=2, H=8, d=40, S=256, T=256),
     dict(B=1, H=8, d=40, S=1024, T=1024),
     dict(B=2, H=8, d=80, S=128, T=77),       # text cross-attention: ragged key tail
@@ -655,10 +698,30 @@ def test_attention_partial_round_split(gpu):
     dict(B=1, H=1, d=40, S=4090, T=4090),              # long walk ending in a ragged query tile AND a ragged key tile
     dict(B=1, H=2, d=80, S=64, T=257, spike=True),     # software-pipelined form: shortest walk it takes + a 1-key ragged tile; one busy wave
     dict(B=3, H=3, d=40, S=300, T=256),                # ... exactly four tiles (the ring's depth), odd batch x heads, ragged queries
-])
-@pytest.mark.parametrize("qf", [2, 1, 4])   # 128 / 64 / 256 queries per workgroup (the library picks by grid size; all forced here; 256: software-pipelined d = 40 only)
-@pytest.mark.parametrize("presc", [False, True])   # q carrying scale*log2(e) already (the UNet's projections) or not
-@pytest.mark.parametrize("form", [2, 1, 0])   # d = 40 / 80: the 32x32x16 MFMA kernel, software-pipelined (2) or plain (1), or the 16x16x32 one (0); other head sizes: 16x16x32 either way
+]
+
+
+def _attention_params():
+    """(case, qf, presc, form) without duplicates: qf = 128 / 64 / 256 queries per workgroup (the library picks by grid size; all
+    forced here; 256 exists in the software-pipelined d = 40 form only, on key walks of 4 tiles and more); presc = q carrying
+    scale * log2(e) already (the UNet's projections) or not; form, d = 40 / 80: the 32x32x16 MFMA kernel, software-pipelined (2) or
+    plain (1), or the 16x16x32 one (0) — other head sizes run the 16x16x32 kernel whatever the form says, and the long walks are
+    checked on one 16x16x32 form only (the CPU reference is the expensive part), so those combinations are not generated."""
+    out = []
+    for case in ATTENTION_CASES:
+        for form in (2, 1, 0):
+            if form != 1 and (case["d"] not in (40, 80) or (form == 0 and case["S"] > 2048)):
+                continue
+            for presc in (False, True):
+                for qf in (2, 1, 4):
+                    if qf == 4 and not (form == 2 and case["d"] == 40 and case["T"] >= 256):
+                        continue
+                    out.append(pytest.param(case, qf, presc, form, id=f"form{form}-presc{int(presc)}-qf{qf}-" +
+                                            "-".join(f"{k}{int(v)}" for k, v in case.items())))
+    return out
+
+
+@pytest.mark.parametrize("case,qf,presc,form", _attention_params())
 def test_attention(gpu, case, qf, presc, form):
     """The lazy rescale (attention.hip ATTN_THR) is a rare data-dependent branch: the `spike` cases force it at chosen
     tiles (one key row scaled so the tile maximum jumps far past the threshold), `ramp` makes the maximum grow by
@@ -696,10 +759,6 @@ def test_attention(gpu, case, qf, presc, form):
     kd = k.to(torch.bfloat16).to(gpu)
     call = ops.attention(q=qbuf.data_ptr() + 2 * C, k=kd, vt=vt, out=out, batch=B, heads=H,
                          head_dim=d, s=S, t=T, q_ld=3 * C, k_ld=C, vt_ld=Tp, o_ld=C, scale=scale, q_prescaled=presc)
-    if form != 1 and (d not in (40, 80) or (form == 0 and S > 2048)):
-        pytest.skip("the same kernel as form 1 (or a long CPU reference already spent on it)")
-    if qf == 4 and not (form == 2 and d == 40 and T >= 256):
-        pytest.skip("256 queries per workgroup exist in the software-pipelined d = 40 form only (key walks of 4 tiles and more)")
     _lib.load().msd_set_option(b"attn_qf", qf)
     _lib.load().msd_set_option(b"attn_form", form)
     try:

@@ -22,7 +22,40 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--controlnet", action="store_true")
+    ap.add_argument("--calls-json", default=None,
+                    help="write, in launch order, the algorithmic FLOP of every msd_conv_gemm call this process makes and the "
+                         "shader clock sampled from sysfs while the steps run (tools/pmc_mfma.py joins it with the kernel trace)")
     args = ap.parse_args()
+    conv_log, clk = [], {"mhz": [], "stop": False}
+    if args.calls_json:
+        from minsdtf_amd import _lib, ops
+
+        orig_call = ops.Call.__call__
+
+        def logged(self, stream):   # every library call passes here: record the conv / dense ones (M, N, K, split-K)
+            s = self.keep
+            if isinstance(s, _lib.MsdConvGemm):
+                K = s.ksize * s.ksize * (s.c0 + s.c1) + s.c2 + s.c3
+                M = s.batch * s.h_out * s.w_out
+                conv_log.append({"name": self.name, "M": M, "N": s.N, "K": K, "splitk": int(s.splitk), "flop": 2.0 * M * s.N * K})
+            return orig_call(self, stream)
+
+        ops.Call.__call__ = logged
+
+        def sample_clock():   # current sclk level of every card (the line marked '*'), a few times per millisecond of work
+            import glob
+            import time
+
+            files = glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")
+            while not clk["stop"]:
+                for fn in files:
+                    try:
+                        for ln in open(fn):
+                            if "*" in ln:
+                                clk["mhz"].append(float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+                    except (OSError, ValueError, IndexError):
+                        pass
+                time.sleep(0.002)
     size, steps, B = args.size, 25, args.batch
     dev = torch.device("cuda:0")
     sd = StableDiffusion(size, size, jit_compile=False, device=dev)
@@ -39,8 +72,24 @@ def main():
     sd.scheduler.set_timesteps(steps)
     eng = sd._engine(B, 77, 77, steps, 7.5, 0.7, args.controlnet)
     eng.prepare(eng.contexts(unc, ctx), noise, sd.scheduler, None, 0, hint)
+    if args.calls_json:
+        import threading
+
+        th = threading.Thread(target=sample_clock, daemon=True)
+        th.start()
+    n_before = len(conv_log)
     eng.run_steps(2, None)
     torch.cuda.synchronize()
+    if args.calls_json:
+        import json
+
+        clk["stop"] = True
+        th.join(timeout=1)
+        mhz = sorted(clk["mhz"])
+        with open(args.calls_json, "w") as f:
+            json.dump({"conv_calls": conv_log, "first_step_call": n_before,
+                       "sclk_mhz_samples": len(mhz), "sclk_mhz_median": mhz[len(mhz) // 2] if mhz else None,
+                       "sclk_mhz_min": mhz[0] if mhz else None, "sclk_mhz_max": mhz[-1] if mhz else None}, f)
     print("done", float(eng.latent.abs().mean()))
 
 
