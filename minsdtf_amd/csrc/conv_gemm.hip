@@ -324,6 +324,8 @@ static const TileCfg g_cfgs[] = {
 constexpr int NUM_TILE_CFGS = 19;
 
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream);
+int msd_conv_wreg_nj(int bm, int bn, int stages);   // 16-column blocks per wave of a built configuration, 0: not built
+int msd_conv_wreg_launch(const CGArgs& a, int bm, int bn, int stages, int slices, bool dense, hipStream_t stream);
 bool msd_conv_rowpanel_eligible(const CGArgs& a, int rows, int wg_cols);
 int msd_conv_rowpanel_launch(CGArgs a, int rows, int wg_cols, hipStream_t stream);
 
@@ -351,6 +353,7 @@ int msd_conv_gemm_init() {
 
 // tile width the launch will use (same rules as msd_conv_gemm below)
 static int cg_effective_bn(const MsdConvGemm* q) {
+    if (q->tile_m >= 4000) return q->tile_n;      // wreg form (conv_wreg.hip): the request IS the tile (the launch fails if it is not built)
     int bn = q->tile_m >= 3000 ? 64 : q->tile_n;   // (a row-panel request that is not eligible runs on the 128x64 tile)
     if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
     if (bn == 80 && q->act == MSD_ACT_GEGLU) bn = 64;
@@ -459,7 +462,13 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     }
     // (again, with the shortcut channels in K: the weight loader's 32-bit byte offsets are n * K * 2 + ...)
     if ((long long)a.N * a.K * 2 >= (1ll << 32) - 4096) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: an operand of 4 GB or more");
-    if (q->w_layout != 0 && q->w_layout != 1) MSD_FAIL(MSD_E_ARG, "conv_gemm: w_layout %d", q->w_layout);
+    if (q->w_layout < 0 || q->w_layout > 2) MSD_FAIL(MSD_E_ARG, "conv_gemm: w_layout %d", q->w_layout);
+    const bool wreg = q->tile_m >= 4000 && q->tile_m < 5000;
+    if (wreg != (q->w_layout == 2))
+        MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_m %d with w_layout %d (the fragment-major weight image, w_layout 2, is read by the wreg form, tile_m 4000 + rows, and by nothing else)",
+                 q->tile_m, q->w_layout);
+    if (wreg && ((q->N % 16) || !msd_conv_wreg_nj(q->tile_m - 4000, q->tile_n, q->stages)))
+        MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: no wreg configuration %d x %d stages %d (N %% 16 must be 0: N = %d)", q->tile_m - 4000, q->tile_n, q->stages, q->N);
     a.w_rs = q->w_layout ? 128u : (uint32_t)a.K * 2u;
     a.w_ks = q->w_layout ? (uint32_t)a.N * 128u : 128u;
     a.ln_in = q->ln_in; a.ln_colsum = q->ln_colsum; a.ln_out = q->ln_out;
@@ -533,6 +542,27 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         rc = msd_conv_rowpanel_launch(a, q->tile_m - 3000, q->tile_n, stream);
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
+        return MSD_OK;
+    }
+    if (wreg) {   // weights global -> VGPR in fragment order, activations through the LDS ring: conv_wreg.hip
+        const int wbm = q->tile_m - 4000, wbn = q->tile_n;
+        if (q->act == MSD_ACT_GEGLU && (msd_conv_wreg_nj(wbm, wbn, q->stages) % 2)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: GEGLU needs x | gate fragment pairs per wave");
+        a.tiles_m = (a.M + wbm - 1) / wbm;
+        a.tiles_n = (a.N + wbn - 1) / wbn;
+        a.m_fast = (a.N > a.M) ? 1 : 0;
+        a.mg_tdiv = udiv_magic_of(a.m_fast ? a.tiles_m : a.tiles_n);
+        a.mg_tps = a.mg_tx = 0;
+        const bool needs_dense = q->ln_in || q->act == MSD_ACT_GEGLU || q->split_mode;
+        const bool dense = !q->rowvec && !q->a2 && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in;
+        if (needs_dense && !dense)
+            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold, GEGLU and the q|k|v^T split run on the 1x1 / Dense form only");
+        rc = msd_conv_wreg_launch(a, wbm, wbn, q->stages, slices, dense, stream);
+        if (rc) return rc;
+        MSD_CHECK_LAUNCH();
+        if (slices > 1) {
+            launch_finalize(a, slices, stream);
+            MSD_CHECK_LAUNCH();
+        }
         return MSD_OK;
     }
     int cfg = -1;

@@ -384,6 +384,10 @@ class Emitter:
             wn = wkey or name
             kw.update(w=self.W[wn + ".lnw"], bias=self.W[wn + ".lnb"], ln_in=ln_in[0], ln_in_slots=ln_in[1],
                       ln_colsum=self.W[wn + ".lncs"], ln_eps=EPS, w_layout=self.w_layout(wn + ".lnw"))
+        if tile_m >= 4000:   # wreg form (csrc/conv_wreg.hip): reads the fragment-major image of the same matrix
+            wk = (wkey or name) + (".lnw" if ln_in is not None else ".w")
+            frag = getattr(self.W, "fragment_major", None)
+            kw.update(w=frag(wk) if frag is not None else self.W[wk], w_layout=2)
         if ln_out:
             slots = ops.conv_gemm_ln_slots(N=N, tile_n=tile_n, tile_m=tile_m, ksize=ksize, act=act)
             out.ln = (p.alloc(M * slots * 8), slots)

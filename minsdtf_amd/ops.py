@@ -79,7 +79,7 @@ def conv_gemm(*, a0, w, out, batch, h_in, w_in, c0, N, a1=None, c1=0, ksize=1, s
     s.ln_in, s.ln_colsum, s.ln_out = _p(ln_in), _p(ln_colsum), _p(ln_out)
     s.ln_in_slots, s.ln_out_slots, s.ln_eps = ln_in_slots, ln_out_slots, float(ln_eps)
     s.a2, s.a3, s.c2, s.c3 = _p(a2), _p(a3), c2, c3   # shortcut operand: extra K tiles read at the output pixel
-    s.w_layout = int(w_layout)   # 0: [N][K]; 1: chunk-major [K/64][N][64] (pack.chunk_major)
+    s.w_layout = int(w_layout)   # 0: [N][K]; 1: chunk-major [K/64][N][64] (packing.chunk_major); 2: fragment-major (packing.fragment_major)
     return Call(lib.msd_conv_gemm, (C.byref(s),), name, keep=s)
 
 

@@ -28,6 +28,7 @@ class PackedWeights(dict):
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.chunk_major_keys = set()
+        self._fragment = {}   # key -> fragment-major copy (w_layout 2), made when a launch plan first asks for it
 
     def layout(self, key: str) -> int:
         return 1 if key in self.chunk_major_keys else 0
@@ -38,6 +39,37 @@ class PackedWeights(dict):
             return   # (a K that is no multiple of 64 stays in rows: the kernels take either layout)
         self[key] = chunk_major(t)
         self.chunk_major_keys.add(key)
+
+
+    def fragment_major(self, key: str) -> torch.Tensor:
+        """The fragment-major image (MsdConvGemm.w_layout = 2, fragment_major below) of weight matrix `key`, for the launches
+        the tuning table sends to the wreg form (csrc/conv_wreg.hip).  A second copy beside the stored one, made on first use and
+        kept: which kernel reads a matrix is a per-(shape, batch) decision of the table, the other forms (halo, row-panel, the
+        fused cross-attention) read rows or chunk-major, and 1.7 GB of weights are nothing in 288 GB of HBM."""
+        t = self._fragment.get(key)
+        if t is None:
+            w = self[key]
+            if key in self.chunk_major_keys:   # [K/64][N][64] -> [N][K]
+                w = w.permute(1, 0, 2).reshape(w.shape[1], -1)
+            t = self._fragment[key] = fragment_major(w)
+        return t
+
+
+FRAGMENT_ROW_ORDER = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)   # MFMA row r <- weight row of the 16-column block (cg_wrow, conv_common.h)
+
+
+def fragment_major(w_nk: torch.Tensor) -> torch.Tensor:
+    """[N][K] -> [K/64][N/16][2][64 lanes][8] (MsdConvGemm.w_layout = 2): the operand registers of `v_mfma_f32_16x16x32_bf16`
+    laid out in memory.  Lane l = 16 g + r of the fragment (K tile kt, column block nb, half ks) holds the 8 values
+    W[16 nb + FRAGMENT_ROW_ORDER[r]][64 kt + 32 ks + 8 g .. + 8], so a wave loads a fragment as ONE contiguous, aligned KiB
+    (global_load_dwordx4, lane l at byte 16 l) and a wave's NJ column blocks of a K tile are 2 NJ consecutive KiB.  Same
+    values, same K order as the row / chunk-major layouts: a launch that reads it (csrc/conv_wreg.hip) computes the same bits."""
+    n, k = w_nk.shape
+    assert n % 16 == 0 and k % 64 == 0, (n, k)
+    order = torch.tensor(FRAGMENT_ROW_ORDER, device=w_nk.device)
+    w = w_nk.reshape(n // 16, 16, k)[:, order, :]                       # (nb, r, k)
+    w = w.reshape(n // 16, 16, k // 64, 2, 4, 8)                        # (nb, r, kt, ks, g, e)
+    return w.permute(2, 0, 3, 4, 1, 5).contiguous()                     # (kt, nb, ks, g, r, e)
 
 
 def chunk_major(w_nk: torch.Tensor) -> torch.Tensor:

@@ -31,6 +31,12 @@ HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (125
               (1128, 64, 63), (1128, 80, 63))   # 60 + depth: ... staged by two loader waves behind the compute waves
 
 
+# (4000 + rows per workgroup, columns per workgroup, ring depth [+ 10: 8 waves]): wreg form (csrc/conv_wreg.hip) — weights global ->
+# VGPR from the fragment-major image, every wave owns all rows and its own 16-column blocks
+WREG_TILES = ((4128, 128, 3), (4128, 128, 4), (4128, 64, 3), (4128, 64, 4), (4064, 128, 3), (4064, 128, 4), (4064, 256, 3), (4064, 256, 4),
+              (4064, 64, 4), (4256, 64, 3), (4128, 128, 13))
+
+
 # (rows per workgroup + 3000, columns per workgroup): row-panel Dense kernel (csrc/conv_rowpanel.hip) for the LayerNorm-
 # consumer GEMMs of the transformer blocks (K = 320 / 640, 128 rows per workgroup)
 ROWPANEL_ROWS = {320: (3128,), 640: (3128,)}
@@ -105,8 +111,10 @@ def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int, ln_produce
     the column tile (how the moments are grouped into partials).  `ln_producer` = False for the shapes that never do — the
     GEGLU and q|k|v projections, the keys ending in "n": their column tile orders nothing.  The table holds ONE class per
     layer shape for all batch sizes (tools/tune_conv.py)."""
-    if tile_m >= 3000:   # row-panel Dense kernel: the tile kernel's bits (a launch it cannot take runs on the 128x64 tile)
+    if 3000 <= tile_m < 4000:   # row-panel Dense kernel: the tile kernel's bits (a launch it cannot take runs on the 128x64 tile)
         return (False, splitk, 64 if (ksize == 1 and ln_producer) else 0)
+    if tile_m >= 4000:   # wreg form: the tile kernel's K walk and epilogue, partials per column tile as requested
+        return (False, splitk, tile_n if (ksize == 1 and ln_producer) else 0)
     return (tile_m >= 1000, splitk, tile_n if (ksize == 1 and ln_producer) else 0)
 
 

@@ -102,6 +102,24 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=8, W=16, c0=320, N=320, ks=3, tile_m=1128, tile_n=80, stages=63, same_as=(1128, 80, 0)),
     dict(B=1, H=16, W=32, c0=64, c1=64, N=100, ks=3, tile_m=1128, tile_n=64, stages=63, same_as=(1128, 64, 0)),
     dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, stages=63, splitk=2),
+    # wreg form (conv_wreg.hip; tile_m 4000 + rows): weights global -> VGPR from the fragment-major image (w_layout 2), all waves
+    # split over N; the tile kernel's K walk and epilogue, so its bits
+    dict(B=2, H=16, W=16, c0=64, N=128, ks=3, tile_m=4128, tile_n=128, stages=3, same_as=(128, 128, 0)),
+    dict(B=2, H=12, W=20, c0=128, N=192, ks=3, tile_m=4128, tile_n=128, stages=4, same_as=(128, 128, 0)),      # ragged M (480) and N (1.5 tiles)
+    dict(B=1, H=16, W=16, c0=320, N=320, ks=1, tile_m=4128, tile_n=64, stages=3, same_as=(128, 64, 0)),        # dense loader, one block per wave
+    dict(B=1, H=16, W=16, c0=320, N=320, ks=1, tile_m=4128, tile_n=64, stages=4, same_as=(128, 64, 0)),
+    dict(B=2, H=8, W=8, c0=64, c1=128, N=64, ks=1, tile_m=4064, tile_n=64, stages=4, same_as=(64, 64, 0)),      # 1x1 over a concat, K = 3 tiles
+    dict(B=1, H=8, W=8, c0=1280, N=1280, ks=3, splitk=9, tile_m=4128, tile_n=128, stages=3, same_as=(64, 128, 0)),   # 8x8 level: BM = M, split-K
+    dict(B=1, H=8, W=8, c0=1280, N=1280, ks=3, splitk=12, tile_m=4128, tile_n=64, stages=4, same_as=(64, 128, 0)),
+    dict(B=2, H=16, W=16, c0=64, N=64, ks=3, stride=2, tile_m=4064, tile_n=128, stages=3, same_as=(64, 64, 0)),      # stride 2; N < the column tile
+    dict(B=1, H=8, W=8, c0=128, N=128, ks=3, upsample=True, tile_m=4064, tile_n=128, stages=4, same_as=(64, 64, 0)),
+    dict(B=2, H=8, W=8, c0=128, c1=64, N=272, ks=3, tile_m=4064, tile_n=256, stages=3, same_as=(64, 64, 0)),       # 4 blocks per wave, ragged N (17 blocks)
+    dict(B=2, H=8, W=8, c0=128, c1=64, N=272, ks=3, tile_m=4064, tile_n=256, stages=4, same_as=(64, 64, 0)),
+    dict(B=3, H=12, W=20, c0=64, N=192, ks=3, tile_m=4256, tile_n=64, stages=3, same_as=(128, 64, 0)),             # 256 rows x one block per wave
+    dict(B=2, H=12, W=20, c0=128, N=320, ks=1, tile_m=4128, tile_n=128, stages=13, same_as=(128, 64, 0)),          # 8 waves
+    dict(B=2, H=16, W=16, c0=128, N=128, ks=3, stride=2, asym=True, tile_m=4064, tile_n=64, stages=4, same_as=(64, 64, 0)),
+    dict(B=2, H=16, W=16, c0=64, N=128, ks=3, f32out=True, act="silu", tile_m=4128, tile_n=64, stages=3, same_as=(128, 64, 0)),
+    dict(B=2, H=12, W=20, c0=64, N=128, ks=3, tile_m=4064, tile_n=64, stages=4, splitk=3, same_as=(64, 64, 0)),    # K = 9 tiles in 3 slices of 3 (< ring depth + 1)
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing
@@ -141,7 +159,9 @@ def test_conv_gemm(gpu, case):
     ws = torch.empty(max(1, splitk * M * N), dtype=torch.float32, device=d)
     step = torch.tensor([2], dtype=torch.int32, device=d)
     biasd, tembd, residd = bias.to(d), temb.to(d), resid.to(torch.bfloat16).to(d)   # (a Call holds addresses, not tensors)
-    call = ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=wp, out=out, batch=B, h_in=H, w_in=W, c0=c0, N=N, ksize=ks, stride=stride,
+    wreg = case.get("tile_m", 0) >= 4000
+    wmain = packing.fragment_major(wp) if wreg else wp
+    call = ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=wmain, w_layout=2 if wreg else 0, out=out, batch=B, h_in=H, w_in=W, c0=c0, N=N, ksize=ks, stride=stride,
                          upsample=ups, bias=biasd, rowvec=tembd, rv_step_stride=B * N, rv_batch_stride=N,
                          step_ptr=step, residual=residd, act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
                          out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, workspace=ws, workspace_floats=ws.numel(),
@@ -155,8 +175,12 @@ def test_conv_gemm(gpu, case):
         run_calls(ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=wp, out=out2, batch=B, h_in=H, w_in=W, c0=c0, N=N, ksize=ks, stride=stride,
                                 upsample=ups, bias=biasd, rowvec=tembd, rv_step_stride=B * N, rv_batch_stride=N, step_ptr=step,
                                 residual=residd, act=ops.ACT_SILU if case.get("act") else ops.ACT_NONE,
-                                out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, tile_n=tn, tile_m=tm, stages=stg))
-        assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "tile shape changed the bits"
+                                out_dtype=ops.OUT_F32 if f32out else ops.OUT_BF16, tile_n=tn, tile_m=tm, stages=stg,
+                                workspace=ws, workspace_floats=ws.numel(), splitk=splitk, **(dict(pad=0, pad_end=1) if asym else {})))
+        bits = torch.int32 if f32out else torch.int16
+        assert torch.equal(out.view(bits), out2.view(bits)), "tile shape / kernel form changed the bits"
+    if wreg:   # (the fragment-major image IS the layout this form reads)
+        return
     # chunk-major weights [K/64][N][64] (w_layout = 1, the form the models keep): storage order only, the same bits
     out3 = torch.full_like(out, float("nan"))
     run_calls(ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=packing.chunk_major(wp), w_layout=1, out=out3, batch=B, h_in=H, w_in=W, c0=c0, N=N,
@@ -173,6 +197,8 @@ def test_conv_gemm(gpu, case):
     dict(B=2, H=8, W=8, c=192, cx0=128, cx1=64, N=192, ks=3, splitk=3),                # shortcut over a concat, split-K across both parts
     dict(B=1, H=16, W=16, c=64, cx0=64, cx1=0, N=320, ks=3, tile_m=64, tile_n=64),
     dict(B=2, H=12, W=20, c=64, cx0=128, cx1=0, N=100, ks=1, tile_m=128, tile_n=64, stages=13),   # 1x1 main part
+    dict(B=2, H=8, W=8, c=192, cx0=128, cx1=64, N=192, ks=3, splitk=3, tile_m=4128, tile_n=128, stages=3),   # wreg form (fragment-major weights)
+    dict(B=1, H=16, W=16, c=64, cx0=64, cx1=0, N=320, ks=3, tile_m=4064, tile_n=256, stages=4),
 ])
 def test_conv_gemm_shortcut_operand(gpu, case):
     """conv(h) + conv1x1(x) as one contraction (diffusion_model.py:34-38,50): K = taps of h, then the channels of x."""
@@ -196,27 +222,31 @@ def test_conv_gemm_shortcut_operand(gpu, case):
     sk = case.get("splitk", 1)
     keep = [h.to(torch.bfloat16).to(d), x0.to(torch.bfloat16).to(d), x1.to(torch.bfloat16).to(d) if cx1 else None, (b2 + bs).to(d),
             torch.empty(max(1, sk * M * N), dtype=torch.float32, device=d)]
+    from minsdtf_amd import packing
+
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=d)
-    call = ops.conv_gemm(a0=keep[0], w=wcat, out=out, batch=B, h_in=H, w_in=W, c0=c, N=N, ksize=ks, bias=keep[3], a2=keep[1], c2=cx0,
-                         a3=keep[2], c3=cx1, workspace=keep[4], workspace_floats=keep[4].numel(), splitk=sk,
+    wreg = case.get("tile_m", 0) >= 4000
+    wmain = packing.fragment_major(wcat) if wreg else wcat
+    call = ops.conv_gemm(a0=keep[0], w=wmain, w_layout=2 if wreg else 0, out=out, batch=B, h_in=H, w_in=W, c0=c, N=N, ksize=ks, bias=keep[3],
+                         a2=keep[1], c2=cx0, a3=keep[2], c3=cx1, workspace=keep[4], workspace_floats=keep[4].numel(), splitk=sk,
                          tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0))
     run_calls(call)
     close(out.reshape(B, H, W, N), ref, what=str(case))
-    from minsdtf_amd import packing
-
+    # chunk-major weights on the same tile (wreg: on the tile kernel): storage order / kernel form only, the same bits
+    other = dict(tile_m=64, tile_n=128) if wreg else dict(tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0))
     out2 = torch.full_like(out, float("nan"))
     run_calls(ops.conv_gemm(a0=keep[0], w=packing.chunk_major(wcat), w_layout=1, out=out2, batch=B, h_in=H, w_in=W, c0=c, N=N, ksize=ks,
                             bias=keep[3], a2=keep[1], c2=cx0, a3=keep[2], c3=cx1, workspace=keep[4], workspace_floats=keep[4].numel(),
-                            splitk=sk, tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0)))
-    assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "weight layout changed the bits"
+                            splitk=sk, **other))
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "weight layout / kernel form changed the bits"
 
 
-@pytest.mark.parametrize("tile", [(0, 0), (128, 160), (64, 128), (3128, 320)])   # heuristic tile, the 128x160 tile (16x16 level), 64x128, row panels
+@pytest.mark.parametrize("tile", [(0, 0), (128, 160), (64, 128), (3128, 320), (4128, 128), (4064, 256)])   # heuristic tile, the 128x160 tile (16x16 level), 64x128, row panels, wreg
 def test_conv_gemm_geglu(gpu, tile):
     from minsdtf_amd import ops, packing
 
     torch.manual_seed(2)
-    M, C = (192, 64) if tile[0] < 3000 else (200, 320)   # (the row-panel kernel takes K = 320 / 640)
+    M, C = (192, 64) if not 3000 <= tile[0] < 4000 else (200, 320)   # (the row-panel kernel takes K = 320 / 640)
     x = bf(torch.randn(M, C))
     w = bf(torch.randn(C, 8 * C) / math.sqrt(C))
     b = torch.randn(8 * C) * 0.1
@@ -225,8 +255,9 @@ def test_conv_gemm_geglu(gpu, tile):
     ref = a * 0.5 * gate * (1 + torch.tanh(gate * 0.7978845608 * (1 + 0.044715 * gate ** 2)))
     wp, bp = packing.pack_geglu(w.numpy(), b.numpy(), gpu)
     out = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device=gpu)
-    call = ops.conv_gemm(a0=x.to(torch.bfloat16).to(gpu), w=wp, out=out, batch=1, h_in=M, w_in=1, c0=C, N=8 * C, bias=bp,
-                         act=ops.ACT_GEGLU, tile_m=tile[0], tile_n=tile[1])
+    wreg = tile[0] >= 4000
+    call = ops.conv_gemm(a0=x.to(torch.bfloat16).to(gpu), w=packing.fragment_major(wp) if wreg else wp, w_layout=2 if wreg else 0, out=out, batch=1,
+                         h_in=M, w_in=1, c0=C, N=8 * C, bias=bp, act=ops.ACT_GEGLU, tile_m=tile[0], tile_n=tile[1], stages=3 if wreg else 0)
     run_calls(call)
     close(out, ref, what=f"geglu {tile}")
 
@@ -256,6 +287,12 @@ def test_conv_gemm_geglu(gpu, tile):
     dict(M=300, C=320, tile=(3128, 128, 0), mode="geglu", ctile=(3128, 320, 0), csame=True, psame=True),   # 128 + 128 + 64 column shares; attn2.to_out -> GEGLU
     dict(M=260, C=640, tile=(3128, 128, 0), mode="qkv", ctile=(3128, 480, 0), csame=True, psame=True),     # K = 640; proj_in -> q|k|v
     dict(M=136, C=640, tile=(3128, 64, 0), mode="dense", psame=True, nores=True),                          # proj_in: no residual
+    # producer and / or consumer on the wreg form (conv_wreg.hip: fragment-major weights straight to registers): the tile kernel's bits
+    dict(M=600, C=320, tile=(4128, 64, 3), mode="dense", ctile=(4128, 64, 4), csame=True, psame=True),     # both; ragged M
+    dict(M=300, C=320, tile=(4128, 64, 4), mode="geglu", ctile=(4128, 128, 3), csame=True, psame=True),    # GEGLU pairs inside a wave's two blocks
+    dict(M=260, C=640, tile=(4064, 64, 4), mode="qkv", ctile=(4064, 256, 3), csame=True, psame=True),      # q | k | v^T split from 4 blocks per wave
+    dict(M=136, C=1280, tile=(4128, 64, 3), mode="dense", ctile=(4256, 64, 3), psame=True, csame=True, nores=True),   # 20 partials per row
+    dict(M=200, C=320, tile=(4128, 128, 3), mode="dense", ctile=(4128, 128, 13), csame=True),              # 128-column producer tiles (3 partials), 8-wave consumer
 ])
 def test_conv_gemm_layer_norm_fold(gpu, case):
     """LayerNormalization folded into the GEMMs around it (diffusion_model.py:84-88 + Dense): the producer
@@ -268,6 +305,10 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
     tm, tn, stg = case["tile"]
     ctm, ctn, cstg = case.get("ctile", (0, 0, 0))
     ckw = dict(tile_m=ctm, tile_n=ctn, stages=cstg)
+
+    def lay(w, tile_m):   # the weight image a launch reads: fragment-major for the wreg form
+        return dict(w=packing.fragment_major(w), w_layout=2) if tile_m >= 4000 else dict(w=w)
+
     x = bf(torch.randn(M, C))
     res = bf(torch.randn(M, C) * 2 + 0.5)                      # non-zero row means
     if case.get("nores"):
@@ -280,12 +321,13 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
     d = gpu
     tdev = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
     slots = ops.conv_gemm_ln_slots(N=C, tile_n=tn, tile_m=tm)
-    assert slots == -(-C // (64 if tm >= 3000 else tn))
+    assert slots == -(-C // (64 if 3000 <= tm < 4000 else tn))
     stats = torch.full((M, slots, 2), float("nan"), dtype=torch.float32, device=d)
     keep = [x.to(torch.bfloat16).to(d), packing.pack_dense(w0.numpy(), d), b0.to(d), res.to(torch.bfloat16).to(d)]   # (Calls hold raw pointers)
     if case.get("nores"):
         keep[3] = None
-    prod = ops.conv_gemm(a0=keep[0], w=keep[1], out=tdev, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=keep[2], residual=keep[3],
+    keep.append(lay(keep[1], tm))
+    prod = ops.conv_gemm(a0=keep[0], **keep[4], out=tdev, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=keep[2], residual=keep[3],
                          tile_m=tm, tile_n=tn, stages=stg, ln_out=stats, ln_out_slots=slots)
     if case.get("psame"):
         tdev2, stats2 = torch.full_like(tdev, float("nan")), torch.full_like(stats, float("nan"))
@@ -303,7 +345,8 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
         order = torch.from_numpy(packing.geglu_row_order(4 * C))
         wf, cs, cb = packing.fold_layer_norm(w1.t().contiguous()[order], b1.numpy()[order.numpy()], gamma.numpy(), beta.numpy(), d)
         out = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device=d)
-        cons = ops.conv_gemm(a0=tdev, w=wf, out=out, batch=1, h_in=M, w_in=1, c0=C, N=8 * C, bias=cb, act=ops.ACT_GEGLU,
+        wfl = lay(wf, ctm)
+        cons = ops.conv_gemm(a0=tdev, **wfl, out=out, batch=1, h_in=M, w_in=1, c0=C, N=8 * C, bias=cb, act=ops.ACT_GEGLU,
                              ln_in=stats, ln_in_slots=slots, ln_colsum=cs, **ckw)
         run_calls([prod, cons])
         close(out, ref, atol=2e-2 * float(ref.abs().max()), what=str(case))
@@ -320,7 +363,8 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
         k = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
         sp = (M + 7) // 8 * 8
         vt = torch.zeros((1, C, sp), dtype=torch.bfloat16, device=d)
-        cons = ops.conv_gemm(a0=tdev, w=wf, out=q, batch=1, h_in=M, w_in=1, c0=C, N=3 * C, bias=cb, split=(C, C, k, C, vt, sp),
+        wfl = lay(wf, ctm)
+        cons = ops.conv_gemm(a0=tdev, **wfl, out=q, batch=1, h_in=M, w_in=1, c0=C, N=3 * C, bias=cb, split=(C, C, k, C, vt, sp),
                              ln_in=stats, ln_in_slots=slots, ln_colsum=cs, **ckw)
         run_calls([prod, cons])
         atol = 2e-2 * float(ref.abs().max())
@@ -339,7 +383,8 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
         ref = ln @ w1 + b1
         wf, cs, cb = packing.fold_layer_norm(w1.t().contiguous(), b1.numpy(), gamma.numpy(), beta.numpy(), d)
         out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=d)
-        cons = ops.conv_gemm(a0=tdev, w=wf, out=out, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=cb, ln_in=stats, ln_in_slots=slots,
+        wfl = lay(wf, ctm)
+        cons = ops.conv_gemm(a0=tdev, **wfl, out=out, batch=1, h_in=M, w_in=1, c0=C, N=C, bias=cb, ln_in=stats, ln_in_slots=slots,
                              ln_colsum=cs, **ckw)
         run_calls([prod, cons])
         close(out, ref, atol=2e-2 * float(ref.abs().max()), what=str(case))

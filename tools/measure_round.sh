@@ -25,6 +25,21 @@ pmc() {
     echo "pmc$sfx done"
 }
 
+# mfma: matrix-pipe counter against the FLOP-derived fraction (tools/pmc_mfma.py): PMC pass, un-profiled trace, calibration loop
+if [ "$WHAT" = mfma ]; then
+    rm -rf $OUT/mfma_pmc $OUT/mfma_plain $OUT/mfma_calib
+    $T 300 rocprofv3 --pmc MfmaUtil MfmaFlopsBF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc -- python3 tools/pmc_step.py --calls-json $OUT/mfma_pmc_calls.json > $OUT/mfma_pmc.log 2>&1 \
+        || $T 300 rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $OUT/mfma_pmc -- python3 tools/pmc_step.py --calls-json $OUT/mfma_pmc_calls.json > $OUT/mfma_pmc.log 2>&1 || exit 3
+    mv $OUT/mfma_pmc_calls.json $OUT/mfma_pmc/calls.json
+    $T 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/mfma_plain -- python3 tools/pmc_step.py --calls-json $OUT/mfma_plain_calls.json > $OUT/mfma_plain.log 2>&1 || exit 4
+    mv $OUT/mfma_plain_calls.json $OUT/mfma_plain/calls.json
+    $T 200 rocprofv3 --pmc MfmaUtil MfmaFlopsBF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_calib -- python3 tools/mfma_rate.py > $OUT/mfma_calib.log 2>&1 || echo "calibration pass failed (see mfma_calib.log)"
+    python tools/pmc_mfma.py $OUT/mfma_pmc $OUT/mfma_plain $OUT/${TAG}_pmc_mfma.json "$COMMIT" $( [ -d $OUT/mfma_calib ] && echo $OUT/mfma_calib ) > $OUT/mfma_sum.log 2>&1 || { echo "pmc_mfma failed"; tail -5 $OUT/mfma_sum.log; exit 5; }
+    rm -rf $OUT/mfma_pmc/*/*.db $OUT/mfma_plain/*/*.db 2>/dev/null
+    tail -40 $OUT/mfma_sum.log
+    echo "mfma done"
+    exit 0
+fi
 if [ "$WHAT" = all ] || [ "$WHAT" = headline ]; then
     pmc "" || exit $?
     $T 400 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench_n1.err || exit 1

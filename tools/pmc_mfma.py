@@ -43,6 +43,7 @@ def trace(d):
 
 
 def counters(d, name="MfmaUtil"):
+    """dispatch id -> (kernel name, value of counter `name`)."""
     f = find(d, "*counter_collection.csv")
     if not f:
         raise SystemExit(f"no counter_collection.csv under {d}")
@@ -73,13 +74,18 @@ def main():
     calib_dir = sys.argv[5] if len(sys.argv) > 5 else None
     pmc_rows, plain_rows = trace(pmc_dir), trace(plain_dir)
     util = counters(pmc_dir)
+    # optional, when the pass also collected them: executed MFMA FLOP (SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512) and GRBM_GUI_ACTIVE (cycles of
+    # the busiest XCD): executed FLOP / (1,048,576 x GUI cycles) has MfmaUtil's own denominator, so the two must agree if the busy
+    # counter is right, whatever the clock; GUI cycles / duration is the clock the dispatch ran at (reads high on dispatches < 0.3 ms)
+    xflop = {k: v[1] for k, v in counters(pmc_dir, "MfmaFlopsBF16").items()}
+    gui = {k: v[1] for k, v in counters(pmc_dir, "GRBM_GUI_ACTIVE").items()}
     pmc_calls = json.load(open(os.path.join(pmc_dir, "calls.json")))
     plain_calls = json.load(open(os.path.join(plain_dir, "calls.json")))
     flop_pmc = join_calls(pmc_rows, pmc_calls["conv_calls"])
     flop_plain = join_calls(plain_rows, plain_calls["conv_calls"])
     clock_ghz = (plain_calls.get("sclk_mhz_median") or 2400.0) / 1e3
 
-    per = collections.defaultdict(lambda: {"n": 0, "pmc_us": 0.0, "util_x_us": 0.0, "flop": 0.0, "flop_us": 0.0})
+    per = collections.defaultdict(lambda: {"n": 0, "pmc_us": 0.0, "util_x_us": 0.0, "flop": 0.0, "flop_us": 0.0, "xflop": 0.0, "gui": 0.0, "util_x_gui": 0.0})
     for i, (s, e, k, did) in enumerate(pmc_rows):
         if did not in util:
             continue
@@ -88,6 +94,9 @@ def main():
         p["n"] += 1
         p["pmc_us"] += us
         p["util_x_us"] += util[did][1] * us
+        p["xflop"] += xflop.get(did, 0.0)
+        p["gui"] += gui.get(did, 0.0)
+        p["util_x_gui"] += util[did][1] * gui.get(did, 0.0)
         if i in flop_pmc:
             p["flop"] += flop_pmc[i]["flop"]
     plain = collections.defaultdict(lambda: {"n": 0, "us": 0.0, "flop": 0.0})
@@ -112,6 +121,12 @@ def main():
             if q["flop"] > 0:
                 row["flop_busy_pct_plain_at_2.4GHz"] = round(frac(q["flop"], q["us"], 2.4), 2)
                 row[f"flop_busy_pct_plain_at_sclk_{clock_ghz:.2f}GHz"] = round(frac(q["flop"], q["us"], clock_ghz), 2)
+        if p["gui"] > 0:
+            row["executed_flop_busy_pct_over_gui_cycles"] = round(100.0 * p["xflop"] / (FLOP_PER_CYCLE * p["gui"]), 2)
+            row["mfma_util_pct_gui_weighted"] = round(p["util_x_gui"] / p["gui"], 2)
+            row["clock_ghz_gui_cycles_over_pmc_duration"] = round(p["gui"] / (p["pmc_us"] * 1e3), 3)
+            if p["flop"] > 0:
+                row["executed_over_algorithmic_flop"] = round(p["xflop"] / p["flop"], 3)
         if row["mfma_util_pct_time_weighted"] > 0.3 or p["flop"] > 0:
             kernels[k] = row
 
@@ -127,6 +142,14 @@ def main():
         r = {"dispatches": sum(per[k]["n"] for k in sel), "pmc_ms": round((pmc_us + fin_pmc) / 1e3, 3), "plain_ms": round((pl_us + fin_pl) / 1e3, 3),
              "pmc_over_plain_duration": round((pmc_us + fin_pmc) / (pl_us + fin_pl), 3) if pl_us else None,
              "mfma_util_pct_time_weighted": round(ux / (pmc_us + fin_pmc), 2) if pmc_us else None}
+        g_ = sum(per[k]["gui"] for k in sel)
+        if g_ > 0:
+            xf = sum(per[k]["xflop"] for k in sel)
+            r["executed_flop_busy_pct_over_gui_cycles"] = round(100.0 * xf / (FLOP_PER_CYCLE * g_), 2)
+            r["mfma_util_pct_gui_weighted"] = round(sum(per[k]["util_x_gui"] for k in sel) / g_, 2)
+            r["clock_ghz_gui_cycles_over_pmc_duration"] = round(g_ / (pmc_us * 1e3), 3)
+            if fl:
+                r["executed_over_algorithmic_flop"] = round(xf / fl, 3)
         if fl:
             r["flop_busy_pct_pmc_pass_at_2.4GHz"] = round(frac(fl, pmc_us + fin_pmc, 2.4), 2)
             r["flop_busy_pct_plain_at_2.4GHz"] = round(frac(pl_fl, pl_us + fin_pl, 2.4), 2)
@@ -149,10 +172,18 @@ def main():
         cal = collections.defaultdict(list)
         for _did, (k, v) in cu.items():
             cal[k].append(v)
+        cx = counters(calib_dir, "MfmaFlopsBF16")
+        cg = counters(calib_dir, "GRBM_GUI_ACTIVE")
+        calx = collections.defaultdict(list)
+        for did, (k, v) in cx.items():
+            if did in cg and cg[did][1] > 0:
+                calx[k].append(100.0 * v / (FLOP_PER_CYCLE * cg[did][1]))
         # tools/mfma_rate.py launches every mode on 1 block and on 256 blocks (one wave per SIMD, every SIMD): the 256-block
         # dispatches are the larger readings
-        res["calibration (bare MFMA loops, tools/mfma_rate.py)"] = {k: {"dispatches": len(v), "mfma_util_pct_max": round(max(v), 2)}
-                                                                   for k, v in cal.items() if max(v) > 1.0}
+        res["calibration (bare MFMA loops, tools/mfma_rate.py)"] = {
+            k: {"dispatches": len(v), "mfma_util_pct_max": round(max(v), 2),
+                "executed_flop_busy_pct_over_gui_cycles_max": round(max(calx[k]), 2) if calx.get(k) else None}
+            for k, v in cal.items() if max(v) > 1.0}
     if commit:
         res["commit"] = commit
     res["kernels"] = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["mfma_util_pct_time_weighted"]))

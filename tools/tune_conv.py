@@ -127,7 +127,12 @@ def tune_one(shape, iters=10):
         cands += [t for t in tuning.HALO_TILES if h_in % ((t[0] % 1000) // 16) == 0]
     if ks == 1 and stride == 1 and not ups and not cx and cin in tuning.ROWPANEL_ROWS and N % 32 == 0:   # row-panel Dense kernel
         cands += [(rows, cols, 0) for rows in tuning.ROWPANEL_ROWS[cin] for cols in tuning.ROWPANEL_COLS if N % cols == 0]
+    if N % 16 == 0 and not os.environ.get("MSD_TUNE_NO_WREG"):   # wreg form (fragment-major weights straight to registers)
+        cands += [t for t in tuning.WREG_TILES if not (t[1] > 64 and N <= 64)]
+    frag = None
     for (bm, bn, stg) in cands:
+        if bm >= 4000 and allow_split is False and bn // (8 if stg >= 10 else 4) < 32:
+            continue   # (the 'n' shapes include GEGLU, which pairs the two blocks of a wave)
         if bm < 3000:
             if bm == 256 and M < 1024:
                 continue
@@ -138,17 +143,22 @@ def tune_one(shape, iters=10):
             if bn == 160 and (N % 160 or N < 1280):
                 continue
         sks = [1]
-        if allow_split and bm < 3000:
+        if allow_split and (bm < 3000 or bm >= 4000):
             # candidates from the PER-SAMPLE shape, so every batch of a layer is measured on the same set of slice counts
             bme = bm % 1000 if bm >= 1000 else bm
             tiles = ((M // batch + bme - 1) // bme) * ((N + bn - 1) // bn)
-            kmax = (cin // 64) if bm >= 1000 else nk // 4   # the halo kernel splits over 64-channel chunks
+            kmax = (cin // 64) if 1000 <= bm < 3000 else nk // 4   # the halo kernel splits over 64-channel chunks
             sks += [s for s in (2, 3, 4, 6, 8, 12, 16) if s <= kmax and tiles * s <= 2048 and tiles < 512]
         for sk in sks:
             wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32) if sk > 1 else None
+            if bm >= 4000 and frag is None:
+                from minsdtf_amd import packing
+
+                frag = [packing.fragment_major(w) for w in ws_]
             calls = [ops.conv_gemm(a0=x, w=w, out=out, batch=batch, h_in=h_in, w_in=w_in, c0=cin, N=N, ksize=ks, stride=stride,
                                    upsample=ups, bias=bias, workspace=wsf, workspace_floats=0 if wsf is None else wsf.numel(),
-                                   splitk=sk, tile_m=bm, tile_n=bn, stages=stg, a2=xx, c2=cx) for w in ws_]
+                                   splitk=sk, tile_m=bm, tile_n=bn, stages=stg, a2=xx, c2=cx, w_layout=2 if bm >= 4000 else 0)
+                     for w in (frag if bm >= 4000 else ws_)]
             for c in calls[:2]:
                 c(st.cuda_stream)
             torch.cuda.synchronize()

@@ -187,9 +187,9 @@ def main():
                 bv = min(vend.values())
                 tot_o += r["ours_us"] * r["launches_per_step"]
                 tot_v += bv * r["launches_per_step"]
-                f.write(f"| `{r['key']}` | {r['launches_per_step']} | {r['M']} x {r['N']} x {r['K']} | {r['ours_us']:.1f} ({r['gflop'] / r['ours_us'] / 1e3:.0f}) | "
+                f.write(f"| `{r['key']}` | {r['launches_per_step']} | {r['M']} x {r['N']} x {r['K']} | {r['ours_us']:.1f} ({r["gflop"] / r["ours_us"] * 1e3:.0f}) | "
                         f"{r['ours_cfg']} | {r['matmul_kn_us']:.1f} | {r['matmul_nk_us']:.1f} | {r['addmm_us']:.1f} | "
-                        f"{r.get('conv2d_us', float('nan')):.1f} | {r['gflop'] / bv / 1e3:.0f} | {bv / r['ours_us']:.2f} |\n")
+                        f"{r.get('conv2d_us', float('nan')):.1f} | {r["gflop"] / bv * 1e3:.0f} | {bv / r['ours_us']:.2f} |\n")
             f.write(f"\nSum over one step's launches: ours {tot_o / 1e3:.3f} ms, per-shape best vendor kernel {tot_v / 1e3:.3f} ms "
                     f"(ratio {tot_v / tot_o:.2f}).\n\n")
     print(f"wrote {args.out} in {time.time() - t0:.0f}s")
