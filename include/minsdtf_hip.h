@@ -118,13 +118,21 @@ typedef struct MsdConvGemm {
     int32_t tile_m;      /* 0 = 128, else 64 / 128 / 256; valid (tile_m x tile_n): 128x128 128x64 64x64 64x128 256x128 128x80;
                             1128 / 1256 = halo-tile 3x3 kernel with 8x16 / 16x16 pixel tiles (x 64 / 80 / 128 channels;
                             falls back if not eligible).  The 80-wide tiles serve N = 320 / 640 at small batch, where
-                            they make the workgroup count a multiple of the 256 CUs */
+                            they make the workgroup count a multiple of the 256 CUs;
+                            4000 + rows (4064 / 4128 / 4256) = the wreg form (csrc/conv_wreg.hip): the weights are read global ->
+                            VGPR from the fragment-major image (w_layout 2, required: MSD_E_ARG with any other layout), only the
+                            activation tile goes through LDS; tile_n x stages must name a built configuration (MSD_E_UNSUPPORTED
+                            otherwise: there is no fallback, the other forms cannot read that image); N % 16 == 0.  Same K walk
+                            and epilogue as the tile kernel: the same results bit for bit */
     int32_t stages;      /* 0 = default LDS ring depth of the tile; deeper rings built: 128x128:4 64x64:8 64x128:5 128x64:5
                             128x80:4; halo tiles 1128x64:8 1128x128:6 1128x80:8 1256x80:5 (an unknown depth = the default);
                             10 + depth = the tile on 8 waves (two per SIMD): 64x64:14 128x64:13 64x128:13;
                             20 + depth = 64x64 per wave: 128x128:23/24 128x64:24 64x128:24;
                             30 + depth = halo tiles with 3 filter taps (one filter row) per K step: 1128x64:33/34 1128x80:33
-                            2128x64:33; 60 + depth = the same with two loader waves that do all the staging: 1128x64:63 1128x80:63 */
+                            2128x64:33; 60 + depth = the same with two loader waves that do all the staging: 1128x64:63 1128x80:63;
+                            wreg form (tile_m 4000 + rows): depth 3 / 4, + 10 = 8 waves (4256x128: a 2 x 4 wave grid),
+                            + 20 = two K tiles (128 channels) per ring stage: 4064x64:4/23/24 4064x128:3/4/23/24 4064x256:3/4/23
+                            4128x64:3/4/23 4128x128:3/4/13/23 4256x64:3 4256x128:13/14 */
     const float* ln_in;      /* float2 [M][ln_in_slots] row-moment partials of the input rows, or NULL */
     const float* ln_colsum;  /* [N]: sum_k W[n][k] of the gamma-folded bf16 weights (with ln_in) */
     float* ln_out;           /* float2 [M][ln_out_slots] row-moment partials of the stored output, or NULL */
@@ -141,7 +149,11 @@ typedef struct MsdConvGemm {
     /* Storage order of w.  0: [N][K] rows.  1: chunk-major [K/64][N][64] — the 64-element K chunk kc of ALL output
      * columns is one contiguous N x 128-byte run, so the weight tile of a K step (any tile_n, any column offset) is a
      * single contiguous block of HBM instead of tile_n pieces of 128 bytes K*2 bytes apart (the packed form the
-     * models keep; same values, same K order, same results). */
+     * models keep; same values, same K order, same results).  2: fragment-major [K/64][N/16][2][64][8] — the operand
+     * registers of v_mfma_f32_16x16x32_bf16 laid out in memory: lane l = 16 g + r of fragment (K tile kt, 16-column block
+     * nb, half ks) holds W[16 nb + rho(r)][64 kt + 32 ks + 8 g .. + 8], rho = (0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15), at
+     * byte 16 l of the fragment's contiguous KiB (minsdtf_amd/packing.py fragment_major); read by the wreg form only
+     * (tile_m 4000 + rows), which loads a fragment with one coalesced global_load_dwordx4 per wave. */
     int32_t w_layout;
 } MsdConvGemm;
 

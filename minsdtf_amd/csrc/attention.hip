@@ -1546,6 +1546,10 @@ static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = 64 / 128 queries per wor
 void msd_set_attn_qf(int v) { g_attn_qf = v; }
 static int g_attn_form = 2;   // head sizes 40 and 80: 2 = 32x32x16 MFMA form, software-pipelined for long key walks [default], 1 = 32x32x16 plain loop, 0 = 16x16x32 form like the other head sizes (A/B runs)
 void msd_set_attn_form(int v) { g_attn_form = v; }
+static int g_attn_d160_pipe = 1;   // d = 160, 64-query workgroups: 1 = K/V tile t+1 prefetched to registers under the products of tile t (NBUF 2; 204 registers)
+                                   // [default], 0 = load -> store -> compute (NBUF 1: the only form the 128-query workgroups have registers for).  Staging only:
+                                   // the same bits.  The S <= 256 launches of the 16x16 / 8x8 levels put one wave on a SIMD of a quarter of the CUs: a serial chain
+void msd_set_attn_d160_pipe(int v) { g_attn_d160_pipe = v; }
 static int g_xattn_nw = 0;    // 0 = automatic, 4 / 8 = waves (x 16 queries) per workgroup of the fused cross-attention (A/B runs)
 void msd_set_xattn_nw(int v) { g_xattn_nw = v; }
 
@@ -1566,6 +1570,10 @@ static hipError_t attn_attr() {
     if (e == hipSuccess) e = attn_attr1<D, NB, 2, false>();
     if (e == hipSuccess) e = attn_attr1<D, NB, 1, true>();
     if (e == hipSuccess) e = attn_attr1<D, NB, 2, true>();
+    if constexpr (D == 160) {   // the prefetching form of the 64-query workgroups (g_attn_d160_pipe)
+        if (e == hipSuccess) e = attn_attr1<D, 2, 1, false>();
+        if (e == hipSuccess) e = attn_attr1<D, 2, 1, true>();
+    }
     if constexpr (attn_form32<D>()) {
         if (e == hipSuccess) e = attn32_attr1<D, NB, 2, false>();
         if (e == hipSuccess) e = attn32_attr1<D, NB, 4, false>();
@@ -1636,6 +1644,9 @@ static void attn_launch(const AArgs& a, int qf, hipStream_t stream) {
             else attn32_launch2<D, attn_nbuf<D>(), 4>(a, grid, stream);
             return;
         }
+    }
+    if constexpr (D == 160) {
+        if (qf == 1 && g_attn_d160_pipe) { attn_launch2<D, 2, 1>(a, grid, stream); return; }
     }
     if (qf == 1) attn_launch2<D, attn_nbuf<D>(), 1>(a, grid, stream);
     else attn_launch2<D, attn_nbuf<D>(), 2>(a, grid, stream);

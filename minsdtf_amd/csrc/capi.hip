@@ -31,6 +31,7 @@ void msd_set_gn_poll_limit(int v);
 void msd_set_attn_qf(int v);
 void msd_set_xattn_nw(int v);
 void msd_set_attn_form(int v);
+void msd_set_attn_d160_pipe(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "gn_impl" (1 = single-launch per-group
  * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
 extern "C" int msd_set_option(const char* key, int value) {
@@ -46,6 +47,10 @@ extern "C" int msd_set_option(const char* key, int value) {
     if (key && strcmp(key, "attn_form") == 0) {   // d = 40 / 80: 2 = 32x32x16 MFMAs, software-pipelined on long key walks [default], 1 = 32x32x16 plain, 0 = 16x16x32
         if (value < 0 || value > 2) MSD_FAIL(MSD_E_ARG, "set_option: attn_form takes 0, 1 or 2");
         msd_set_attn_form(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "attn_d160_pipe") == 0) {   // d = 160, 64-query workgroups: 1 = K/V register prefetch [default], 0 = serial staging (same bits)
+        msd_set_attn_d160_pipe(value ? 1 : 0);
         return MSD_OK;
     }
     if (key && strcmp(key, "xattn_nw") == 0) {    // 0 = automatic [default], 4 / 8 = 64 / 128 queries per fused cross-attention workgroup

@@ -22,6 +22,13 @@
 
 typedef uint32_t wr_u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef MSD_STAMPS
+// (tools/gemm_stamps.py, `make stamps` library only: the in-kernel timeline of this translation unit's kernels)
+extern "C" MSD_API int msd_debug_stamps_wreg(unsigned long long* host_out, int count) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count);
+}
+#endif
+
 // one 16-column x 32-deep weight fragment: 64 lanes x 16 B from `base` (wave-uniform, SGPR pair) + per-lane byte offset (+ 1 KiB
 // for the second half of the K tile).  The first load of a group opens with s_nop 4 (a scalar base fresh from SALU / readfirstlane
 // arithmetic read by a VMEM instruction inside an asm string: nothing pads it for us).
@@ -35,23 +42,36 @@ __device__ __forceinline__ void wr_load(wr_u32x4& lo, wr_u32x4& hi, const void* 
 }
 
 // BM x (NW x NJ x 16) output tile on NW waves (all split over N), S-stage LDS ring for A, S - 1 register sets for B.
-template <int BM, int NJ, int NW, int S, bool DENSE>
+// KT = K tiles per ring stage / per wait + barrier (1 or 2).  The small-M layers of the 16x16 and 8x8 levels are latency chains:
+// a 64-deep K step of a 64-row tile is wait -> barrier -> fragment reads -> 8-16 MFMAs, ~0.3 us for ~0.05 us of MFMA work, and with
+// KT = 2 that chain is paid once per 128 channels.  In conv_gemm.hip the same idea cost the second workgroup per CU (both
+// operands in a 98-131 KB ring); here the ring holds A only (64 rows x 2 tiles x 3 stages = 48 KB).  The K tiles are still walked
+// in ascending order, so the bits do not change.
+// WGM = wave rows (1: every wave owns all BM rows; 2: the waves form a 2 x NW/2 grid, each owning BM/2 rows x NJ blocks — for
+// 256-row tiles on 8 waves: 48 KB of operands per K tile where two 128x128 workgroups move 64 KB; the two waves of a column
+// pair load the same fragments, the second from the CU's L1).
+template <int BM, int NJ, int NW, int S, bool DENSE, int KT = 1, int WGM = 1>
 __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
     constexpr int NT = NW * 64;
-    constexpr int BN = NW * NJ * 16;
-    constexpr int MI = BM / 16;
+    constexpr int WGN = NW / WGM;
+    constexpr int BN = WGN * NJ * 16;
+    constexpr int WMT = BM / WGM;                  // rows per wave
+    constexpr int MI = WMT / 16;
+    static_assert(NW % WGM == 0 && BM % (16 * WGM) == 0, "wave grid");
     constexpr int RPP = NT / 8;                   // rows covered by one pass of the workgroup's DMAs
     constexpr int AR = BM * 8 / NT;               // LDS-DMA instructions per thread per K tile
-    constexpr int L = AR + 2 * NJ;                // vector-memory operations per thread per K tile (one group)
-    constexpr int PB = S - 1;                     // register sets for the weight fragments (= K tiles in flight)
-    constexpr int A_BYTES = BM * 128;
-    static_assert(AR >= 1 && (BM * 8) % NT == 0 && BM % 16 == 0 && S >= 3 && (S - 2) * L <= 63, "tile config");
+    constexpr int L = KT * (AR + 2 * NJ);         // vector-memory operations per thread per ring stage (one group)
+    constexpr int PB = S - 1;                     // register sets for the weight fragments (= stages in flight)
+    constexpr int A_BYTES = BM * 128;             // one K tile of A; a ring stage holds KT of them
+    static_assert(AR >= 1 && (BM * 8) % NT == 0 && BM % 16 == 0 && S >= 3 && (S - 2) * L <= 63 && (KT == 1 || KT == 2), "tile config");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
     const int r = lane & 15, g = lane >> 4;
+    MSD_STAMP(0);
     // tile order as in conv_gemm.hip: XCD-contiguous runs that share the pixel rows (n fastest) or the weight panel (m fastest)
     const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;
@@ -61,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kt_begin = blockIdx.y * p.nk_per;
     const int kt_end = min(p.nk, kt_begin + p.nk_per);
-    const int nkt = kt_end - kt_begin;
+    const int nkt = (kt_end - kt_begin + KT - 1) / KT;   // ring stages (= steps) of this slice; the last one may hold fewer than KT tiles
 
     // ---- A loader coordinates (conv_gemm.hip's): thread -> (row = lrow + RPP i, 16-byte chunk position tid & 7) ----------
     const int cpos = tid & 7, lrow = tid >> 3;
@@ -95,8 +115,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
         }
     }
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
-    auto issue_a = [&](int kt, int stage) {
-        const uint32_t sbase = lds_wave + (uint32_t)stage * A_BYTES;
+    auto issue_a = [&](int kt, int slot) {   // slot = stage * KT + tile inside the stage
+        const uint32_t sbase = lds_wave + (uint32_t)slot * A_BYTES;
         if constexpr (DENSE) {
             const int c = kt * 64;
             const bool first = c < p.c0;                       // wave-uniform: which tensor of the concat
@@ -132,12 +152,12 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
     // ---- B: this wave's NJ column blocks of K tile kt = 2 NJ contiguous KiB of the fragment-major image ------------------
     // image: [K / 64][N / 16][2][64 lanes][16 B]; blocks past N re-read the last block (their columns are never stored)
     const int NB = p.N >> 4;
-    const int nb0 = (n0 >> 4) + wave * NJ;
+    const int nb0 = (n0 >> 4) + wn * NJ;
     uint32_t boff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) boff[j] = (uint32_t)min(nb0 + j, NB - 1) * 2048u + (uint32_t)lane * 16u;
     const size_t kt_bytes = (size_t)NB * 2048u;
-    wr_u32x4 bw[PB][NJ][2];
+    wr_u32x4 bw[PB][KT][NJ][2];
     auto issue_b = [&](int kt, wr_u32x4 (&dst)[NJ][2]) {
         const char* base = reinterpret_cast<const char*>(p.w) + (size_t)kt * kt_bytes;
         wr_load_first(dst[0][0], dst[0][1], base, boff[0]);
@@ -157,46 +177,67 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
 #pragma unroll
             for (int i = 0; i < EC; ++i) acc[h][j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // prologue: groups 0 .. S-2 (A tile into ring slot s, B fragments into register set s)
+    // a group = the KT tiles of one ring stage.  Every group has exactly L operations (the counted waits rely on it): a tile past
+    // the slice's end (odd tile count with KT = 2) is issued as a re-read of the slice's last tile and never multiplied
+    auto issue_group_a = [&](int stp, int stage) {
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) issue_a(min(kt_begin + stp * KT + kk, kt_end - 1), stage * KT + kk);
+    };
+    auto issue_group_b = [&](int stp, wr_u32x4 (&dst)[KT][NJ][2]) {
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) issue_b(min(kt_begin + stp * KT + kk, kt_end - 1), dst[kk]);
+    };
+    // prologue: groups 0 .. S-2 (A tiles into ring stage s, B fragments into register set s)
 #pragma unroll
     for (int s = 0; s < PB; ++s)
-        if (s < nkt) { issue_a(kt_begin + s, s); issue_b(kt_begin + s, bw[s]); }
+        if (s < nkt) { issue_group_a(s, s); issue_group_b(s, bw[s]); }
+    MSD_STAMP(1);
 
     const int swz = r >> 1;
     int stage = 0;
-    // one K tile on register set U (compile-time: the sets rotate by unrolling the loop PB times)
-    auto step = [&](int it, wr_u32x4 (&bs)[NJ][2]) {
+    // one ring stage on register set U (compile-time: the sets rotate by unrolling the loop PB times)
+    auto step = [&](int it, wr_u32x4 (&bs)[KT][NJ][2]) {
         // retire group `it`: all but the groups issued after it may stay in flight
         const int later = min(nkt, it + S - 1) - (it + 1);
         wait_vmcnt_tiles<L, S - 2>(later);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { asm volatile("" : "+v"(bs[j][0])); asm volatile("" : "+v"(bs[j][1])); }   // consumers stay below the wait
-        __builtin_amdgcn_s_barrier();   // A tile `it` visible to all waves; ring slot (it - 1) % S free for reuse
-        const char* bA = smem + stage * A_BYTES + r * 128;
-        bf16x8 a0[MI], a1[MI];
+        for (int kk = 0; kk < KT; ++kk)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a0[i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + ((g ^ swz) << 4));
+            for (int j = 0; j < NJ; ++j) { asm volatile("" : "+v"(bs[kk][j][0])); asm volatile("" : "+v"(bs[kk][j][1])); }   // consumers stay below the wait
+        __builtin_amdgcn_s_barrier();   // stage `it` visible to all waves; ring stage (it - 1) % S free for reuse
+#ifdef MSD_STAMPS
+        if (it == 0) MSD_STAMP(2);
+        if (it == (nkt >> 1)) MSD_STAMP(5);
+#endif
         const bool more = it + S - 1 < nkt;
-        if (more) {   // ring slot (it - 1) % S: every wave finished reading it before the barrier above
-            int st = stage + S - 1;
-            if (st >= S) st -= S;
-            issue_a(kt_begin + it + S - 1, st);
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            if (kk > 0 && kt_begin + it * KT + kk >= kt_end) break;   // (wave-uniform: the slice's last stage holds one tile)
+            const char* bA = smem + (stage * KT + kk) * A_BYTES + (wm * WMT + r) * 128;
+            bf16x8 a0[MI], a1[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a0[i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + ((g ^ swz) << 4));
+            if (kk == 0 && more) {   // ring stage (it - 1) % S: every wave finished reading it before the barrier above
+                int st = stage + S - 1;
+                if (st >= S) st -= S;
+                issue_group_a(it + S - 1, st);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a1[i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + (((4 + g) ^ swz) << 4));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[i / EC][j][i % EC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bs[kk][j][0]), a0[i], acc[i / EC][j][i % EC], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[i / EC][j][i % EC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bs[kk][j][1]), a1[i], acc[i / EC][j][i % EC], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a1[i] = *reinterpret_cast<const bf16x8*>(bA + i * 16 * 128 + (((4 + g) ^ swz) << 4));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                acc[i / EC][j][i % EC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bs[j][0]), a0[i], acc[i / EC][j][i % EC], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                acc[i / EC][j][i % EC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bs[j][1]), a1[i], acc[i / EC][j][i % EC], 0, 0, 0);
         // this set's registers are free once the MFMAs above have been ISSUED (they read their operands at issue): the fragments of
-        // K tile it + S - 1 go into the same set, the last operations of the group
-        if (more) issue_b(kt_begin + it + S - 1, bs);
+        // stage it + S - 1 go into the same set, the last operations of the group
+        if (more) issue_group_b(it + S - 1, bs);
         if (++stage == S) stage = 0;
     };
     for (int it = 0; it < nkt; it += PB) {
@@ -205,46 +246,65 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
             if (it + u < nkt) step(it + u, bw[u]);
     }
 
+    MSD_STAMP(3);
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
         int mrow[EC];
 #pragma unroll
-        for (int i = 0; i < EC; ++i) mrow[i] = m0 + (h * EC + i) * 16;
-        cg_epilogue<EC, NJ, false, DENSE>(p, acc[h], mrow, n0 + wave * NJ * 16, r, g, reinterpret_cast<float*>(smem), wave, NW, h * EC * 16, BM, tile_n);
+        for (int i = 0; i < EC; ++i) mrow[i] = m0 + wm * WMT + (h * EC + i) * 16;
+        cg_epilogue<EC, NJ, false, DENSE>(p, acc[h], mrow, n0 + wn * NJ * 16, r, g, reinterpret_cast<float*>(smem), wn, WGN, wm * WMT + h * EC * 16, BM, tile_n);
     }
+#ifdef MSD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
+    MSD_STAMP(4);
+#endif
 }
 
-// ---- configurations: (BM, NJ, NW, S); selected by tile_m = 4000 + BM, tile_n = NW x NJ x 16, stages = S (+ 10 for 8 waves) -----
+// ---- configurations: (BM, NJ, NW, S, KT, WGM); selected by tile_m = 4000 + BM, tile_n = (NW / WGM) x NJ x 16,
+//      stages = S (+ 10 for 8 waves) (+ 20 for two K tiles per stage) ------------------------------------------------------------
 #define MSD_WREG_CFGS(X) \
-    X(128, 2, 4, 3)  \
-    X(128, 2, 4, 4)  \
-    X(128, 1, 4, 3)  \
-    X(128, 1, 4, 4)  \
-    X(64, 2, 4, 3)   \
-    X(64, 2, 4, 4)   \
-    X(64, 4, 4, 3)   \
-    X(64, 4, 4, 4)   \
-    X(64, 1, 4, 4)   \
-    X(256, 1, 4, 3)  \
-    X(128, 1, 8, 3)
+    X(128, 2, 4, 3, 1, 1)  \
+    X(128, 2, 4, 4, 1, 1)  \
+    X(128, 1, 4, 3, 1, 1)  \
+    X(128, 1, 4, 4, 1, 1)  \
+    X(64, 2, 4, 3, 1, 1)   \
+    X(64, 2, 4, 4, 1, 1)   \
+    X(64, 4, 4, 3, 1, 1)   \
+    X(64, 4, 4, 4, 1, 1)   \
+    X(64, 1, 4, 4, 1, 1)   \
+    X(256, 1, 4, 3, 1, 1)  \
+    X(128, 1, 8, 3, 1, 1)  \
+    X(64, 1, 4, 3, 2, 1)   \
+    X(64, 1, 4, 4, 2, 1)   \
+    X(64, 2, 4, 3, 2, 1)   \
+    X(64, 2, 4, 4, 2, 1)   \
+    X(64, 4, 4, 3, 2, 1)   \
+    X(128, 1, 4, 3, 2, 1)  \
+    X(128, 2, 4, 3, 2, 1)  \
+    X(256, 2, 8, 3, 1, 2)  \
+    X(256, 2, 8, 4, 1, 2)
 
-constexpr int wreg_lds(int bm, int nj, int nw, int s) {
+constexpr int wreg_lds(int bm, int nj, int nw, int s, int kt, int wgm) {
     // the A ring; the LayerNorm-producer epilogue reuses it for BM x (BN / 16) float2 block sums
-    const int ring = s * bm * 128, red = bm * nw * nj * 8;
+    const int ring = s * kt * bm * 128, red = bm * (nw / wgm) * nj * 8;
     return ring > red ? ring : red;
 }
+#define X(bm, nj, nw, st, kt, wgm) static_assert(wreg_lds(bm, nj, nw, st, kt, wgm) <= 160 * 1024, "wreg configuration exceeds the CU's LDS");
+MSD_WREG_CFGS(X)
+#undef X
+constexpr int wreg_code(int nw, int s, int kt) { return s + (nw == 8 ? 10 : 0) + (kt == 2 ? 20 : 0); }
 
 static bool g_wreg_attr_done = false;
 int msd_conv_wreg_init() {
     if (g_wreg_attr_done) return MSD_OK;
     hipError_t e = hipSuccess;
-#define X(bm, nj, nw, st)                                                                                              \
+#define X(bm, nj, nw, st, kt, wgm)                                                                                        \
     if (e == hipSuccess)                                                                                               \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<bm, nj, nw, st, false>),               \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, wreg_lds(bm, nj, nw, st));                 \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<bm, nj, nw, st, false, kt, wgm>),      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, wreg_lds(bm, nj, nw, st, kt, wgm));        \
     if (e == hipSuccess)                                                                                               \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<bm, nj, nw, st, true>),                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, wreg_lds(bm, nj, nw, st));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wreg_kernel<bm, nj, nw, st, true, kt, wgm>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, wreg_lds(bm, nj, nw, st, kt, wgm));
     MSD_WREG_CFGS(X)
 #undef X
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_wreg): %s", hipGetErrorString(e));
@@ -254,7 +314,7 @@ int msd_conv_wreg_init() {
 
 // 16-column blocks per wave of the configuration a (bm, bn, stages) request selects, 0 if it is not built
 int msd_conv_wreg_nj(int bm, int bn, int stages) {
-#define X(bm_, nj, nw, st) if (bm == bm_ && bn == nw * nj * 16 && stages == st + (nw == 8 ? 10 : 0)) return nj;
+#define X(bm_, nj, nw, st, kt, wgm) if (bm == bm_ && bn == (nw / wgm) * nj * 16 && stages == wreg_code(nw, st, kt)) return nj;
     MSD_WREG_CFGS(X)
 #undef X
     return 0;
@@ -265,12 +325,12 @@ int msd_conv_wreg_launch(const CGArgs& a, int bm, int bn, int stages, int slices
     int rc = msd_conv_wreg_init();
     if (rc) return rc;
     const dim3 grid(a.tiles_m * a.tiles_n, slices);
-#define X(bm_, nj, nw, st)                                                                                             \
-    if (bm == bm_ && bn == nw * nj * 16 && stages == st + (nw == 8 ? 10 : 0)) {                                        \
+#define X(bm_, nj, nw, st, kt, wgm)                                                                                    \
+    if (bm == bm_ && bn == (nw / wgm) * nj * 16 && stages == wreg_code(nw, st, kt)) {                                  \
         if (dense)                                                                                                     \
-            hipLaunchKernelGGL((conv_wreg_kernel<bm_, nj, nw, st, true>), grid, dim3(nw * 64), wreg_lds(bm_, nj, nw, st), stream, a); \
+            hipLaunchKernelGGL((conv_wreg_kernel<bm_, nj, nw, st, true, kt, wgm>), grid, dim3(nw * 64), wreg_lds(bm_, nj, nw, st, kt, wgm), stream, a); \
         else                                                                                                           \
-            hipLaunchKernelGGL((conv_wreg_kernel<bm_, nj, nw, st, false>), grid, dim3(nw * 64), wreg_lds(bm_, nj, nw, st), stream, a); \
+            hipLaunchKernelGGL((conv_wreg_kernel<bm_, nj, nw, st, false, kt, wgm>), grid, dim3(nw * 64), wreg_lds(bm_, nj, nw, st, kt, wgm), stream, a); \
         return MSD_OK;                                                                                                 \
     }
     MSD_WREG_CFGS(X)

@@ -31,10 +31,14 @@ HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (125
               (1128, 64, 63), (1128, 80, 63))   # 60 + depth: ... staged by two loader waves behind the compute waves
 
 
-# (4000 + rows per workgroup, columns per workgroup, ring depth [+ 10: 8 waves]): wreg form (csrc/conv_wreg.hip) — weights global ->
+# (4000 + rows per workgroup, columns per workgroup, ring depth [+ 10: 8 waves] [+ 20: two K tiles per stage]): wreg form (csrc/conv_wreg.hip) — weights global ->
 # VGPR from the fragment-major image, every wave owns all rows and its own 16-column blocks
 WREG_TILES = ((4128, 128, 3), (4128, 128, 4), (4128, 64, 3), (4128, 64, 4), (4064, 128, 3), (4064, 128, 4), (4064, 256, 3), (4064, 256, 4),
-              (4064, 64, 4), (4256, 64, 3), (4128, 128, 13))
+              (4064, 64, 4), (4256, 64, 3), (4128, 128, 13),
+              # stages 20 + depth: two K tiles (128 channels) per ring stage / wait / barrier
+              (4064, 64, 23), (4064, 64, 24), (4064, 128, 23), (4064, 128, 24), (4064, 256, 23), (4128, 64, 23), (4128, 128, 23),
+              # 256 rows on 8 waves as a 2 x 4 wave grid (128 rows x 2 blocks per wave)
+              (4256, 128, 13), (4256, 128, 14))
 
 
 # (rows per workgroup + 3000, columns per workgroup): row-panel Dense kernel (csrc/conv_rowpanel.hip) for the LayerNorm-

@@ -120,6 +120,19 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=16, W=16, c0=128, N=128, ks=3, stride=2, asym=True, tile_m=4064, tile_n=64, stages=4, same_as=(64, 64, 0)),
     dict(B=2, H=16, W=16, c0=64, N=128, ks=3, f32out=True, act="silu", tile_m=4128, tile_n=64, stages=3, same_as=(128, 64, 0)),
     dict(B=2, H=12, W=20, c0=64, N=128, ks=3, tile_m=4064, tile_n=64, stages=4, splitk=3, same_as=(64, 64, 0)),    # K = 9 tiles in 3 slices of 3 (< ring depth + 1)
+    # ... two K tiles per ring stage (stages 20 + depth): odd tile counts end in a half-full stage
+    dict(B=2, H=12, W=20, c0=64, N=128, ks=3, tile_m=4064, tile_n=64, stages=23, same_as=(64, 64, 0)),             # 9 tiles = 4 stages + 1 tile
+    dict(B=2, H=12, W=20, c0=64, N=128, ks=3, tile_m=4064, tile_n=64, stages=24, splitk=3, same_as=(64, 64, 0)),   # slices of 3 tiles: 1.5 stages each
+    dict(B=1, H=16, W=16, c0=320, N=320, ks=1, tile_m=4128, tile_n=64, stages=23, same_as=(128, 64, 0)),           # dense, 5 tiles
+    dict(B=2, H=8, W=8, c0=64, c1=128, N=64, ks=1, tile_m=4064, tile_n=128, stages=23, same_as=(64, 64, 0)),       # concat boundary inside a stage
+    dict(B=1, H=8, W=8, c0=1280, N=1280, ks=3, splitk=12, tile_m=4064, tile_n=128, stages=24, same_as=(64, 128, 0)),   # 8x8 level: 15 tiles per slice
+    dict(B=2, H=8, W=8, c0=128, c1=64, N=272, ks=3, tile_m=4064, tile_n=256, stages=23, same_as=(64, 64, 0)),      # 27 tiles, 4 blocks per wave
+    dict(B=2, H=16, W=16, c0=128, N=128, ks=3, stride=2, tile_m=4128, tile_n=128, stages=23, same_as=(128, 128, 0)),
+    dict(B=1, H=8, W=8, c0=128, N=128, ks=3, upsample=True, tile_m=4064, tile_n=64, stages=23, splitk=2, same_as=(64, 64, 0)),
+    # ... 256 rows on 8 waves as a 2 x 4 wave grid (stages 10 + depth, + 20 for two K tiles per stage)
+    dict(B=3, H=12, W=20, c0=64, N=192, ks=3, tile_m=4256, tile_n=128, stages=13, same_as=(256, 128, 0)),         # ragged M (720) and N
+    dict(B=2, H=16, W=16, c0=128, c1=64, N=128, ks=3, tile_m=4256, tile_n=128, stages=14, upsample=True, same_as=(256, 128, 0)),
+    dict(B=3, H=12, W=20, c0=128, N=320, ks=1, tile_m=4256, tile_n=128, stages=13, same_as=(128, 128, 0)),        # dense loader
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing
@@ -199,6 +212,7 @@ def test_conv_gemm(gpu, case):
     dict(B=2, H=12, W=20, c=64, cx0=128, cx1=0, N=100, ks=1, tile_m=128, tile_n=64, stages=13),   # 1x1 main part
     dict(B=2, H=8, W=8, c=192, cx0=128, cx1=64, N=192, ks=3, splitk=3, tile_m=4128, tile_n=128, stages=3),   # wreg form (fragment-major weights)
     dict(B=1, H=16, W=16, c=64, cx0=64, cx1=0, N=320, ks=3, tile_m=4064, tile_n=256, stages=4),
+    dict(B=2, H=8, W=8, c=192, cx0=128, cx1=64, N=192, ks=3, splitk=3, tile_m=4064, tile_n=128, stages=23),   # ... two K tiles per stage
 ])
 def test_conv_gemm_shortcut_operand(gpu, case):
     """conv(h) + conv1x1(x) as one contraction (diffusion_model.py:34-38,50): K = taps of h, then the channels of x."""
@@ -293,6 +307,9 @@ def test_conv_gemm_geglu(gpu, tile):
     dict(M=260, C=640, tile=(4064, 64, 4), mode="qkv", ctile=(4064, 256, 3), csame=True, psame=True),      # q | k | v^T split from 4 blocks per wave
     dict(M=136, C=1280, tile=(4128, 64, 3), mode="dense", ctile=(4256, 64, 3), psame=True, csame=True, nores=True),   # 20 partials per row
     dict(M=200, C=320, tile=(4128, 128, 3), mode="dense", ctile=(4128, 128, 13), csame=True),              # 128-column producer tiles (3 partials), 8-wave consumer
+    dict(M=300, C=320, tile=(4128, 64, 23), mode="geglu", ctile=(4064, 128, 23), csame=True, psame=True),  # two K tiles per stage, 5 tiles
+    dict(M=136, C=1280, tile=(4064, 64, 24), mode="qkv", ctile=(4064, 256, 23), csame=True, psame=True),
+    dict(M=600, C=320, tile=(4256, 128, 13), mode="geglu", ctile=(4256, 128, 14), csame=True),            # 2 x 4 wave grid: producer partials from both wave rows
 ])
 def test_conv_gemm_layer_norm_fold(gpu, case):
     """LayerNormalization folded into the GEMMs around it (diffusion_model.py:84-88 + Dense): the producer

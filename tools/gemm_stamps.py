@@ -34,7 +34,7 @@ def main():
     lib = _lib.load()
     lib.msd_init()
     lib.msd_set_option(b"conv_dense", args.dense)
-    for fn in (lib.msd_debug_stamps, lib.msd_debug_stamps_halo):
+    for fn in (lib.msd_debug_stamps, lib.msd_debug_stamps_halo, lib.msd_debug_stamps_wreg):
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_int]
     dev = torch.device("cuda:0")
@@ -55,17 +55,22 @@ def main():
         res = torch.randn(M, N, device=dev).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32)
+        wreg = tm >= 4000   # wreg form: tile 4000 + rows, fragment-major weights
+        if wreg:
+            from minsdtf_amd import packing
+
+            ws = [packing.fragment_major(wi) for wi in ws]
         calls = [ops.conv_gemm(a0=x, w=wi, out=out, batch=2, h_in=h, w_in=h, c0=cin, N=N, ksize=args.ks, bias=bias, residual=res,
-                               workspace=wsf, workspace_floats=wsf.numel(), splitk=sk, tile_m=tm, tile_n=tn, stages=stg)
+                               workspace=wsf, workspace_floats=wsf.numel(), splitk=sk, tile_m=tm, tile_n=tn, stages=stg, w_layout=2 if wreg else 0)
                  for wi in ws]
         for c in calls:          # the last call's stamps survive; weights rotate so they come from HBM
             c(st.cuda_stream)
         torch.cuda.synchronize()
-        halo = tm >= 1000
-        bm = (tm % 1000) if halo else tm
+        halo = 1000 <= tm < 3000
+        bm = (tm % 1000) if tm >= 1000 else tm
         nwg = ((M + bm - 1) // bm) * ((N + tn - 1) // tn) * sk
         buf = np.zeros(16 * 8192, np.uint64)
-        rc = (lib.msd_debug_stamps_halo if halo else lib.msd_debug_stamps)(buf.ctypes.data, buf.size)
+        rc = (lib.msd_debug_stamps_halo if halo else lib.msd_debug_stamps_wreg if wreg else lib.msd_debug_stamps)(buf.ctypes.data, buf.size)
         assert rc == 0, rc
         t = buf.reshape(8192, 16)[:min(nwg, 8192)].astype(np.int64)
         t0 = t[:, 0].min()

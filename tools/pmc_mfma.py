@@ -24,6 +24,8 @@ import os
 import sys
 
 FLOP_PER_CYCLE = 256 * 4 * 1024.0   # dense bf16 MFMA, whole chip
+XCDS = 8                            # rocprofv3 reports the raw GRBM_GUI_ACTIVE summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back);
+                                    # MfmaUtil's own formula takes the per-XCD maximum
 CONV = ("conv_gemm_dma", "conv3x3_halo", "dense_rowpanel", "conv_wreg")
 
 
@@ -78,7 +80,7 @@ def main():
     # the busiest XCD): executed FLOP / (1,048,576 x GUI cycles) has MfmaUtil's own denominator, so the two must agree if the busy
     # counter is right, whatever the clock; GUI cycles / duration is the clock the dispatch ran at (reads high on dispatches < 0.3 ms)
     xflop = {k: v[1] for k, v in counters(pmc_dir, "MfmaFlopsBF16").items()}
-    gui = {k: v[1] for k, v in counters(pmc_dir, "GRBM_GUI_ACTIVE").items()}
+    gui = {k: v[1] / XCDS for k, v in counters(pmc_dir, "GRBM_GUI_ACTIVE").items()}
     pmc_calls = json.load(open(os.path.join(pmc_dir, "calls.json")))
     plain_calls = json.load(open(os.path.join(plain_dir, "calls.json")))
     flop_pmc = join_calls(pmc_rows, pmc_calls["conv_calls"])
@@ -150,6 +152,13 @@ def main():
             r["clock_ghz_gui_cycles_over_pmc_duration"] = round(g_ / (pmc_us * 1e3), 3)
             if fl:
                 r["executed_over_algorithmic_flop"] = round(xf / fl, 3)
+            # RECONCILED: GRBM_GUI_ACTIVE keeps counting for a few microseconds around each dispatch (on dispatches of 60 us and more
+            # GUI cycles / duration equals the sampled shader clock; on 20-us dispatches it reads 3+ "GHz"), so MfmaUtil's denominator is
+            # too large on short dispatches.  Busy cycles over the cycles of the kernel's own start -> end interval at the sampled clock:
+            pmc_clock = (pmc_calls.get("sclk_mhz_max") or 2400.0) / 1e3
+            run_clock = clock_ghz   # (median sclk of the un-profiled pass: the PMC pass idles between its serialised dispatches)
+            r["mfma_busy_pct_over_kernel_interval_at_sampled_clock"] = round(r["mfma_util_pct_gui_weighted"] * g_ / (pmc_us * 1e3 * run_clock), 2)
+            r["sampled_clock_ghz"] = round(run_clock, 3)
         if fl:
             r["flop_busy_pct_pmc_pass_at_2.4GHz"] = round(frac(fl, pmc_us + fin_pmc, 2.4), 2)
             r["flop_busy_pct_plain_at_2.4GHz"] = round(frac(pl_fl, pl_us + fin_pl, 2.4), 2)
@@ -177,7 +186,7 @@ def main():
         calx = collections.defaultdict(list)
         for did, (k, v) in cx.items():
             if did in cg and cg[did][1] > 0:
-                calx[k].append(100.0 * v / (FLOP_PER_CYCLE * cg[did][1]))
+                calx[k].append(100.0 * v / (FLOP_PER_CYCLE * cg[did][1] / XCDS))
         # tools/mfma_rate.py launches every mode on 1 block and on 256 blocks (one wave per SIMD, every SIMD): the 256-block
         # dispatches are the larger readings
         res["calibration (bare MFMA loops, tools/mfma_rate.py)"] = {

@@ -22,10 +22,17 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--controlnet", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="msd_set_option switch, e.g. --opt gn_cluster=0")
     ap.add_argument("--calls-json", default=None,
                     help="write, in launch order, the algorithmic FLOP of every msd_conv_gemm call this process makes and the "
                          "shader clock sampled from sysfs while the steps run (tools/pmc_mfma.py joins it with the kernel trace)")
     args = ap.parse_args()
+    if args.opt:
+        from minsdtf_amd import _lib as _l
+
+        for kv in args.opt:
+            k, v = kv.split("=")
+            _l.check(_l.load().msd_set_option(k.encode(), int(v)), kv)
     conv_log, clk = [], {"mhz": [], "stop": False}
     if args.calls_json:
         from minsdtf_amd import _lib, ops

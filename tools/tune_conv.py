@@ -102,6 +102,13 @@ def collect_shapes(quick=False):
     return uniq
 
 
+def wreg_nj(bm, bn, stg):
+    """16-column blocks per wave of a wreg configuration (csrc/conv_wreg.hip MSD_WREG_CFGS): 4 waves over N, or 8 (stages code
+    10 + depth), except the 256-row tile whose 8 waves are a 2 x 4 grid."""
+    waves_n = 4 if (stg % 20 < 10 or bm == 4256) else 8
+    return bn // 16 // waves_n
+
+
 def tune_one(shape, iters=10):
     from minsdtf_amd import ops, tuning
 
@@ -131,7 +138,7 @@ def tune_one(shape, iters=10):
         cands += [t for t in tuning.WREG_TILES if not (t[1] > 64 and N <= 64)]
     frag = None
     for (bm, bn, stg) in cands:
-        if bm >= 4000 and allow_split is False and bn // (8 if stg >= 10 else 4) < 32:
+        if bm >= 4000 and allow_split is False and wreg_nj(bm, bn, stg) % 2:
             continue   # (the 'n' shapes include GEGLU, which pairs the two blocks of a wave)
         if bm < 3000:
             if bm == 256 and M < 1024:

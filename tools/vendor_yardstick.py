@@ -140,13 +140,45 @@ def measure(shape, iters):
     return res
 
 
+def write_md(rows, out, where):
+    """rows (the --json dump) -> the markdown table committed under profiles/."""
+    with open(out, "w") as f:
+        f.write(f"# Vendor yardstick for the conv / dense family ({where})\n\n")
+        f.write("`python tools/vendor_yardstick.py` — isolated launches, HIP events around back-to-back calls, random bf16 data, weights "
+                "rotating through > 256 MiB.  `ours` = the conv_tuning.json entry the pipeline launches (bias epilogue, split-K "
+                "reduction launch included).  `matmul` = `torch.matmul` bf16 (hipBLASLt) on an ALREADY im2col'ed `[M, K]` operand, "
+                "weights `[K, N]` / as stored `[N, K]`; `addmm` adds the bias; `conv2d` = `F.conv2d` bf16 channels-last (MIOpen), 3x3 "
+                "shapes only.  Ratio = fastest vendor time / ours (< 1: the vendor kernel is faster).  Off the product path.\n\n")
+        for nb in sorted({r["fused_batch"] for r in rows}):
+            sel = [r for r in rows if r["fused_batch"] == nb]
+            f.write(f"## fused batch {nb} (batch {nb // 2} per GPU with CFG)\n\n")
+            f.write("| shape | launches / step | M x N x K | ours us (TF/s) | config | matmul [K,N] | matmul [N,K] | addmm | conv2d | best vendor TF/s | vendor / ours |\n")
+            f.write("|---|---|---|---|---|---|---|---|---|---|---|\n")
+            tot_o = tot_v = 0.0
+            for r in sel:
+                vend = {k: v for k, v in r.items() if k.endswith("_us") and k != "ours_us"}
+                bv = min(vend.values())
+                tot_o += r["ours_us"] * r["launches_per_step"]
+                tot_v += bv * r["launches_per_step"]
+                f.write(f"| `{r['key']}` | {r['launches_per_step']} | {r['M']} x {r['N']} x {r['K']} | {r['ours_us']:.1f} ({r['gflop'] / r['ours_us'] * 1e3:.0f}) | "
+                        f"{r['ours_cfg']} | {r['matmul_kn_us']:.1f} | {r['matmul_nk_us']:.1f} | {r['addmm_us']:.1f} | "
+                        f"{r.get('conv2d_us', float('nan')):.1f} | {r['gflop'] / bv * 1e3:.0f} | {bv / r['ours_us']:.2f} |\n")
+            f.write(f"\nSum over one step's launches: ours {tot_o / 1e3:.3f} ms, per-shape best vendor kernel {tot_v / 1e3:.3f} ms "
+                    f"(ratio {tot_v / tot_o:.2f}).\n\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="profiles/r4_vendor_yardstick.md")
     ap.add_argument("--json", default=None)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batches", default="2,8", help="fused batches (2 = batch 1 with CFG, 8 = batch 4)")
+    ap.add_argument("--from-json", default=None, help="only re-write the markdown table from an earlier --json dump (no GPU needed)")
+    ap.add_argument("--where", default="MI355X", help="device / software line for --from-json")
     args = ap.parse_args()
+    if args.from_json:
+        write_md(json.load(open(args.from_json)), args.out, args.where)
+        return
     from minsdtf_amd import _lib, tuning
 
     _lib.load().msd_init()
@@ -169,29 +201,7 @@ def main():
         with open(args.json, "w") as f:
             json.dump(rows, f, indent=1)
     dev_name = torch.cuda.get_device_properties(0).name
-    with open(args.out, "w") as f:
-        f.write(f"# Vendor yardstick for the conv / dense family ({dev_name}, torch {torch.__version__})\n\n")
-        f.write("`python tools/vendor_yardstick.py` — isolated launches, HIP events around back-to-back calls, random bf16 data, weights "
-                "rotating through > 256 MiB.  `ours` = the conv_tuning.json entry the pipeline launches (bias epilogue, split-K "
-                "reduction launch included).  `matmul` = `torch.matmul` bf16 (hipBLASLt) on an ALREADY im2col'ed `[M, K]` operand, "
-                "weights `[K, N]` / as stored `[N, K]`; `addmm` adds the bias; `conv2d` = `F.conv2d` bf16 channels-last (MIOpen), 3x3 "
-                "shapes only.  Ratio = fastest vendor time / ours (< 1: the vendor kernel is faster).  Off the product path.\n\n")
-        for nb in sorted({r["fused_batch"] for r in rows}):
-            sel = [r for r in rows if r["fused_batch"] == nb]
-            f.write(f"## fused batch {nb} (batch {nb // 2} per GPU with CFG)\n\n")
-            f.write("| shape | launches / step | M x N x K | ours us (TF/s) | config | matmul [K,N] | matmul [N,K] | addmm | conv2d | best vendor TF/s | vendor / ours |\n")
-            f.write("|---|---|---|---|---|---|---|---|---|---|---|\n")
-            tot_o = tot_v = 0.0
-            for r in sel:
-                vend = {k: v for k, v in r.items() if k.endswith("_us") and k != "ours_us"}
-                bv = min(vend.values())
-                tot_o += r["ours_us"] * r["launches_per_step"]
-                tot_v += bv * r["launches_per_step"]
-                f.write(f"| `{r['key']}` | {r['launches_per_step']} | {r['M']} x {r['N']} x {r['K']} | {r['ours_us']:.1f} ({r["gflop"] / r["ours_us"] * 1e3:.0f}) | "
-                        f"{r['ours_cfg']} | {r['matmul_kn_us']:.1f} | {r['matmul_nk_us']:.1f} | {r['addmm_us']:.1f} | "
-                        f"{r.get('conv2d_us', float('nan')):.1f} | {r["gflop"] / bv * 1e3:.0f} | {bv / r['ours_us']:.2f} |\n")
-            f.write(f"\nSum over one step's launches: ours {tot_o / 1e3:.3f} ms, per-shape best vendor kernel {tot_v / 1e3:.3f} ms "
-                    f"(ratio {tot_v / tot_o:.2f}).\n\n")
+    write_md(rows, args.out, f"{dev_name}, torch {torch.__version__}")
     print(f"wrote {args.out} in {time.time() - t0:.0f}s")
 
 
