@@ -32,6 +32,11 @@ struct AArgs {
     int q_begin, q_count;           // attention32_kernel: the launch covers queries [q_begin, q_begin + q_count) of every sample (mg_qtiles: of that range)
 };
 
+// Kernarg preload (conv_common.h CG_HOT_PARAMS): the 16 dwords the kernels' prologues need, as leading scalar arguments
+#define ATTN_HOT_PARAMS const bf16_t* hot_q, const bf16_t* hot_k, const bf16_t* hot_vt, int hot_heads, int hot_s, int hot_t, int hot_q_ld, int hot_k_ld, \
+                        int hot_batch, uint32_t hot_mg_qtiles, uint32_t hot_mg_heads, int hot_q_begin, int hot_q_count
+#define ATTN_HOT_ARGS(a) (a).q, (a).k, (a).vt, (a).heads, (a).s, (a).t, (a).q_ld, (a).k_ld, (a).batch, (a).mg_qtiles, (a).mg_heads, (a).q_begin, (a).q_count
+
 // Maximum over the 4 lanes {l, l^16, l^32, l^48} (the four 16-lane rows of the wave), result on every lane: two
 // VALU row swaps (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute round trips through the LDS crossbar
 // (each ~100+ cycles of latency in the middle of the softmax's dependency chain).  v_max via asm: fmaxf() on these
@@ -69,7 +74,7 @@ __device__ __forceinline__ float rows_max4(float v) {
 //  16 cycles: ~750 issue cycles per tile and wave, measured ~1600 per tile for the two waves of a SIMD; overlapping inside
 //  one wave adds registers (190 vs 152: one wave per SIMD fewer) and removes no instruction.)
 template <int D, int NBUF, int QF = 2, bool PRESC = false>
-__global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
+__global__ __launch_bounds__(256) void attention_kernel(ATTN_HOT_PARAMS, const AArgs p) {
     constexpr bool PIPE = NBUF == 2;
     constexpr int QT = 64 * QF;          // queries per workgroup
     constexpr int DPAD = ((D + 31) / 32) * 32;
@@ -86,10 +91,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
     const int r = lane & 15, g = lane >> 4;
     // 1-D grid, XCD-aware: all query tiles of one (batch, head) run on one XCD so its K / V^T
     // (655 KB at S=4096, d=40) stay in that XCD's L2 instead of every XCD streaming all heads
-    const int qtiles = (p.s + QT - 1) / QT;
-    const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);   // (= gridDim.x, without reading the implicit arguments)
-    const int bh = udiv_magic(wi, qtiles, p.mg_qtiles);
-    const int b = udiv_magic(bh, p.heads, p.mg_heads), h = bh - b * p.heads;
+    const int qtiles = (hot_s + QT - 1) / QT;
+    const int wi = xcd_remap(blockIdx.x, qtiles * hot_heads * hot_batch);   // (= gridDim.x, without reading the implicit arguments)
+    const int bh = udiv_magic(wi, qtiles, hot_mg_qtiles);
+    const int b = udiv_magic(bh, hot_heads, hot_mg_heads), h = bh - b * hot_heads;
     const int q0 = (wi - bh * qtiles) * QT + wave * (16 * QF);
 
     // zero the whole LDS image once: pad columns / pad rows are never written afterwards
@@ -115,9 +120,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 #pragma unroll
     for (int f = 0; f < QF; ++f) { mref[f] = 0.f; lrun[f] = 0.f; negm[f] = (f32x4){0, 0, 0, 0}; }
 
-    const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
-    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
-    const int ntiles = (p.t + 63) / 64;
+    const bf16_t* kbase = hot_k + (size_t)b * hot_t * hot_k_ld + h * D;
+    const bf16_t* vbase = hot_vt + ((size_t)b * hot_heads + h) * D * p.vt_ld;
+    const int ntiles = (hot_t + 63) / 64;
 
     // K / V^T tile staging: global -> registers (issued ahead when PIPE) -> LDS.
     // Per-thread source pointers / LDS offsets are fixed for the whole kernel; a full tile
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         kin[i] = idx < 64 * DCH;
         const int row = kin[i] ? idx / DCH : 0, ch = kin[i] ? idx - row * DCH : 0;
         krow[i] = row;
-        kptr[i] = kbase + (size_t)row * p.k_ld + ch * 8;
+        kptr[i] = kbase + (size_t)row * hot_k_ld + ch * 8;
         klds[i] = row * KROW + ch * 16;
     }
 #pragma unroll
@@ -148,8 +153,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         vlds[i] = d * VROW + ch * 16;
     }
     auto gload = [&](int t0) {
-        const size_t koff = (size_t)t0 * p.k_ld;
-        if (t0 + 64 <= p.t) {
+        const size_t koff = (size_t)t0 * hot_k_ld;
+        if (t0 + 64 <= hot_t) {
 #pragma unroll
             for (int i = 0; i < KCH; ++i)
                 if (kin[i]) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
@@ -160,13 +165,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
                 rk[i] = make_uint4(0, 0, 0, 0);
-                if (kin[i] && t0 + krow[i] < p.t) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
+                if (kin[i] && t0 + krow[i] < hot_t) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
             }
 #pragma unroll
             for (int i = 0; i < VCH; ++i) {
                 rv[i] = make_uint4(0, 0, 0, 0);
                 const int key0 = t0 + vkey[i];
-                if (vin[i] && key0 + 8 <= p.vt_ld && key0 < p.t) rv[i] = *reinterpret_cast<const uint4*>(vptr[i] + t0);
+                if (vin[i] && key0 + 8 <= p.vt_ld && key0 < hot_t) rv[i] = *reinterpret_cast<const uint4*>(vptr[i] + t0);
             }
         }
     };
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 #pragma unroll
         for (int i = 0; i < KCH; ++i)
             if (kin[i]) *reinterpret_cast<uint4*>(dK + klds[i]) = rk[i];
-        if (t0 + 64 <= p.t) {
+        if (t0 + 64 <= hot_t) {
 #pragma unroll
             for (int i = 0; i < VCH; ++i)
                 if (vin[i]) *reinterpret_cast<uint4*>(dV + vlds[i]) = rv[i];
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
             for (int i = 0; i < VCH; ++i) {
                 if (!vin[i]) continue;
                 uint4 v = rv[i];
-                const int valid = p.t - (t0 + vkey[i]);  // keys >= t are padding of unspecified content: force to 0
+                const int valid = hot_t - (t0 + vkey[i]);  // keys >= t are padding of unspecified content: force to 0
                 if (valid < 8) {
                     uint32_t* u = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
@@ -204,8 +209,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         int qrow = q0 + f * 16 + r;
-        if (qrow > p.s - 1) qrow = p.s - 1;
-        const bf16_t* qp = p.q + ((size_t)b * p.s + qrow) * p.q_ld + h * D;
+        if (qrow > hot_s - 1) qrow = hot_s - 1;
+        const bf16_t* qp = hot_q + ((size_t)b * hot_s + qrow) * hot_q_ld + h * D;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d0 = ks * 32 + 8 * g;
@@ -245,14 +250,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         const int t0 = tile * 64;
         // (the key index is made opaque INSIDE each branch: otherwise hipcc hoists its 16 adds out of both branches into
         //  every tile's straight-line path — 64 issue cycles of ~750 — although self-attention tiles take neither branch)
-        if (t0 + 64 > p.t) {  // ragged key tail (text context): only this tile pays for the masking
+        if (t0 + 64 > hot_t) {  // ragged key tail (text context): only this tile pays for the masking
             int key0 = t0 + 4 * g;
             asm volatile("" : "+v"(key0));
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (key0 + kf * 16 + e >= p.t) {
+                    if (key0 + kf * 16 + e >= hot_t) {
 #pragma unroll
                         for (int f = 0; f < QF; ++f) s[kf][f][e] = -1e30f;
                     }
@@ -394,8 +399,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AArgs p) {
         }
         const float inv = 1.0f / lt;
         const int qrow = q0 + f * 16 + r;
-        if (qrow < p.s) {
-            bf16_t* op = p.out + ((size_t)b * p.s + qrow) * p.o_ld + h * D;
+        if (qrow < hot_s) {
+            bf16_t* op = p.out + ((size_t)b * hot_s + qrow) * p.o_ld + h * D;
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
                 const int d = df * 16 + 4 * g;
@@ -467,7 +472,7 @@ extern "C" MSD_API int msd_debug_stamps_attn(unsigned long long* host_out, int c
 __host__ __device__ constexpr int attn32_loaders(int nbuf, int nw, int d) { return nbuf == 4 ? ((nw >= 8 || d > 64) ? 2 : 1) : 0; }
 
 template <int D, int NBUF, int NW, bool PRESC>
-__global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void attention32_kernel(const AArgs p) {
+__global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void attention32_kernel(ATTN_HOT_PARAMS, const AArgs p) {
     constexpr bool SWP = NBUF == 4;          // software-pipelined tile loop (below)
     // SWP, prescaled q, head size with a padded k-step (d = 40 -> 48): the reference maximum rides in the padding — channel
     // D of every K row is 1, channel D of the query holds -m_ref (a bf16 value; any reference works as long as every use
@@ -488,12 +493,12 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int qtiles = (p.q_count + QT - 1) / QT;
-    const int q_end = p.q_begin + p.q_count;   // (<= p.s)
-    const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);
-    const int bh = udiv_magic(wi, qtiles, p.mg_qtiles);
-    const int b = udiv_magic(bh, p.heads, p.mg_heads), hd = bh - b * p.heads;
-    const int q0 = p.q_begin + (wi - bh * qtiles) * QT + wave * 32;
+    const int qtiles = (hot_q_count + QT - 1) / QT;
+    const int q_end = hot_q_begin + hot_q_count;   // (<= hot_s)
+    const int wi = xcd_remap(blockIdx.x, qtiles * hot_heads * hot_batch);
+    const int bh = udiv_magic(wi, qtiles, hot_mg_qtiles);
+    const int b = udiv_magic(bh, hot_heads, hot_mg_heads), hd = bh - b * hot_heads;
+    const int q0 = hot_q_begin + (wi - bh * qtiles) * QT + wave * 32;
 
     if constexpr (SWP) {
         // The DMAs write every data slot of a tile image before it is read; only what they leave alone needs a value: the pad
@@ -537,9 +542,9 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
 #pragma unroll
     for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 
-    const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + hd * D;
-    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + hd) * D * p.vt_ld;
-    const int ntiles = (p.t + 63) / 64;
+    const bf16_t* kbase = hot_k + (size_t)b * hot_t * hot_k_ld + hd * D;
+    const bf16_t* vbase = hot_vt + ((size_t)b * hot_heads + hd) * D * p.vt_ld;
+    const int ntiles = (hot_t + 63) / 64;
     constexpr int KCH = (64 * DCH + NT - 1) / NT, VCH = (D * 8 + NT - 1) / NT;
     uint4 rk[KCH], rv[VCH];
     const bf16_t* kptr[KCH];
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
         kin[i] = idx < 64 * DCH;
         const int row = kin[i] ? idx / DCH : 0, ch = kin[i] ? idx - row * DCH : 0;
         krow[i] = row;
-        kptr[i] = kbase + (size_t)row * p.k_ld + ch * 8;
+        kptr[i] = kbase + (size_t)row * hot_k_ld + ch * 8;
         klds[i] = row * KROW + ch * 16;
     }
 #pragma unroll
@@ -566,8 +571,8 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
         vlds[i] = d * VROW + ((ch >> 1) * 16 + (ch & 1) * 4) * 2;
     }
     auto gload = [&](int t0) {
-        const size_t koff = (size_t)t0 * p.k_ld;
-        if (t0 + 64 <= p.t) {
+        const size_t koff = (size_t)t0 * hot_k_ld;
+        if (t0 + 64 <= hot_t) {
 #pragma unroll
             for (int i = 0; i < KCH; ++i)
                 if (kin[i]) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
@@ -578,13 +583,13 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
                 rk[i] = make_uint4(0, 0, 0, 0);
-                if (kin[i] && t0 + krow[i] < p.t) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
+                if (kin[i] && t0 + krow[i] < hot_t) rk[i] = *reinterpret_cast<const uint4*>(kptr[i] + koff);
             }
 #pragma unroll
             for (int i = 0; i < VCH; ++i) {
                 rv[i] = make_uint4(0, 0, 0, 0);
                 const int key0 = t0 + vkey[i];
-                if (vin[i] && key0 + 8 <= p.vt_ld && key0 < p.t) rv[i] = *reinterpret_cast<const uint4*>(vptr[i] + t0);
+                if (vin[i] && key0 + 8 <= p.vt_ld && key0 < hot_t) rv[i] = *reinterpret_cast<const uint4*>(vptr[i] + t0);
             }
         }
     };
@@ -597,8 +602,8 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
         for (int i = 0; i < VCH; ++i) {
             if (!vin[i]) continue;
             uint4 v = rv[i];
-            if (t0 + 64 > p.t) {   // ragged last tile: keys >= t are padding of unspecified content, force them to 0
-                const int valid = p.t - (t0 + vkey[i]);
+            if (t0 + 64 > hot_t) {   // ragged last tile: keys >= t are padding of unspecified content, force them to 0
+                const int valid = hot_t - (t0 + vkey[i]);
                 if (valid < 8) {
                     uint32_t* u = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
@@ -617,8 +622,8 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
     bf16x8 qf[KS];
     {
         int qrow = q0 + c;
-        if (qrow > p.s - 1) qrow = p.s - 1;
-        const bf16_t* qp = p.q + ((size_t)b * p.s + qrow) * p.q_ld + hd * D;
+        if (qrow > hot_s - 1) qrow = hot_s - 1;
+        const bf16_t* qp = hot_q + ((size_t)b * hot_s + qrow) * hot_q_ld + hd * D;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d0 = ks * 16 + 8 * h;
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
             const int q = ldr + NL * n;
             const int sidx = 64 * q + lane, row = sidx / KSL, ch = sidx - row * KSL;
             const bool on = q < KI && ch < DCH;
-            kvo[n] = on ? (uint32_t)(row * p.k_ld * 2 + ch * 16) : 0u;
+            kvo[n] = on ? (uint32_t)(row * hot_k_ld * 2 + ch * 16) : 0u;
             kon[n] = __builtin_amdgcn_ballot_w64(on);
         }
 #pragma unroll
@@ -689,13 +694,13 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
             vvo[n] = on ? (uint32_t)(row * p.vt_ld * 2 + ch * 16) : 0u;
             von[n] = __builtin_amdgcn_ballot_w64(on);
         }
-        const size_t kstep = (size_t)p.k_ld * 128;          // bytes per 64-key tile
+        const size_t kstep = (size_t)hot_k_ld * 128;          // bytes per 64-key tile
         const char* kb_next = reinterpret_cast<const char*>(kbase);   // source of the next tile to stage
         const char* vb_next = reinterpret_cast<const char*>(vbase);
         int t0_next = 0;
         auto stage = [&](int slot) {   // the next tile -> ring slot; returns with the DMAs in flight
             const uint32_t dst0 = lds0 + (uint32_t)(slot * BUF_BYTES);
-            if (t0_next + 64 <= p.t) {
+            if (t0_next + 64 <= hot_t) {
 #pragma unroll
                 for (int n = 0; n < NKL; ++n)
                     if (kon[n]) dma16sm(kb_next, kvo[n], dst0 + (uint32_t)(n * NL * 1024), kon[n]);
@@ -704,17 +709,17 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
                     if (von[n]) dma16sm(vb_next, vvo[n], dst0 + (uint32_t)(64 * KROW + n * NL * 1024), von[n]);
             } else {
                 const int t0 = t0_next;
-                const uint32_t klim = (uint32_t)(((p.t - 1 - t0) * p.k_ld + (D - 8)) * 2);
+                const uint32_t klim = (uint32_t)(((hot_t - 1 - t0) * hot_k_ld + (D - 8)) * 2);
 #pragma unroll
                 for (int n = 0; n < NKL; ++n)
                     if (kon[n]) dma16sm(kb_next, min(kvo[n], klim), dst0 + (uint32_t)(n * NL * 1024), kon[n]);
                 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
                 char* dV = smem + slot * BUF_BYTES + 64 * KROW;
-                const uint32_t clim = (uint32_t)(((p.t - 1 - t0) >> 3) * 16);
+                const uint32_t clim = (uint32_t)(((hot_t - 1 - t0) >> 3) * 16);
                 for (int idx = ldr * 64 + lane; idx < D * 8; idx += 64 * NL) {
                     const int d = idx >> 3, ch = idx & 7;
                     u32x4_t v = *reinterpret_cast<const u32x4_t*>(vb_next + ((size_t)d * p.vt_ld * 2 + min((uint32_t)(ch * 16), clim)));
-                    const int valid = p.t - (t0 + ch * 8);
+                    const int valid = hot_t - (t0 + ch * 8);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (2 * j >= valid) v[j] = 0;
@@ -814,14 +819,14 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
         ASTAMP(0, mref);
         qk(nxt, smem + slot1 * BUF_BYTES);   // (past the last tile: a slot of finite leftovers, the result is never used)
         if (MASKED) {
-            if (t0 + 64 > p.t) {
+            if (t0 + 64 > hot_t) {
                 int key0 = t0 + 8 * h;
                 asm volatile("" : "+v"(key0));
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        if (key0 + kb * 32 + (i & 7) + 16 * (i >> 3) >= p.t) cur[kb][i] = -1e30f;
+                        if (key0 + kb * 32 + (i & 7) + 16 * (i >> 3) >= hot_t) cur[kb][i] = -1e30f;
             }
             if (p.causal) {
                 int key0 = t0 + 8 * h;
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
     qk(sA, smem);
     int tile = 0, slot = 0;
     if (!p.causal) {
-        const int nfull = p.t >> 6;   // tiles without a ragged tail
+        const int nfull = hot_t >> 6;   // tiles without a ragged tail
         for (; tile + 2 <= nfull; tile += 2) {
             step(std::false_type{}, sA, sB, tile, slot);
             slot = (slot + 1) & 3;
@@ -975,14 +980,14 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
             }
         ASTAMP(1, sacc[1][0]);
         // ---- masks (ragged key tail, causal): only the tiles that need them pay
-        if (t0 + 64 > p.t) {
+        if (t0 + 64 > hot_t) {
             int key0 = t0 + 4 * h;
             asm volatile("" : "+v"(key0));
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (key0 + kb * 32 + (i & 3) + 8 * (i >> 2) >= p.t) sacc[kb][i] = -1e30f;
+                    if (key0 + kb * 32 + (i & 3) + 8 * (i >> 2) >= hot_t) sacc[kb][i] = -1e30f;
         }
         if (p.causal) {
             int key0 = t0 + 4 * h;
@@ -1088,7 +1093,7 @@ __global__ __launch_bounds__(64 * (NW + attn32_loaders(NBUF, NW, D))) void atten
     }
     const float inv = 1.0f / lt;
     const int qrow = q0 + c;
-    bf16_t* op = p.out + ((size_t)b * p.s + min(qrow, p.s - 1)) * p.o_ld + hd * D;
+    bf16_t* op = p.out + ((size_t)b * hot_s + min(qrow, hot_s - 1)) * p.o_ld + hd * D;
     if ((p.o_ld & 7) == 0) {
         // 16-byte stores: one half-wave swap per register turns (group 2j of this lane, group 2j of the other half) into 8
         // consecutive channels — lower half: channels 16 j + 0..7, upper half: 16 j + 8..15 of the 32-channel block
@@ -1145,7 +1150,11 @@ struct XArgs {
 // NW waves = 16 NW queries per workgroup (4 or 8: the weight / K / V^T images are shared by twice the queries; the host picks 8
 // when the 64-query grid would need more than one round of workgroups).
 template <int D, int NW>
-__global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
+// (leading scalars: kernarg preload — x, wq, k (6 dwords) + batch, heads, s, t, k_ld, ln_slots, w_rs, w_ks, mg_heads, mg_qtiles)
+#define XATTN_HOT_PARAMS const bf16_t* hot_x, const bf16_t* hot_wq, const bf16_t* hot_k, int hot_batch, int hot_heads, int hot_s, int hot_t, int hot_k_ld, \
+                         int hot_ln_slots, uint32_t hot_w_rs, uint32_t hot_w_ks, uint32_t hot_mg_heads, uint32_t hot_mg_qtiles
+#define XATTN_HOT_ARGS(a) (a).x, (a).wq, (a).k, (a).batch, (a).heads, (a).s, (a).t, (a).k_ld, (a).ln_slots, (a).w_rs, (a).w_ks, (a).mg_heads, (a).mg_qtiles
+__global__ __launch_bounds__(64 * NW) void xattn_q_kernel(XATTN_HOT_PARAMS, const XArgs p) {
     constexpr int NT = 64 * NW, QT = 16 * NW;
     constexpr int C = 8 * D;                  // (8 heads: SD1.5)
     constexpr int KC = C / 64;                // 64-channel chunks of the projection's K
@@ -1166,10 +1175,10 @@ __global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int qtiles = (p.s + QT - 1) / QT;
-    const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);
-    const int qt_b = udiv_magic(wi, p.heads, p.mg_heads), h = wi - qt_b * p.heads;     // head fastest: the 8 heads of a tile share x
-    const int b = udiv_magic(qt_b, qtiles, p.mg_qtiles);
+    const int qtiles = (hot_s + QT - 1) / QT;
+    const int wi = xcd_remap(blockIdx.x, qtiles * hot_heads * hot_batch);
+    const int qt_b = udiv_magic(wi, hot_heads, hot_mg_heads), h = wi - qt_b * hot_heads;     // head fastest: the 8 heads of a tile share x
+    const int b = udiv_magic(qt_b, qtiles, hot_mg_qtiles);
     const int q0 = (qt_b - b * qtiles) * QT + wave * 16;
 
     // ---- 1. everything this workgroup reads, issued at once: weight DMAs first (oldest in the queue), then plain loads
@@ -1179,25 +1188,25 @@ __global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
 #pragma unroll
         for (int rr = 0; rr < WR / 32; ++rr) {
             const int row = rr * 32 + lrow;
-            const uint32_t off = (uint32_t)(h * D + min(row, D - 1)) * p.w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
+            const uint32_t off = (uint32_t)(h * D + min(row, D - 1)) * hot_w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
-                dma16s(p.wq, off + (uint32_t)kc * p.w_ks, __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)(kc * WR + rr * 32) * 128u));
+                dma16s(hot_wq, off + (uint32_t)kc * hot_w_ks, __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)(kc * WR + rr * 32) * 128u));
         }
     }
     bf16x8 xf[KC * 2];
-    const int qrow = min(q0 + r, p.s - 1);
+    const int qrow = min(q0 + r, hot_s - 1);
     {
-        const bf16_t* src = p.x + ((size_t)b * p.s + qrow) * C + g * 8;
+        const bf16_t* src = hot_x + ((size_t)b * hot_s + qrow) * C + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KC * 2; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 32);
     }
     constexpr int LNS = 5;   // (LN_MAX_SLOTS / 4 of conv_common.h)
     float2 lnp[LNS];
     {
-        const float2* src = reinterpret_cast<const float2*>(p.ln_in) + ((size_t)b * p.s + qrow) * p.ln_slots;
+        const float2* src = reinterpret_cast<const float2*>(p.ln_in) + ((size_t)b * hot_s + qrow) * hot_ln_slots;
 #pragma unroll
-        for (int k = 0; k < LNS; ++k) lnp[k] = src[min(g + 4 * k, p.ln_slots - 1)];
+        for (int k = 0; k < LNS; ++k) lnp[k] = src[min(g + 4 * k, hot_ln_slots - 1)];
     }
     float4 csv[DB], bsv[DB];   // column sums / folded bias of this lane's 4 head channels per block (clamped: masked below)
 #pragma unroll
@@ -1208,19 +1217,19 @@ __global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
     }
     constexpr int KCH = (TPAD * DCH + NT - 1) / NT, VCH = (D * (TPAD / 8) + NT - 1) / NT;
     uint4 rk[KCH], rv[VCH];
-    const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
-    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
+    const bf16_t* kbase = hot_k + (size_t)b * hot_t * hot_k_ld + h * D;
+    const bf16_t* vbase = p.vt + ((size_t)b * hot_heads + h) * D * p.vt_ld;
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
         const int idx = tid + NT * i, key = idx / DCH, ch = idx - key * DCH;
         rk[i] = make_uint4(0, 0, 0, 0);
-        if (key < p.t) rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * p.k_ld + ch * 8);
+        if (key < hot_t) rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * hot_k_ld + ch * 8);
     }
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
         const int idx = tid + NT * i, d = idx / (TPAD / 8), ch = idx - d * (TPAD / 8);
         rv[i] = make_uint4(0, 0, 0, 0);
-        if (d < D && ch * 8 + 8 <= p.vt_ld && ch * 8 < p.t) rv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + ch * 8);
+        if (d < D && ch * 8 + 8 <= p.vt_ld && ch * 8 < hot_t) rv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)d * p.vt_ld + ch * 8);
     }
     // K / V^T images: zero everything (pad rows / columns are never written), then the loaded pieces
     for (int off = tid * 16; off < K_BYTES + V_BYTES; off += NT * 16) *reinterpret_cast<uint4*>(sK + off) = make_uint4(0, 0, 0, 0);
@@ -1228,14 +1237,14 @@ __global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
         const int idx = tid + NT * i, key = idx / DCH, ch = idx - key * DCH;
-        if (key < p.t) *reinterpret_cast<uint4*>(sK + key * KROW + ch * 16) = rk[i];
+        if (key < hot_t) *reinterpret_cast<uint4*>(sK + key * KROW + ch * 16) = rk[i];
     }
 #pragma unroll
     for (int i = 0; i < VCH; ++i) {
         const int idx = tid + NT * i, d = idx / (TPAD / 8), ch = idx - d * (TPAD / 8);
-        if (d >= D || ch * 8 >= p.t) continue;
+        if (d >= D || ch * 8 >= hot_t) continue;
         uint4 v = rv[i];
-        const int valid = p.t - ch * 8;   // keys >= t are padding of unspecified content: force to 0
+        const int valid = hot_t - ch * 8;   // keys >= t are padding of unspecified content: force to 0
         if (valid < 8) {
             uint32_t* u = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
@@ -1252,7 +1261,7 @@ __global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < LNS; ++k)
-            if (g + 4 * k < p.ln_slots) { s1 += lnp[k].x; s2 += lnp[k].y; }
+            if (g + 4 * k < hot_ln_slots) { s1 += lnp[k].x; s2 += lnp[k].y; }
         s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         mean = s1 * p.ln_inv_k;
@@ -1312,7 +1321,7 @@ __global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
     for (int kb = 0; kb < TB; ++kb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (kb * 16 + 4 * g + e >= p.t) sacc[kb][e] = -1e30f;
+            if (kb * 16 + 4 * g + e >= hot_t) sacc[kb][e] = -1e30f;
             m = fmaxf(m, sacc[kb][e]);
         }
     m = rows_max4(m);
@@ -1347,9 +1356,9 @@ __global__ __launch_bounds__(64 * NW) void xattn_q_kernel(const XArgs p) {
             oacc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, oacc[bb], 0, 0, 0);
         }
     }
-    if (q0 + r < p.s) {
+    if (q0 + r < hot_s) {
         const float inv = 1.0f / lsum;
-        bf16_t* op = p.out + ((size_t)b * p.s + q0 + r) * p.o_ld + h * D;
+        bf16_t* op = p.out + ((size_t)b * hot_s + q0 + r) * p.o_ld + h * D;
 #pragma unroll
         for (int bb = 0; bb < DB; ++bb) {
             const int d = bb * 16 + 4 * g;
@@ -1614,15 +1623,15 @@ int msd_attention_init() {
 template <int D, int NBUF, int QF>
 static void attn_launch2(const AArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int lds = attn_lds_bytes<D, NBUF>();
-    if (a.presc) hipLaunchKernelGGL((attention_kernel<D, NBUF, QF, true>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((attention_kernel<D, NBUF, QF, false>), grid, dim3(256), lds, stream, a);
+    if (a.presc) hipLaunchKernelGGL((attention_kernel<D, NBUF, QF, true>), grid, dim3(256), lds, stream, ATTN_HOT_ARGS(a), a);
+    else hipLaunchKernelGGL((attention_kernel<D, NBUF, QF, false>), grid, dim3(256), lds, stream, ATTN_HOT_ARGS(a), a);
 }
 template <int D, int NBUF, int NW>
 static void attn32_launch2(const AArgs& a, dim3 grid, hipStream_t stream) {
     constexpr int lds = attn32_lds_bytes<D, NBUF>();
     constexpr int threads = 64 * (NW + attn32_loaders(NBUF, NW, D));   // (NBUF 4: the software-pipelined form, NW compute waves + the loader wave)
-    if (a.presc) hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, true>), grid, dim3(threads), lds, stream, a);
-    else hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, false>), grid, dim3(threads), lds, stream, a);
+    if (a.presc) hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, true>), grid, dim3(threads), lds, stream, ATTN_HOT_ARGS(a), a);
+    else hipLaunchKernelGGL((attention32_kernel<D, NBUF, NW, false>), grid, dim3(threads), lds, stream, ATTN_HOT_ARGS(a), a);
 }
 // The software-pipelined form needs a walk long enough to pay for its longer prologue (three tiles staged before the first
 // product): key walks of 4 tiles and more.  A function of the head size and the key count only — the forms round differently.
@@ -1776,11 +1785,11 @@ extern "C" int msd_cross_attention_q(const MsdCrossAttnQ* q, msd_stream_t stream
     a.mg_heads = udiv_magic_of(q->heads); a.mg_qtiles = udiv_magic_of(qtiles);
     const dim3 grid((unsigned)qtiles * q->heads * q->batch);
     if (q->head_dim == 40) {
-        if (nw == 8) hipLaunchKernelGGL((xattn_q_kernel<40, 8>), grid, dim3(512), xattn_lds<40>(), stream, a);
-        else hipLaunchKernelGGL((xattn_q_kernel<40, 4>), grid, dim3(256), xattn_lds<40>(), stream, a);
+        if (nw == 8) hipLaunchKernelGGL((xattn_q_kernel<40, 8>), grid, dim3(512), xattn_lds<40>(), stream, XATTN_HOT_ARGS(a), a);
+        else hipLaunchKernelGGL((xattn_q_kernel<40, 4>), grid, dim3(256), xattn_lds<40>(), stream, XATTN_HOT_ARGS(a), a);
     } else {
-        if (nw == 8) hipLaunchKernelGGL((xattn_q_kernel<80, 8>), grid, dim3(512), xattn_lds<80>(), stream, a);
-        else hipLaunchKernelGGL((xattn_q_kernel<80, 4>), grid, dim3(256), xattn_lds<80>(), stream, a);
+        if (nw == 8) hipLaunchKernelGGL((xattn_q_kernel<80, 8>), grid, dim3(512), xattn_lds<80>(), stream, XATTN_HOT_ARGS(a), a);
+        else hipLaunchKernelGGL((xattn_q_kernel<80, 4>), grid, dim3(256), xattn_lds<80>(), stream, XATTN_HOT_ARGS(a), a);
     }
     MSD_CHECK_LAUNCH();
     return MSD_OK;

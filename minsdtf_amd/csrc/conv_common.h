@@ -23,6 +23,14 @@ struct CGArgs {
     uint32_t w_rs, w_ks;   // weight addressing in bytes: row (output column) stride, K-chunk stride ([N][K]: 2K, 128; chunk-major: 128, 128 N)
 };
 
+// Kernarg preload: the kernels take the fields their prologue needs FIRST as leading scalar arguments (15 dwords) in front of the
+// argument block; built with -mllvm -amdgpu-kernarg-preload-count=16 these arrive in SGPRs with the wave, so tile mapping and loader
+// coordinates start without waiting for the first scalar-memory round trip (a struct argument is never preloaded).  CG_HOT_ARGS(a) is
+// the launch side, CG_HOT_PARAMS the kernel side (the prologue reads hot_* where it would read p.*; the same values).
+#define CG_HOT_PARAMS const bf16_t* hot_a0, const bf16_t* hot_w, int hot_M, int hot_N, int hot_c0, int hot_tiles_m, int hot_tiles_n, \
+                      int hot_m_fast, int hot_nk_per, int hot_nk, uint32_t hot_mg_tdiv, uint32_t hot_w_rs, uint32_t hot_w_ks
+#define CG_HOT_ARGS(a) (a).a0, (a).w, (a).M, (a).N, (a).c0, (a).tiles_m, (a).tiles_n, (a).m_fast, (a).nk_per, (a).nk, (a).mg_tdiv, (a).w_rs, (a).w_ks
+
 static __device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows (one copy per TU)
 
 
@@ -87,6 +95,46 @@ __device__ __forceinline__ void cg_store4(const CGArgs& p, int m, int b, int n, 
             dst[(size_t)2 * p.out2_ld] = (bf16_t)(o.y & 0xFFFF);
             dst[(size_t)3 * p.out2_ld] = (bf16_t)(o.y >> 16);
         }
+    }
+}
+
+// The same with the operands already in registers (splitk_finalize_kernel issues their loads together with the slab loads); an absent
+// operand arrives as zeros with its flag off.  Same expressions in the same order as cg_store4: the same bits.
+__device__ __forceinline__ void cg_store4_pre(const CGArgs& p, int m, int b, int n, float v[4], float4 bv, bool has_b, float4 rv, bool has_rv,
+                                              uint2 rr, bool has_r) {
+    if (has_b) { v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+    if (has_rv) { v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+    if (p.act == MSD_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    } else if (p.act == MSD_ACT_QUICK_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_rcp(1.0f + __expf(-1.702f * v[e]));
+    }
+    if (p.split_mode == 0) {
+        if (has_r) { v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y); }
+        if (p.out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+        }
+        return;
+    }
+    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+    if (n < p.ns0) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n) = o;
+    } else if (n < p.ns0 + p.ns1) {
+        *reinterpret_cast<uint2*>(p.out1 + (size_t)m * p.out1_ld + (n - p.ns0)) = o;
+    } else {
+        const int nv = p.N - p.ns0 - p.ns1;
+        const int nn = n - p.ns0 - p.ns1;
+        const int sidx = m - b * p.hw_out;
+        bf16_t* dst = p.out2 + ((size_t)b * nv + nn) * p.out2_ld + sidx;
+        dst[0] = (bf16_t)(o.x & 0xFFFF);
+        dst[(size_t)p.out2_ld] = (bf16_t)(o.x >> 16);
+        dst[(size_t)2 * p.out2_ld] = (bf16_t)(o.y & 0xFFFF);
+        dst[(size_t)3 * p.out2_ld] = (bf16_t)(o.y >> 16);
     }
 }
 

@@ -44,7 +44,7 @@ extern "C" MSD_API int msd_debug_stamps(unsigned long long* host_out, int count)
 // per step against 128-256 of MFMA).  Both forms now issue the fragment ds_reads of the current tile
 // BEFORE the address generation + DMA of the tile S-1 ahead, so that work overlaps the LDS latency.
 template <int BM, int BN, int WGM, int WGN, int S, bool DENSE>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGArgs p) {
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(CG_HOT_PARAMS, const CGArgs p) {
     constexpr int NW = WGM * WGN;               // waves per workgroup
     constexpr int NT = NW * 64;                 // threads
     constexpr int WMT = BM / WGM, WNT = BN / WGN;   // wave tile
@@ -67,17 +67,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
     // so give each XCD a CONTIGUOUS run of tiles: neighbouring tiles re-read the same pixel rows
     // (9 taps, all n-tiles) and then hit that XCD's private 4 MiB L2 instead of the Infinity Cache.
     // Pure speed: any placement computes the same result.
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);   // (= gridDim.x)
+    const int tile = xcd_remap(blockIdx.x, hot_tiles_m * hot_tiles_n);   // (= gridDim.x)
     // which operand the XCD-contiguous run shares: the pixel rows (n fastest) when the activation
     // tensor is the bigger one, the weight rows (m fastest) for the weight-heavy small-M layers —
     // otherwise every XCD's L2 pulls its own copy of up to 59 MB of weights per layer
-    const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;   // one division, by a host-prepared magic number
-    const int tq = udiv_magic(tile, tdiv, p.mg_tdiv), tr = tile - tq * tdiv;
-    const int tile_n = p.m_fast ? tq : tr;
-    const int tile_m = p.m_fast ? tr : tq;
+    const int tdiv = hot_m_fast ? hot_tiles_m : hot_tiles_n;   // one division, by a host-prepared magic number
+    const int tq = udiv_magic(tile, tdiv, hot_mg_tdiv), tr = tile - tq * tdiv;
+    const int tile_n = hot_m_fast ? tq : tr;
+    const int tile_m = hot_m_fast ? tr : tq;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kt_begin = blockIdx.y * p.nk_per;
-    const int kt_end = min(p.nk, kt_begin + p.nk_per);
+    const int kt_begin = blockIdx.y * hot_nk_per;
+    const int kt_end = min(hot_nk, kt_begin + hot_nk_per);
     const int nkt = kt_end - kt_begin;
 
     // ---- loader coordinates: thread -> (row = lrow + RPP*i, LDS chunk position = tid&7) ----------
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         asrc[i] = (cpos ^ ((row >> 1) & 7)) * 8;  // swizzle on the SOURCE chunk (LDS-DMA writes linearly)
         if constexpr (DENSE) {
             // rows past M re-read the last row: their accumulators are never stored
-            const uint32_t mc = (uint32_t)min(m, p.M - 1);
-            aoff0[i] = (mc * (uint32_t)p.c0 + (uint32_t)asrc[i]) * 2u;
+            const uint32_t mc = (uint32_t)min(m, hot_M - 1);
+            aoff0[i] = (mc * (uint32_t)hot_c0 + (uint32_t)asrc[i]) * 2u;
             aoff1[i] = (mc * (uint32_t)p.c1 + (uint32_t)asrc[i]) * 2u;
             ab[i] = ay[i] = ax[i] = 0;
             continue;
         }
-        if (m < p.M) {
+        if (m < hot_M) {
             const int b = udiv_magic(m, p.hw_out, p.mg_hw);
             const int rem = m - b * p.hw_out;
             const int y = udiv_magic(rem, p.w_out, p.mg_w);
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         const int row = lrow + RPP * i;
         const int n = n0 + row;
         // columns past N re-read the last weight row (never stored)
-        woff[i] = (uint32_t)min(n, p.N - 1) * p.w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
+        woff[i] = (uint32_t)min(n, hot_N - 1) * hot_w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
     }
     // LDS destination of this wave's pass i: 8 rows x 128 B, lane-linear
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
@@ -126,13 +126,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         if constexpr (DENSE) {
             const uint32_t sbase = lds_wave + (uint32_t)stage * ST_BYTES;
             const int c = kt * 64;
-            const bool first = c < p.c0;                       // wave-uniform: which tensor of the concat
-            const bf16_t* abase = first ? p.a0 : p.a1;
-            const uint32_t cb = (uint32_t)(first ? c : c - p.c0) * 2u;
+            const bool first = c < hot_c0;                       // wave-uniform: which tensor of the concat
+            const bf16_t* abase = first ? hot_a0 : p.a1;
+            const uint32_t cb = (uint32_t)(first ? c : c - hot_c0) * 2u;
 #pragma unroll
             for (int i = 0; i < AR; ++i) dma16s(abase, (first ? aoff0[i] : aoff1[i]) + cb, sbase + (uint32_t)(RPP * i) * 128u);
 #pragma unroll
-            for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * p.w_ks, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
+            for (int i = 0; i < BR; ++i) dma16s(hot_w, woff[i] + (uint32_t)kt * hot_w_ks, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
             return;
         }
         // general form, branch-free: coordinates clamped into the image, an out-of-image tap selects the zero page by
@@ -145,9 +145,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
         const int c = extra ? (kt - p.nk_main) * 64 : (kt - tap * p.nkc) * 64;
         const int ky = extra ? p.pad : (tap * 11) >> 5;
         const int kx = extra ? p.pad : tap - ky * 3;
-        const int cA = extra ? p.c2 : p.c0;
+        const int cA = extra ? p.c2 : hot_c0;
         const bool first = c < cA;
-        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? p.a0 : p.a1));
+        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? hot_a0 : p.a1));
         const int csrc = first ? cA : (extra ? p.K - p.nk_main * 64 - p.c2 : p.c1), coff = first ? c : c - cA;
         const uint32_t sbase = lds_wave + (uint32_t)stage * ST_BYTES;
         const uint64_t zaddr = (uint64_t)zero;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
             dma16(reinterpret_cast<const void*>(((sb + off) & m64) | (zaddr & ~m64)), sbase + (uint32_t)(RPP * i) * 128u);
         }
 #pragma unroll
-        for (int i = 0; i < BR; ++i) dma16s(p.w, woff[i] + (uint32_t)kt * p.w_ks, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
+        for (int i = 0; i < BR; ++i) dma16s(hot_w, woff[i] + (uint32_t)kt * hot_w_ks, sbase + A_BYTES + (uint32_t)(RPP * i) * 128u);
     };
 
     f32x4 acc[NJ][MI];
@@ -240,21 +240,38 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(const CGA
 // SL = the slice count as a compile-time constant for the counts the tuner uses (every slab load in flight at once, none
 // redundant: the generic form keeps 8 clamped loads in flight, i.e. issues 8 loads for 3 slices); SL = 0: any count.
 template <int SL>
-__global__ __launch_bounds__(256) void splitk_finalize_kernel(const CGArgs p, int slices, uint32_t mg_nq) {
-    const int nq = p.N >> 2;
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* hot_ws, int hot_M, int hot_N, uint32_t mg_nq, int slices, const CGArgs p) {
+    // (leading scalars: kernarg preload, conv_common.h — the slab loads below depend on nothing else)
+    const int nq = hot_N >> 2;
     const int idx = blockIdx.x * 256 + threadIdx.x;   // (M * N / 4 < 2^31: checked on the host)
-    if (idx >= p.M * nq) return;
+    if (idx >= hot_M * nq) return;
     const int m = udiv_magic(idx, nq, mg_nq);         // (was a 64-bit division by a runtime value: ~100 instructions)
     const int n = (idx - m * nq) * 4;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* src = p.ws + (size_t)m * p.N + n;
-    const size_t zs = (size_t)p.M * p.N;
+    const float* src = hot_ws + (size_t)m * hot_N + n;
+    const size_t zs = (size_t)hot_M * hot_N;
     if constexpr (SL > 0) {
+        // ONE memory round trip: the epilogue's operands (bias, time-embedding row, residual) do not depend on the slabs, so their loads go
+        // out together with the slab loads — unconditionally, from addresses that are valid whatever is present (an absent operand
+        // reads the slab and is masked after the wait: a load under a branch would make hipcc wait vmcnt(0) at the join).  Before:
+        // slabs -> wait -> bias -> wait -> row -> wait -> residual -> wait, four dependent round trips in a 5 us launch.
+        const int step = p.step_ptr ? *p.step_ptr : 0;   // (scalar load, wave-uniform)
+        const int b = udiv_magic(m, p.hw_out, p.mg_hw);
+        const bool has_b = p.bias != nullptr, has_rv = p.rowvec != nullptr;
+        const bool has_r = p.residual != nullptr && p.split_mode == 0;
+        const float* dummy = src;
+        const float4 bv = *reinterpret_cast<const float4*>(has_b ? p.bias + n : dummy);
+        const float4 rv = *reinterpret_cast<const float4*>(has_rv ? p.rowvec + (size_t)step * p.rv_step_stride + (size_t)b * p.rv_batch_stride + n : dummy);
+        const uint2 rr = *reinterpret_cast<const uint2*>(has_r ? reinterpret_cast<const char*>(p.residual + (size_t)m * p.res_ld + n)
+                                                               : reinterpret_cast<const char*>(dummy));
         float4 t[SL];
 #pragma unroll
         for (int u = 0; u < SL; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)u * zs);
 #pragma unroll
         for (int u = 0; u < SL; ++u) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }   // slice order
+        cg_store4_pre(p, m, b, n, v, has_b ? bv : make_float4(0.f, 0.f, 0.f, 0.f), has_b, has_rv ? rv : make_float4(0.f, 0.f, 0.f, 0.f), has_rv,
+                      has_r ? rr : make_uint2(0u, 0u), has_r);
+        return;
     } else {
         // 8 slab loads in flight per thread (a one-load-per-iteration loop pays a full memory round trip per slice:
         // 6 us for 12 slices of a 128 x 1280 layer); the adds keep the slice order, so the result is unchanged
@@ -275,10 +292,10 @@ static void launch_finalize(const CGArgs& a, int slices, hipStream_t stream) {
     const dim3 grid((unsigned)((quads + 255) / 256));
     const uint32_t mg = udiv_magic_of(a.N / 4);
     switch (slices) {
-#define F(SL) case SL: hipLaunchKernelGGL(splitk_finalize_kernel<SL>, grid, dim3(256), 0, stream, a, slices, mg); break;
+#define F(SL) case SL: hipLaunchKernelGGL(splitk_finalize_kernel<SL>, grid, dim3(256), 0, stream, a.ws, a.M, a.N, mg, slices, a); break;
         F(2) F(3) F(4) F(6) F(8) F(12)
 #undef F
-        default: hipLaunchKernelGGL(splitk_finalize_kernel<0>, grid, dim3(256), 0, stream, a, slices, mg); break;
+        default: hipLaunchKernelGGL(splitk_finalize_kernel<0>, grid, dim3(256), 0, stream, a.ws, a.M, a.N, mg, slices, a); break;
     }
 }
 
@@ -595,10 +612,10 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     case id:                                                                                                            \
         if (dense)                                                                                                      \
             hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st, true>), grid, dim3(wgm * wgn * 64),        \
-                               cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, a);                                       \
+                               cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, CG_HOT_ARGS(a), a);                       \
         else                                                                                                            \
             hipLaunchKernelGGL((conv_gemm_dma_kernel<bm_, bn_, wgm, wgn, st, false>), grid, dim3(wgm * wgn * 64),       \
-                               cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, a);                                       \
+                               cfg_lds(bm_, bn_, wgm * wgn * 64, st), stream, CG_HOT_ARGS(a), a);                       \
         break;
         MSD_TILE_CFGS(X)
 #undef X

@@ -46,8 +46,12 @@ __device__ __forceinline__ void halo_wait(int later, bool halo) {
 // NL = loader waves behind the WGM x WGN compute waves (0: every wave stages its share of each tile, the form above).  With
 // NL > 0 the compute waves' K step is barrier -> fragment reads -> MFMAs and nothing else; the loaders run the same DMA program
 // (counted waits, the barrier, the issues) over a row distribution of their own and leave before the epilogue.
+// Leading scalars = kernarg preload (conv_common.h CG_HOT_PARAMS): what tile mapping, halo coordinates and the first DMAs need
+#define HALO_HOT_PARAMS const bf16_t* hot_a0, const bf16_t* hot_w, int hot_w_in, int hot_h_in, int hot_tiles_m, int hot_tiles_n, int hot_m_fast, \
+                        uint32_t hot_mg_tdiv, uint32_t hot_mg_tps, uint32_t hot_mg_tx, int hot_nkc, int hot_nk_per, int hot_c0, int hot_N
+#define HALO_HOT_ARGS(a) (a).a0, (a).w, (a).w_in, (a).h_in, (a).tiles_m, (a).tiles_n, (a).m_fast, (a).mg_tdiv, (a).mg_tps, (a).mg_tx, (a).nkc, (a).nk_per, (a).c0, (a).N
 template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1, int NL = 0>
-__global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(const CGArgs p) {
+__global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HALO_HOT_PARAMS, const CGArgs p) {
     constexpr int TW = 16, BM = TH * TW;
     constexpr int NW = WGM * WGN, NT = (NL ? NL : NW) * 64;   // NT = threads that stage
     constexpr int WMT = BM / WGM, WNT = BN / WGN;
@@ -78,21 +82,21 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(con
     MSD_STAMP(0);
 
     // ---- which tile: (n tile, sample, tile row, tile column), XCD-aware order ------------------
-    const int tiles_x = p.w_in / TW, tiles_y = p.h_in / TH;
+    const int tiles_x = hot_w_in / TW, tiles_y = hot_h_in / TH;
     const int tps = tiles_x * tiles_y;
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);   // (= gridDim.x)
-    const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;   // divisions by host-prepared magic numbers
-    const int tq = udiv_magic(tile, tdiv, p.mg_tdiv), tr = tile - tq * tdiv;
-    const int tile_n = p.m_fast ? tq : tr;
-    const int tmi = p.m_fast ? tr : tq;
-    const int b = udiv_magic(tmi, tps, p.mg_tps);
+    const int tile = xcd_remap(blockIdx.x, hot_tiles_m * hot_tiles_n);   // (= gridDim.x)
+    const int tdiv = hot_m_fast ? hot_tiles_m : hot_tiles_n;   // divisions by host-prepared magic numbers
+    const int tq = udiv_magic(tile, tdiv, hot_mg_tdiv), tr = tile - tq * tdiv;
+    const int tile_n = hot_m_fast ? tq : tr;
+    const int tmi = hot_m_fast ? tr : tq;
+    const int b = udiv_magic(tmi, tps, hot_mg_tps);
     const int trem = tmi - b * tps;
-    const int tyi = udiv_magic(trem, tiles_x, p.mg_tx);
+    const int tyi = udiv_magic(trem, tiles_x, hot_mg_tx);
     const int ty0 = tyi * TH, tx0 = (trem - tyi * tiles_x) * TW;
     const int n0 = tile_n * BN;
-    const int nchunks = p.nkc;                             // 64-channel chunks of the (concatenated) input
-    const int c_begin = blockIdx.y * p.nk_per;             // split-K is over chunks here
-    const int c_end = min(nchunks, c_begin + p.nk_per);
+    const int nchunks = hot_nkc;                             // 64-channel chunks of the (concatenated) input
+    const int c_begin = blockIdx.y * hot_nk_per;             // split-K is over chunks here
+    const int c_end = min(nchunks, c_begin + hot_nk_per);
     const int nkt = (c_end - c_begin) * SPC;
 
     // ---- loader coordinates -----------------------------------------------------------------------
@@ -107,9 +111,9 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(con
         const int hrow = lrow + RPP * i;
         const int hy = hrow / HW_, hx = hrow - hy * HW_;
         const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-        const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+        const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)hot_h_in && (unsigned)ix < (unsigned)hot_w_in;
         // (coordinates clamped into the image instead of a conditional: no branch; `ok` only selects the sentinel)
-        const int pix = (b * p.h_in + min(max(iy, 0), p.h_in - 1)) * p.w_in + min(max(ix, 0), p.w_in - 1);
+        const int pix = (b * hot_h_in + min(max(iy, 0), hot_h_in - 1)) * hot_w_in + min(max(ix, 0), hot_w_in - 1);
         hpix[i] = ok ? pix : -1;
         hsrc[i] = (cpos ^ ((hrow >> 1) & 7)) * 8;
     }
@@ -117,16 +121,16 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(con
 #pragma unroll
     for (int i = 0; i < BR1; ++i) {
         const int row = lrow + RPP * i;
-        woff[i] = (uint32_t)min(n0 + row, p.N - 1) * p.w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
+        woff[i] = (uint32_t)min(n0 + row, hot_N - 1) * p.w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
     }
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;   // this wave's 8 rows inside a DMA round
     const uint64_t zaddr = (uint64_t)(reinterpret_cast<const char*>(g_zero_page) + cpos * 16);
 
     auto issue_halo = [&](int c, int buf) {
         const int ch = c * 64;
-        const bool first = ch < p.c0;                                  // wave-uniform: which tensor of the concat
-        const uint64_t sb = (uint64_t)(first ? p.a0 : p.a1);
-        const int csrc = first ? p.c0 : p.c1, coff = first ? ch : ch - p.c0;
+        const bool first = ch < hot_c0;                                  // wave-uniform: which tensor of the concat
+        const uint64_t sb = (uint64_t)(first ? hot_a0 : p.a1);
+        const int csrc = first ? hot_c0 : p.c1, coff = first ? ch : ch - hot_c0;
         const uint32_t base = __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)buf * H_BYTES);
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
@@ -144,7 +148,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(con
             // (readfirstlane: with the tap loop unrolled hipcc no longer proves this sum wave-uniform and M0 needs an SGPR)
             const uint32_t base = __builtin_amdgcn_readfirstlane(lds_wave + 2u * H_BYTES + (uint32_t)stage * W_BYTES + (uint32_t)t * W1_BYTES);
 #pragma unroll
-            for (int i = 0; i < BR1; ++i) dma16s(p.w, woff[i] + koff, base + (uint32_t)(RPP * i) * 128u);
+            for (int i = 0; i < BR1; ++i) dma16s(hot_w, woff[i] + koff, base + (uint32_t)(RPP * i) * 128u);
         }
     };
 
@@ -346,7 +350,7 @@ int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int varian
 #define X(th_, bn_, wgm, wgn, st, var, taps, nl)                                                                          \
     if (th == th_ && bn == bn_ && stages == st && variant == var) {                                                       \
         hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps, nl>), grid, dim3((wgm * wgn + nl) * 64), \
-                           (halo_lds<th_, bn_, wgm, wgn, st, taps, nl>()), stream, a);                                    \
+                           (halo_lds<th_, bn_, wgm, wgn, st, taps, nl>()), stream, HALO_HOT_ARGS(a), a);                                    \
         return MSD_OK;                                                                                                    \
     }
     MSD_HALO_CFGS(X)

@@ -24,7 +24,9 @@
 // of all of them is loaded with the A rows, before the column loop, so that no load sits between the weight DMAs.
 constexpr int RL_STEPS = 4;
 template <int KC, int MI, bool RL = false>
-__global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int wg_cols, int nsplits, uint32_t mg_nsplits) {
+__global__ __launch_bounds__(256) void dense_rowpanel_kernel(const bf16_t* hot_a0, const bf16_t* hot_w, int hot_M, int hot_N, int hot_c0, int hot_tiles_m, int hot_tiles_n,
+                                                             uint32_t hot_w_rs, uint32_t hot_w_ks, int wg_cols, int nsplits, uint32_t mg_nsplits, const CGArgs p) {
+    // (leading scalars: kernarg preload, conv_common.h CG_HOT_PARAMS)
     constexpr int S = 3, NJ = 2, MP = MI / 2;
     constexpr int BM = 4 * MI * 16;
     constexpr int W_BYTES = KC * 4096;   // one step's weight tile: KC chunks x 32 weight rows x 128 B
@@ -37,21 +39,21 @@ __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);   // (= gridDim.x; consecutive tiles = one XCD = one row panel)
+    const int tile = xcd_remap(blockIdx.x, hot_tiles_m * hot_tiles_n);   // (= gridDim.x; consecutive tiles = one XCD = one row panel)
     const int panel = udiv_magic(tile, nsplits, mg_nsplits), ns = tile - panel * nsplits;
     const int m0 = panel * BM + wave * (MI * 16);
     const int n0 = ns * wg_cols;
-    const int nsteps = (min(wg_cols, p.N - n0)) >> 5;
+    const int nsteps = (min(wg_cols, hot_N - n0)) >> 5;
 
     // ---- weight DMA: thread -> (row = tid >> 3 of the 32, 16-byte piece tid & 7), one instruction per 64-channel chunk
     const int cpos = tid & 7, lrow = tid >> 3;
     const uint32_t wsw = (uint32_t)((cpos ^ ((lrow >> 1) & 7)) * 16);
     const uint32_t lds_wave = lds0 + (uint32_t)(wave * 8) * 128u;
     auto issue_w = [&](int step, int stage) {
-        const uint32_t off = (uint32_t)min(n0 + step * 32 + lrow, p.N - 1) * p.w_rs + wsw;
+        const uint32_t off = (uint32_t)min(n0 + step * 32 + lrow, hot_N - 1) * hot_w_rs + wsw;
         const uint32_t base = __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)stage * W_BYTES);
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) dma16s(p.w, off + (uint32_t)kc * p.w_ks, base + (uint32_t)kc * 4096u);
+        for (int kc = 0; kc < KC; ++kc) dma16s(hot_w, off + (uint32_t)kc * hot_w_ks, base + (uint32_t)kc * 4096u);
     };
     if (nsteps > 0) issue_w(0, 0);
     if (nsteps > 1) issue_w(1, 1);
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const CGArgs p, int
     bf16x8 af[MI][KC * 2];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const bf16_t* src = p.a0 + (size_t)min(m0 + i * 16 + r, p.M - 1) * p.c0 + g * 8;
+        const bf16_t* src = hot_a0 + (size_t)min(m0 + i * 16 + r, hot_M - 1) * hot_c0 + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KC * 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8*>(src + ks * 32);
     }
@@ -364,11 +366,11 @@ int msd_conv_rowpanel_launch(CGArgs a, int rows, int wg_cols, hipStream_t stream
     const uint32_t mg = udiv_magic_of(nsplits);
     const bool rl = a.residual || a.ln_out;
     if (a.K == 320) {
-        if (rl) hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2, true>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
-        else hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2>), grid, dim3(256), rp_lds(5, wg_cols), stream, a, wg_cols, nsplits, mg);
+        if (rl) hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2, true>), grid, dim3(256), rp_lds(5, wg_cols), stream, a.a0, a.w, a.M, a.N, a.c0, a.tiles_m, a.tiles_n, a.w_rs, a.w_ks, wg_cols, nsplits, mg, a);
+        else hipLaunchKernelGGL((dense_rowpanel_kernel<5, 2>), grid, dim3(256), rp_lds(5, wg_cols), stream, a.a0, a.w, a.M, a.N, a.c0, a.tiles_m, a.tiles_n, a.w_rs, a.w_ks, wg_cols, nsplits, mg, a);
     } else {
-        if (rl) hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2, true>), grid, dim3(256), rp_lds(10, wg_cols), stream, a, wg_cols, nsplits, mg);
-        else hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2>), grid, dim3(256), rp_lds(10, wg_cols), stream, a, wg_cols, nsplits, mg);
+        if (rl) hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2, true>), grid, dim3(256), rp_lds(10, wg_cols), stream, a.a0, a.w, a.M, a.N, a.c0, a.tiles_m, a.tiles_n, a.w_rs, a.w_ks, wg_cols, nsplits, mg, a);
+        else hipLaunchKernelGGL((dense_rowpanel_kernel<10, 2>), grid, dim3(256), rp_lds(10, wg_cols), stream, a.a0, a.w, a.M, a.N, a.c0, a.tiles_m, a.tiles_n, a.w_rs, a.w_ks, wg_cols, nsplits, mg, a);
     }
     return MSD_OK;
 }

@@ -51,7 +51,7 @@ __device__ __forceinline__ void wr_load(wr_u32x4& lo, wr_u32x4& hi, const void* 
 // 256-row tiles on 8 waves: 48 KB of operands per K tile where two 128x128 workgroups move 64 KB; the two waves of a column
 // pair load the same fragments, the second from the CU's L1).
 template <int BM, int NJ, int NW, int S, bool DENSE, int KT = 1, int WGM = 1>
-__global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
+__global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(CG_HOT_PARAMS, const CGArgs p) {
     constexpr int NT = NW * 64;
     constexpr int WGN = NW / WGM;
     constexpr int BN = WGN * NJ * 16;
@@ -73,14 +73,14 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
     const int r = lane & 15, g = lane >> 4;
     MSD_STAMP(0);
     // tile order as in conv_gemm.hip: XCD-contiguous runs that share the pixel rows (n fastest) or the weight panel (m fastest)
-    const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tdiv = p.m_fast ? p.tiles_m : p.tiles_n;
-    const int tq = udiv_magic(tile, tdiv, p.mg_tdiv), tr = tile - tq * tdiv;
-    const int tile_n = p.m_fast ? tq : tr;
-    const int tile_m = p.m_fast ? tr : tq;
+    const int tile = xcd_remap(blockIdx.x, hot_tiles_m * hot_tiles_n);
+    const int tdiv = hot_m_fast ? hot_tiles_m : hot_tiles_n;
+    const int tq = udiv_magic(tile, tdiv, hot_mg_tdiv), tr = tile - tq * tdiv;
+    const int tile_n = hot_m_fast ? tq : tr;
+    const int tile_m = hot_m_fast ? tr : tq;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int kt_begin = blockIdx.y * p.nk_per;
-    const int kt_end = min(p.nk, kt_begin + p.nk_per);
+    const int kt_begin = blockIdx.y * hot_nk_per;
+    const int kt_end = min(hot_nk, kt_begin + hot_nk_per);
     const int nkt = (kt_end - kt_begin + KT - 1) / KT;   // ring stages (= steps) of this slice; the last one may hold fewer than KT tiles
 
     // ---- A loader coordinates (conv_gemm.hip's): thread -> (row = lrow + RPP i, 16-byte chunk position tid & 7) ----------
@@ -96,13 +96,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
         const int m = m0 + row;
         asrc[i] = (cpos ^ ((row >> 1) & 7)) * 8;   // swizzle on the SOURCE chunk (LDS-DMA writes linearly)
         if constexpr (DENSE) {
-            const uint32_t mc = (uint32_t)min(m, p.M - 1);   // rows past M re-read the last row: never stored
-            aoff0[i] = (mc * (uint32_t)p.c0 + (uint32_t)asrc[i]) * 2u;
+            const uint32_t mc = (uint32_t)min(m, hot_M - 1);   // rows past M re-read the last row: never stored
+            aoff0[i] = (mc * (uint32_t)hot_c0 + (uint32_t)asrc[i]) * 2u;
             aoff1[i] = (mc * (uint32_t)p.c1 + (uint32_t)asrc[i]) * 2u;
             ab[i] = ay[i] = ax[i] = 0;
             continue;
         }
-        if (m < p.M) {
+        if (m < hot_M) {
             const int b = udiv_magic(m, p.hw_out, p.mg_hw);
             const int rem = m - b * p.hw_out;
             const int y = udiv_magic(rem, p.w_out, p.mg_w);
@@ -119,9 +119,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
         const uint32_t sbase = lds_wave + (uint32_t)slot * A_BYTES;
         if constexpr (DENSE) {
             const int c = kt * 64;
-            const bool first = c < p.c0;                       // wave-uniform: which tensor of the concat
-            const bf16_t* abase = first ? p.a0 : p.a1;
-            const uint32_t cb = (uint32_t)(first ? c : c - p.c0) * 2u;
+            const bool first = c < hot_c0;                       // wave-uniform: which tensor of the concat
+            const bf16_t* abase = first ? hot_a0 : p.a1;
+            const uint32_t cb = (uint32_t)(first ? c : c - hot_c0) * 2u;
 #pragma unroll
             for (int i = 0; i < AR; ++i) dma16s(abase, (first ? aoff0[i] : aoff1[i]) + cb, sbase + (uint32_t)(RPP * i) * 128u);
             return;
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
         const int c = extra ? (kt - p.nk_main) * 64 : (kt - tap * p.nkc) * 64;
         const int ky = extra ? p.pad : (tap * 11) >> 5;
         const int kx = extra ? p.pad : tap - ky * 3;
-        const int cA = extra ? p.c2 : p.c0;
+        const int cA = extra ? p.c2 : hot_c0;
         const bool first = c < cA;
-        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? p.a0 : p.a1));
+        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? hot_a0 : p.a1));
         const int csrc = first ? cA : (extra ? p.K - p.nk_main * 64 - p.c2 : p.c1), coff = first ? c : c - cA;
         const uint64_t zaddr = (uint64_t)zero;
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
 
     // ---- B: this wave's NJ column blocks of K tile kt = 2 NJ contiguous KiB of the fragment-major image ------------------
     // image: [K / 64][N / 16][2][64 lanes][16 B]; blocks past N re-read the last block (their columns are never stored)
-    const int NB = p.N >> 4;
+    const int NB = hot_N >> 4;
     const int nb0 = (n0 >> 4) + wn * NJ;
     uint32_t boff[NJ];
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(const CGArgs p) {
     const size_t kt_bytes = (size_t)NB * 2048u;
     wr_u32x4 bw[PB][KT][NJ][2];
     auto issue_b = [&](int kt, wr_u32x4 (&dst)[NJ][2]) {
-        const char* base = reinterpret_cast<const char*>(p.w) + (size_t)kt * kt_bytes;
+        const char* base = reinterpret_cast<const char*>(hot_w) + (size_t)kt * kt_bytes;
         wr_load_first(dst[0][0], dst[0][1], base, boff[0]);
 #pragma unroll
         for (int j = 1; j < NJ; ++j) wr_load(dst[j][0], dst[j][1], base, boff[j]);
@@ -328,9 +328,9 @@ int msd_conv_wreg_launch(const CGArgs& a, int bm, int bn, int stages, int slices
 #define X(bm_, nj, nw, st, kt, wgm)                                                                                    \
     if (bm == bm_ && bn == (nw / wgm) * nj * 16 && stages == wreg_code(nw, st, kt)) {                                  \
         if (dense)                                                                                                     \
-            hipLaunchKernelGGL((conv_wreg_kernel<bm_, nj, nw, st, true, kt, wgm>), grid, dim3(nw * 64), wreg_lds(bm_, nj, nw, st, kt, wgm), stream, a); \
+            hipLaunchKernelGGL((conv_wreg_kernel<bm_, nj, nw, st, true, kt, wgm>), grid, dim3(nw * 64), wreg_lds(bm_, nj, nw, st, kt, wgm), stream, CG_HOT_ARGS(a), a); \
         else                                                                                                           \
-            hipLaunchKernelGGL((conv_wreg_kernel<bm_, nj, nw, st, false, kt, wgm>), grid, dim3(nw * 64), wreg_lds(bm_, nj, nw, st, kt, wgm), stream, a); \
+            hipLaunchKernelGGL((conv_wreg_kernel<bm_, nj, nw, st, false, kt, wgm>), grid, dim3(nw * 64), wreg_lds(bm_, nj, nw, st, kt, wgm), stream, CG_HOT_ARGS(a), a); \
         return MSD_OK;                                                                                                 \
     }
     MSD_WREG_CFGS(X)

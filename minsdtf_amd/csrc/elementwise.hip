@@ -20,26 +20,28 @@ struct CfgArgs {
 // thread; larger latents take the re-reading loop) and the four moments go through one block reduction with the
 // same summation order as four separate ones (wave butterfly, then the 16 wave sums in wave order).
 template <int NPT>
-__global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
+__global__ __launch_bounds__(1024) void cfg_step_kernel(const float* hot_eps, float* hot_latent, const float* hot_coef, int32_t* hot_step_ptr, int hot_batch, int hot_n,
+                                                       int hot_num_steps, float hot_guidance, const CfgArgs p) {
+    // (leading scalars: kernarg preload — the step index -> coefficient loads and the data loads start without the kernarg round trip)
     __shared__ double red[16][4];
     const int b = blockIdx.x, t = threadIdx.x;
-    const int step_raw = p.step_ptr ? *p.step_ptr : 0;
+    const int step_raw = hot_step_ptr ? *hot_step_ptr : 0;
     int step = step_raw;
-    if (step > p.num_steps - 1) step = p.num_steps - 1;
+    if (step > hot_num_steps - 1) step = hot_num_steps - 1;
     if (step < 0) step = 0;
-    const float sr = p.coef[step * 4 + 0], nr = p.coef[step * 4 + 1];
-    const float ca = p.coef[step * 4 + 2], cb = p.coef[step * 4 + 3];   // x' = ca * x0 + cb * eps (+ cz * z)
+    const float sr = hot_coef[step * 4 + 0], nr = hot_coef[step * 4 + 1];
+    const float ca = hot_coef[step * 4 + 2], cb = hot_coef[step * 4 + 3];   // x' = ca * x0 + cb * eps (+ cz * z)
     const float cz = p.step_noise ? p.noise_coef[step] : 0.0f;
-    const float* z = p.step_noise ? p.step_noise + ((size_t)step * p.batch + b) * p.n : nullptr;
-    float* lat = p.latent + (size_t)b * p.n;
-    const bool cfg = p.guidance > 0.0f;
-    const float* u = p.eps + (size_t)b * p.n;
-    const float* c = cfg ? p.eps + (size_t)(p.batch + b) * p.n : u;
+    const float* z = p.step_noise ? p.step_noise + ((size_t)step * hot_batch + b) * hot_n : nullptr;
+    float* lat = hot_latent + (size_t)b * hot_n;
+    const bool cfg = hot_guidance > 0.0f;
+    const float* u = hot_eps + (size_t)b * hot_n;
+    const float* c = cfg ? hot_eps + (size_t)(hot_batch + b) * hot_n : u;
     float ru[NPT > 0 ? NPT : 1], rc[NPT > 0 ? NPT : 1], rl[NPT > 0 ? NPT : 1];
     if (NPT > 0) {   // everything this thread touches, issued up front
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
-            const int i = min(t + k * 1024, p.n - 1);
+            const int i = min(t + k * 1024, hot_n - 1);
             ru[k] = u[i]; rc[k] = c[i]; rl[k] = lat[i];
         }
     }
@@ -50,19 +52,19 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
         // in fp64.  The variance is shift-invariant, and about a shift inside the data's range the fp32 sums lose nothing
         // that matters: (q - s^2/n)/n has no large-number cancellation.  (Was: fp64 per element and six 64-bit
         // ds_bpermute steps per moment: 48 LDS round trips on the step's critical path.)
-        const float c0 = c[0], g0 = u[0] + p.guidance * (c[0] - u[0]);
+        const float c0 = c[0], g0 = u[0] + hot_guidance * (c[0] - u[0]);
         float f4[4] = {0.f, 0.f, 0.f, 0.f};   // s_c, q_c, s_g, q_g (shifted)
         auto acc = [&](float cu, float cc) {
-            const float gq = cu + p.guidance * (cc - cu);
+            const float gq = cu + hot_guidance * (cc - cu);
             const float dc = cc - c0, dg = gq - g0;
             f4[0] += dc; f4[1] += dc * dc; f4[2] += dg; f4[3] += dg * dg;
         };
         if (NPT > 0) {
 #pragma unroll
             for (int k = 0; k < NPT; ++k)
-                if (t + k * 1024 < p.n) acc(ru[k], rc[k]);
+                if (t + k * 1024 < hot_n) acc(ru[k], rc[k]);
         } else {
-            for (int i = t; i < p.n; i += 1024) acc(u[i], c[i]);
+            for (int i = t; i < hot_n; i += 1024) acc(u[i], c[i]);
         }
         double m4[4];
 #pragma unroll
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
             for (int w = 0; w < 16; ++w) s += red[w][q];
             m4[q] = s;
         }
-        const double n = (double)p.n;
+        const double n = (double)hot_n;
         const double mc = m4[0] / n, mg = m4[2] / n;   // (means of the shifted values: the shift drops out of the variance)
         const double vc = fmax(m4[1] / n - mc * mc, 0.0), vg = fmax(m4[3] / n - mg * mg, 0.0);
         const float std_text = (float)sqrt(vc);
@@ -86,13 +88,13 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
         factor = p.rescale * (std_text / std_cfg) + (1.0f - p.rescale);
     }
     auto update = [&](int i, float cu, float cc, float l) {
-        const float e = cfg ? (cu + p.guidance * (cc - cu)) * factor : cu;
+        const float e = cfg ? (cu + hot_guidance * (cc - cu)) * factor : cu;
         const float x0 = (l - nr * e) / sr;
         float x = ca * x0 + cb * e;
         if (z) x += cz * z[i];
         if (p.ip_mask) {   // inpainting: keep the (re-noised) original outside the mask
             const float m = p.ip_mask[i];
-            const float org = sr * p.ip_init[i] + nr * p.ip_noise[(size_t)b * p.n + i];
+            const float org = sr * p.ip_init[i] + nr * p.ip_noise[(size_t)b * hot_n + i];
             x = org * (1.0f - m) + x * m;
         }
         lat[i] = x;
@@ -100,17 +102,17 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const CfgArgs p) {
     if (NPT > 0) {
 #pragma unroll
         for (int k = 0; k < NPT; ++k)
-            if (t + k * 1024 < p.n) update(t + k * 1024, ru[k], rc[k], rl[k]);
+            if (t + k * 1024 < hot_n) update(t + k * 1024, ru[k], rc[k], rl[k]);
     } else {
-        for (int i = t; i < p.n; i += 1024) update(i, u[i], c[i], lat[i]);
+        for (int i = t; i < hot_n; i += 1024) update(i, u[i], c[i], lat[i]);
     }
     if (p.advance_in_kernel && t == 0) {
         // every workgroup read *step_ptr at its start and takes its ticket here, at its end: the one that draws the last
         // ticket knows that all of them have read the step, so it may move it (and clears the tickets for the next launch)
-        const int ticket = __hip_atomic_fetch_add(p.step_ptr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == p.batch - 1) {
-            __hip_atomic_store(p.step_ptr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.step_ptr, step_raw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ticket = __hip_atomic_fetch_add(hot_step_ptr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == hot_batch - 1) {
+            __hip_atomic_store(hot_step_ptr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(hot_step_ptr, step_raw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -131,9 +133,9 @@ extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
     if (a.ip_mask && (!a.ip_init || !a.ip_noise)) MSD_FAIL(MSD_E_ARG, "cfg_step: inpaint_mask needs inpaint_init and inpaint_noise");
     a.step_noise = q->step_noise; a.noise_coef = q->noise_coef;
     if (a.step_noise && !a.noise_coef) MSD_FAIL(MSD_E_ARG, "cfg_step: step_noise needs noise_coef");
-    if (q->n <= 16 * 1024) hipLaunchKernelGGL(cfg_step_kernel<16>, dim3(q->batch), dim3(1024), 0, stream, a);        // <= 64x64 latents
-    else if (q->n <= 36 * 1024) hipLaunchKernelGGL(cfg_step_kernel<36>, dim3(q->batch), dim3(1024), 0, stream, a);   // 96x96
-    else hipLaunchKernelGGL(cfg_step_kernel<0>, dim3(q->batch), dim3(1024), 0, stream, a);
+    if (q->n <= 16 * 1024) hipLaunchKernelGGL(cfg_step_kernel<16>, dim3(q->batch), dim3(1024), 0, stream, a.eps, a.latent, a.coef, a.step_ptr, a.batch, a.n, a.num_steps, a.guidance, a);        // <= 64x64 latents
+    else if (q->n <= 36 * 1024) hipLaunchKernelGGL(cfg_step_kernel<36>, dim3(q->batch), dim3(1024), 0, stream, a.eps, a.latent, a.coef, a.step_ptr, a.batch, a.n, a.num_steps, a.guidance, a);   // 96x96
+    else hipLaunchKernelGGL(cfg_step_kernel<0>, dim3(q->batch), dim3(1024), 0, stream, a.eps, a.latent, a.coef, a.step_ptr, a.batch, a.n, a.num_steps, a.guidance, a);
     MSD_CHECK_LAUNCH();
     if (q->advance == 1) {
         hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, stream, q->step_ptr);

@@ -18,6 +18,10 @@ struct GNArgs {
     int nchunks_stats;         // grid x of the statistics pass (kept here: reading gridDim costs a second kernarg round trip)
 };
 
+// Kernarg preload (see conv_common.h CG_HOT_PARAMS): what the single-launch kernels need before their first load, as leading scalars
+#define GN_HOT_PARAMS const bf16_t* hot_x0, const bf16_t* hot_x1, int hot_C, int hot_hw, int hot_c0, int hot_c1, int upp, int ppp, uint32_t mg_upp
+#define GN_HOT_ARGS(a) (a).x0, (a).x1, (a).C, (a).hw, (a).c0, (a).c1, upp, ppp, mg
+
 // NT threads per workgroup: 256, or 1024 for the mid-sized tensors (the UNet's 64x64 level) where a
 // workgroup's whole 64-pixel chunk is then in flight at once — those launches are bounded by memory
 // latency x bytes in flight, not by bandwidth.
@@ -267,28 +271,28 @@ template <> struct gn_vec<2> { typedef uint2 type; };
 template <> struct gn_vec<4> { typedef uint4 type; };
 
 template <int NPT, int V>
-__global__ __launch_bounds__(1024) void gn_group_kernel(const GNArgs p, int upp, int ppp, uint32_t mg_upp) {
+__global__ __launch_bounds__(1024) void gn_group_kernel(GN_HOT_PARAMS, const GNArgs p) {
     typedef typename gn_vec<V>::type vec_t;
     __shared__ float red[16][2];
     __shared__ float s_stat[2];
     const int t = threadIdx.x;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = slot >> 2, g = xcd * 4 + (slot & 3);
-    const int cpg = p.C / 32;
+    const int cpg = hot_C / 32;
     // (ppp = 1024 / upp: pixels per pass of the workgroup)
     const int pl = udiv_magic(t, upp, mg_upp), u = t - pl * upp;   // my pixel lane, my unit inside the group's run
     const bool active = pl < ppp;
     const int c = g * cpg + u * 2 * V;          // first of my 2V channels
-    const size_t row0 = (size_t)b * p.hw;
-    const bool first = c < p.c0;
-    const int sstride = first ? p.c0 : p.c1;
-    const bf16_t* src = first ? p.x0 + row0 * p.c0 + c : p.x1 + row0 * p.c1 + (c - p.c0);
+    const size_t row0 = (size_t)b * hot_hw;
+    const bool first = c < hot_c0;
+    const int sstride = first ? hot_c0 : hot_c1;
+    const bf16_t* src = first ? hot_x0 + row0 * hot_c0 + c : hot_x1 + row0 * hot_c1 + (c - hot_c0);
 
     union { vec_t v; uint32_t w[V]; } x[NPT];
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int px = pl + k * ppp;
-        if (active && px < p.hw) x[k].v = *reinterpret_cast<const vec_t*>(src + (size_t)px * sstride);
+        if (active && px < hot_hw) x[k].v = *reinterpret_cast<const vec_t*>(src + (size_t)px * sstride);
         else {
 #pragma unroll
             for (int e = 0; e < V; ++e) x[k].w[e] = 0u;
@@ -366,7 +370,7 @@ constexpr int GN_SYNC_WORDS_PER_SLOT = 64;   // [0] ticket, [8] error, [16..31] 
 constexpr int GN_POLL_LIMIT = 1 << 18;   // default bound of the exchange poll (set_option "gn_poll_limit": tests shorten it)
 
 template <int NPT, int V>
-__global__ __launch_bounds__(1024) void gn_cluster_kernel(const GNArgs p, int upp, int ppp, uint32_t mg_upp, int pshift, int ppart,
+__global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int pshift, int ppart, const GNArgs p,
                                                           uint32_t* sync_region, int poll_limit) {
     typedef typename gn_vec<V>::type vec_t;
     __shared__ float red[16][2];
@@ -375,15 +379,15 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(const GNArgs p, int up
     const int P = 1 << pshift;
     const int part = blockIdx.x & (P - 1), slot = blockIdx.x >> pshift;   // slot = b * 32 + g
     const int b = slot >> 5, g = slot & 31;
-    const int cpg = p.C / 32;
+    const int cpg = hot_C / 32;
     const int pl = udiv_magic(t, upp, mg_upp), u = t - pl * upp;   // my pixel lane, my unit inside the group's run
     const bool active = pl < ppp;
-    const int px0 = part * ppart, px1 = min(p.hw, px0 + ppart);
+    const int px0 = part * ppart, px1 = min(hot_hw, px0 + ppart);
     const int c = g * cpg + u * 2 * V;          // first of my 2V channels
-    const size_t row0 = (size_t)b * p.hw;
-    const bool first = c < p.c0;
-    const int sstride = first ? p.c0 : p.c1;
-    const bf16_t* src = first ? p.x0 + row0 * p.c0 + c : p.x1 + row0 * p.c1 + (c - p.c0);
+    const size_t row0 = (size_t)b * hot_hw;
+    const bool first = c < hot_c0;
+    const int sstride = first ? hot_c0 : hot_c1;
+    const bf16_t* src = first ? hot_x0 + row0 * hot_c0 + c : hot_x1 + row0 * hot_c1 + (c - hot_c0);
 
     union { vec_t v; uint32_t w[V]; } x[NPT];
 #pragma unroll
@@ -491,10 +495,10 @@ static void gn_cluster_launch(const GNArgs& a, int upp, int npt, dim3 grid, int 
     const dim3 block(1024);
     const int ppp = 1024 / upp;
     const uint32_t mg = udiv_magic_of(upp);
-    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region, g_gn_poll_limit);
-    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region, g_gn_poll_limit);
-    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region, g_gn_poll_limit);
-    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, a, upp, ppp, mg, pshift, ppart, region, g_gn_poll_limit);
+    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
+    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
+    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
 }
 
 template <int V>
@@ -502,10 +506,10 @@ static void gn_group_launch(const GNArgs& a, int upp, int npt, dim3 grid, hipStr
     const dim3 block(1024);
     const int ppp = 1024 / upp;
     const uint32_t mg = udiv_magic_of(upp);
-    if (npt <= 2) hipLaunchKernelGGL((gn_group_kernel<2, V>), grid, block, 0, stream, a, upp, ppp, mg);
-    else if (npt <= 4) hipLaunchKernelGGL((gn_group_kernel<4, V>), grid, block, 0, stream, a, upp, ppp, mg);
-    else if (npt <= 8) hipLaunchKernelGGL((gn_group_kernel<8, V>), grid, block, 0, stream, a, upp, ppp, mg);
-    else if constexpr (V < 4) hipLaunchKernelGGL((gn_group_kernel<16, V>), grid, block, 0, stream, a, upp, ppp, mg);
+    if (npt <= 2) hipLaunchKernelGGL((gn_group_kernel<2, V>), grid, block, 0, stream, GN_HOT_ARGS(a), a);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_group_kernel<4, V>), grid, block, 0, stream, GN_HOT_ARGS(a), a);
+    else if (npt <= 8) hipLaunchKernelGGL((gn_group_kernel<8, V>), grid, block, 0, stream, GN_HOT_ARGS(a), a);
+    else if constexpr (V < 4) hipLaunchKernelGGL((gn_group_kernel<16, V>), grid, block, 0, stream, GN_HOT_ARGS(a), a);
 }
 
 static int g_gn_impl = 1;  // 1 = single-launch per-group kernel where the group slab fits, 0 = always stats/finalize/apply

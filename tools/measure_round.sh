@@ -6,7 +6,7 @@
 #   gpurun --timeout 1150 -- "bash tools/measure_round.sh r3 $(git rev-parse --short HEAD) [headline|b4|768|controlnet|all]"
 # Outputs under gpurun_out/final/; copy what should be judged into profiles/.
 set -o pipefail
-TAG=${1:-r3}
+TAG=${1:-r4}
 COMMIT=${2:-unknown}
 WHAT=${3:-all}
 OUT=gpurun_out/final
