@@ -92,7 +92,7 @@ def main():
 
         clk["stop"] = True
         th.join(timeout=1)
-        mhz = sorted(clk["mhz"])
+        mhz = sorted(x for x in clk["mhz"] if x > 1000.0)   # (a GPU of the box that idles — or this one between launches — reads its sleep level)
         with open(args.calls_json, "w") as f:
             json.dump({"conv_calls": conv_log, "first_step_call": n_before,
                        "sclk_mhz_samples": len(mhz), "sclk_mhz_median": mhz[len(mhz) // 2] if mhz else None,
