@@ -1150,10 +1150,10 @@ struct XArgs {
 // NW waves = 16 NW queries per workgroup (4 or 8: the weight / K / V^T images are shared by twice the queries; the host picks 8
 // when the 64-query grid would need more than one round of workgroups).
 template <int D, int NW>
-// (leading scalars: kernarg preload — x, wq, k (6 dwords) + batch, heads, s, t, k_ld, ln_slots, w_rs, w_ks, mg_heads, mg_qtiles)
-#define XATTN_HOT_PARAMS const bf16_t* hot_x, const bf16_t* hot_wq, const bf16_t* hot_k, int hot_batch, int hot_heads, int hot_s, int hot_t, int hot_k_ld, \
-                         int hot_ln_slots, uint32_t hot_w_rs, uint32_t hot_w_ks, uint32_t hot_mg_heads, uint32_t hot_mg_qtiles
-#define XATTN_HOT_ARGS(a) (a).x, (a).wq, (a).k, (a).batch, (a).heads, (a).s, (a).t, (a).k_ld, (a).ln_slots, (a).w_rs, (a).w_ks, (a).mg_heads, (a).mg_qtiles
+// (leading scalars: kernarg preload, 14 dwords — x, wq, k + batch, heads, s, mg_heads, mg_qtiles, w_rs, w_ks, t; k_ld / ln_slots follow unpreloaded)
+#define XATTN_HOT_PARAMS const bf16_t* hot_x, const bf16_t* hot_wq, const bf16_t* hot_k, int hot_batch, int hot_heads, int hot_s, uint32_t hot_mg_heads, \
+                         uint32_t hot_mg_qtiles, uint32_t hot_w_rs, uint32_t hot_w_ks, int hot_t, int hot_k_ld, int hot_ln_slots
+#define XATTN_HOT_ARGS(a) (a).x, (a).wq, (a).k, (a).batch, (a).heads, (a).s, (a).mg_heads, (a).mg_qtiles, (a).w_rs, (a).w_ks, (a).t, (a).k_ld, (a).ln_slots
 __global__ __launch_bounds__(64 * NW) void xattn_q_kernel(XATTN_HOT_PARAMS, const XArgs p) {
     constexpr int NT = 64 * NW, QT = 16 * NW;
     constexpr int C = 8 * D;                  // (8 heads: SD1.5)

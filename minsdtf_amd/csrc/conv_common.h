@@ -27,9 +27,23 @@ struct CGArgs {
 // argument block; built with -mllvm -amdgpu-kernarg-preload-count=16 these arrive in SGPRs with the wave, so tile mapping and loader
 // coordinates start without waiting for the first scalar-memory round trip (a struct argument is never preloaded).  CG_HOT_ARGS(a) is
 // the launch side, CG_HOT_PARAMS the kernel side (the prologue reads hot_* where it would read p.*; the same values).
-#define CG_HOT_PARAMS const bf16_t* hot_a0, const bf16_t* hot_w, int hot_M, int hot_N, int hot_c0, int hot_tiles_m, int hot_tiles_n, \
-                      int hot_m_fast, int hot_nk_per, int hot_nk, uint32_t hot_mg_tdiv, uint32_t hot_w_rs, uint32_t hot_w_ks
-#define CG_HOT_ARGS(a) (a).a0, (a).w, (a).M, (a).N, (a).c0, (a).tiles_m, (a).tiles_n, (a).m_fast, (a).nk_per, (a).nk, (a).mg_tdiv, (a).w_rs, (a).w_ks
+#define CG_HOT_PARAMS const bf16_t* hot_a0, const bf16_t* hot_w, const bf16_t* hot_a1, int hot_M, int hot_N, uint32_t hot_pk_c, uint32_t hot_pk_tiles, \
+                      uint32_t hot_pk_nk, uint32_t hot_mg_tdiv, uint32_t hot_w_rs, uint32_t hot_w_ks
+// 14 dwords = all the preload the hardware offers (16 user SGPRs less the kernarg pointer), so three pairs travel packed; cg_hot_ok()
+// is the host-side range check.  CG_HOT_UNPACK declares the fields the prologues read.
+#define CG_HOT_ARGS(a) (a).a0, (a).w, (a).a1, (a).M, (a).N, ((uint32_t)(a).c0 | ((uint32_t)(a).c1 << 16)),                           \
+                       ((uint32_t)(a).tiles_m | ((uint32_t)(a).tiles_n << 23) | ((uint32_t)((a).m_fast ? 1u : 0u) << 31)),          \
+                       ((uint32_t)(a).nk_per | ((uint32_t)(a).nk << 16)), (a).mg_tdiv, (a).w_rs, (a).w_ks
+#define CG_HOT_UNPACK                                                                                                          \
+    const int hot_c0 = (int)(hot_pk_c & 0xFFFFu), hot_c1 = (int)(hot_pk_c >> 16);                                             \
+    const int hot_tiles_m = (int)(hot_pk_tiles & 0x7FFFFFu), hot_tiles_n = (int)((hot_pk_tiles >> 23) & 0xFFu);                \
+    const int hot_m_fast = (int)(hot_pk_tiles >> 31);                                                                          \
+    const int hot_nk_per = (int)(hot_pk_nk & 0xFFFFu), hot_nk = (int)(hot_pk_nk >> 16);                                        \
+    (void)hot_c1; (void)hot_a1; (void)hot_w_rs; (void)hot_w_ks
+static inline bool cg_hot_ok(const CGArgs& a) {
+    return a.c0 >= 0 && a.c0 < 65536 && a.c1 >= 0 && a.c1 < 65536 && a.tiles_m > 0 && a.tiles_m < (1 << 23) && a.tiles_n > 0 && a.tiles_n < 256 &&
+           a.nk_per > 0 && a.nk_per < 65536 && a.nk > 0 && a.nk < 65536;
+}
 
 static __device__ __attribute__((aligned(128))) uint32_t g_zero_page[32];  // source of padding rows (one copy per TU)
 

@@ -45,6 +45,7 @@ extern "C" MSD_API int msd_debug_stamps(unsigned long long* host_out, int count)
 // BEFORE the address generation + DMA of the tile S-1 ahead, so that work overlaps the LDS latency.
 template <int BM, int BN, int WGM, int WGN, int S, bool DENSE>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(CG_HOT_PARAMS, const CGArgs p) {
+    CG_HOT_UNPACK;
     constexpr int NW = WGM * WGN;               // waves per workgroup
     constexpr int NT = NW * 64;                 // threads
     constexpr int WMT = BM / WGM, WNT = BN / WGN;   // wave tile
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(CG_HOT_PA
             // rows past M re-read the last row: their accumulators are never stored
             const uint32_t mc = (uint32_t)min(m, hot_M - 1);
             aoff0[i] = (mc * (uint32_t)hot_c0 + (uint32_t)asrc[i]) * 2u;
-            aoff1[i] = (mc * (uint32_t)p.c1 + (uint32_t)asrc[i]) * 2u;
+            aoff1[i] = (mc * (uint32_t)hot_c1 + (uint32_t)asrc[i]) * 2u;
             ab[i] = ay[i] = ax[i] = 0;
             continue;
         }
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(CG_HOT_PA
             const uint32_t sbase = lds_wave + (uint32_t)stage * ST_BYTES;
             const int c = kt * 64;
             const bool first = c < hot_c0;                       // wave-uniform: which tensor of the concat
-            const bf16_t* abase = first ? hot_a0 : p.a1;
+            const bf16_t* abase = first ? hot_a0 : hot_a1;
             const uint32_t cb = (uint32_t)(first ? c : c - hot_c0) * 2u;
 #pragma unroll
             for (int i = 0; i < AR; ++i) dma16s(abase, (first ? aoff0[i] : aoff1[i]) + cb, sbase + (uint32_t)(RPP * i) * 128u);
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_dma_kernel(CG_HOT_PA
         const int kx = extra ? p.pad : tap - ky * 3;
         const int cA = extra ? p.c2 : hot_c0;
         const bool first = c < cA;
-        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? hot_a0 : p.a1));
-        const int csrc = first ? cA : (extra ? p.K - p.nk_main * 64 - p.c2 : p.c1), coff = first ? c : c - cA;
+        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? hot_a0 : hot_a1));
+        const int csrc = first ? cA : (extra ? p.K - p.nk_main * 64 - p.c2 : hot_c1), coff = first ? c : c - cA;
         const uint32_t sbase = lds_wave + (uint32_t)stage * ST_BYTES;
         const uint64_t zaddr = (uint64_t)zero;
 #pragma unroll
@@ -573,6 +574,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         const bool dense = !q->rowvec && !q->a2 && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in;
         if (needs_dense && !dense)
             MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold, GEGLU and the q|k|v^T split run on the 1x1 / Dense form only");
+        if (!cg_hot_ok(a)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: tile / K-tile / channel counts beyond the packed launch arguments (K tiles, channels < 65536; row tiles < 2^23; column tiles < 256)");
         rc = msd_conv_wreg_launch(a, wbm, wbn, q->stages, slices, dense, stream);
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
@@ -598,6 +600,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     a.mg_tdiv = udiv_magic_of(a.m_fast ? a.tiles_m : a.tiles_n);
     a.mg_tps = a.mg_tx = 0;
     dim3 grid(tiles_m * a.tiles_n, slices);
+    if (!cg_hot_ok(a)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: tile / K-tile / channel counts beyond the packed launch arguments (K tiles, channels < 65536; row tiles < 2^23; column tiles < 256)");
     // 1x1 / Dense form: 32-bit byte offsets from the tensor bases
     // (the DENSE kernel carries the LayerNorm-fold consumer and no time-embedding row, the general kernel the reverse)
     const bool needs_dense = q->ln_in || q->act == MSD_ACT_GEGLU || q->split_mode;

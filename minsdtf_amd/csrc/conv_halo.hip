@@ -47,11 +47,14 @@ __device__ __forceinline__ void halo_wait(int later, bool halo) {
 // NL > 0 the compute waves' K step is barrier -> fragment reads -> MFMAs and nothing else; the loaders run the same DMA program
 // (counted waits, the barrier, the issues) over a row distribution of their own and leave before the epilogue.
 // Leading scalars = kernarg preload (conv_common.h CG_HOT_PARAMS): what tile mapping, halo coordinates and the first DMAs need
-#define HALO_HOT_PARAMS const bf16_t* hot_a0, const bf16_t* hot_w, int hot_w_in, int hot_h_in, int hot_tiles_m, int hot_tiles_n, int hot_m_fast, \
-                        uint32_t hot_mg_tdiv, uint32_t hot_mg_tps, uint32_t hot_mg_tx, int hot_nkc, int hot_nk_per, int hot_c0, int hot_N
-#define HALO_HOT_ARGS(a) (a).a0, (a).w, (a).w_in, (a).h_in, (a).tiles_m, (a).tiles_n, (a).m_fast, (a).mg_tdiv, (a).mg_tps, (a).mg_tx, (a).nkc, (a).nk_per, (a).c0, (a).N
+// (14 dwords: tiles_m | tiles_n << 23 | m_fast << 31 travel packed, range-checked by cg_hot_ok on the host)
+#define HALO_HOT_PARAMS const bf16_t* hot_a0, const bf16_t* hot_w, int hot_w_in, int hot_h_in, uint32_t hot_pk_tiles, uint32_t hot_mg_tdiv, uint32_t hot_mg_tps, \
+                        uint32_t hot_mg_tx, int hot_nkc, int hot_nk_per, int hot_c0, int hot_N
+#define HALO_HOT_ARGS(a) (a).a0, (a).w, (a).w_in, (a).h_in, ((uint32_t)(a).tiles_m | ((uint32_t)(a).tiles_n << 23) | ((uint32_t)((a).m_fast ? 1u : 0u) << 31)), \
+                         (a).mg_tdiv, (a).mg_tps, (a).mg_tx, (a).nkc, (a).nk_per, (a).c0, (a).N
 template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1, int NL = 0>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HALO_HOT_PARAMS, const CGArgs p) {
+    const int hot_tiles_m = (int)(hot_pk_tiles & 0x7FFFFFu), hot_tiles_n = (int)((hot_pk_tiles >> 23) & 0xFFu), hot_m_fast = (int)(hot_pk_tiles >> 31);
     constexpr int TW = 16, BM = TH * TW;
     constexpr int NW = WGM * WGN, NT = (NL ? NL : NW) * 64;   // NT = threads that stage
     constexpr int WMT = BM / WGM, WNT = BN / WGN;
@@ -332,6 +335,8 @@ int msd_conv_halo_init() {
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream) {
     int rc = msd_conv_halo_init();
     if (rc) return rc;
+    if (a.tiles_m <= 0 || a.tiles_m >= (1 << 23) || a.tiles_n <= 0 || a.tiles_n >= 256)
+        MSD_FAIL(MSD_E_UNSUPPORTED, "conv_halo: tile counts beyond the packed launch arguments (row tiles < 2^23, column tiles < 256)");
     const int tiles = a.batch * (a.h_in / th) * (a.w_in / 16) * a.tiles_n;
     dim3 grid(tiles, slices);
     // `stages` picks the ring depth if that variant is built, otherwise the tile's default (3)

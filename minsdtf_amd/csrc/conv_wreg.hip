@@ -52,6 +52,7 @@ __device__ __forceinline__ void wr_load(wr_u32x4& lo, wr_u32x4& hi, const void* 
 // pair load the same fragments, the second from the CU's L1).
 template <int BM, int NJ, int NW, int S, bool DENSE, int KT = 1, int WGM = 1>
 __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(CG_HOT_PARAMS, const CGArgs p) {
+    CG_HOT_UNPACK;
     constexpr int NT = NW * 64;
     constexpr int WGN = NW / WGM;
     constexpr int BN = WGN * NJ * 16;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(CG_HOT_PARAMS, const
         if constexpr (DENSE) {
             const uint32_t mc = (uint32_t)min(m, hot_M - 1);   // rows past M re-read the last row: never stored
             aoff0[i] = (mc * (uint32_t)hot_c0 + (uint32_t)asrc[i]) * 2u;
-            aoff1[i] = (mc * (uint32_t)p.c1 + (uint32_t)asrc[i]) * 2u;
+            aoff1[i] = (mc * (uint32_t)hot_c1 + (uint32_t)asrc[i]) * 2u;
             ab[i] = ay[i] = ax[i] = 0;
             continue;
         }
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(CG_HOT_PARAMS, const
         if constexpr (DENSE) {
             const int c = kt * 64;
             const bool first = c < hot_c0;                       // wave-uniform: which tensor of the concat
-            const bf16_t* abase = first ? hot_a0 : p.a1;
+            const bf16_t* abase = first ? hot_a0 : hot_a1;
             const uint32_t cb = (uint32_t)(first ? c : c - hot_c0) * 2u;
 #pragma unroll
             for (int i = 0; i < AR; ++i) dma16s(abase, (first ? aoff0[i] : aoff1[i]) + cb, sbase + (uint32_t)(RPP * i) * 128u);
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(CG_HOT_PARAMS, const
         const int kx = extra ? p.pad : tap - ky * 3;
         const int cA = extra ? p.c2 : hot_c0;
         const bool first = c < cA;
-        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? hot_a0 : p.a1));
-        const int csrc = first ? cA : (extra ? p.K - p.nk_main * 64 - p.c2 : p.c1), coff = first ? c : c - cA;
+        const uint64_t sb = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? hot_a0 : hot_a1));
+        const int csrc = first ? cA : (extra ? p.K - p.nk_main * 64 - p.c2 : hot_c1), coff = first ? c : c - cA;
         const uint64_t zaddr = (uint64_t)zero;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
