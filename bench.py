@@ -16,7 +16,10 @@ timed region (RCCL), nothing crosses GPUs inside a step.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the dominant kernel (implicit-GEMM conv/dense on MFMA): algorithmic FLOP per launch
-                / its average launch duration measured here with HIP events on the launch stream
+                / its average launch duration measured here with HIP events on the launch stream;
+                `traffic` = L2-miss bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that THIS
+                run makes as child processes over tools/pmc_step.py before it touches the GPU itself (N = 1 only;
+                --quoted-traffic, or a box without rocprofv3, falls back to the newest file under profiles/ and says so)
   cpu_baseline  the oracle (fp32 CPU restatement of the reference path; Keras itself is not
                 installable here) timed on this box's host cores on a bounded sample
 """
@@ -56,6 +59,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--quoted-traffic", action="store_true",
+                    help="roofline.traffic from the newest PMC summary under profiles/ instead of two live rocprofv3 --pmc passes (saves ~2 min)")
     ap.add_argument("--controlnet", action="store_true", help="BASELINE config 5: ControlNet residuals every step")
     ap.add_argument("--sync-phases", action="store_true", help="drain the device at the end of every roctx phase range (profiling)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
@@ -69,6 +74,59 @@ def parse_args(argv=None):
                     help="replace the GPU pipeline by a trivial per-sample generator (launcher / sharding self-test; the "
                          "line is marked stub and is not a measurement)")
     return ap.parse_args(argv)
+
+
+LIVE_TRAFFIC = None   # summary of this run's own PMC passes (live_traffic), read by kernel_roofline
+
+
+def live_traffic(args):
+    """roofline.traffic measured by THIS run: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, as
+    MI355X_MICROARCH.md prescribes; the program itself after `--`) over tools/pmc_step.py — the same launch list run eagerly for two
+    denoise steps — started as CHILD processes before this process has touched the GPU, summarised by tools/pmc_summarize.py (its unit
+    and gfx950 corrections).  Returns the summary dict, or None (with the reason on stderr) when the passes cannot run here."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        log("live traffic: this process is itself running under a profiler; quoting profiles/ instead")
+        return None
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        log("live traffic: no rocprofv3 on PATH; quoting profiles/ instead")
+        return None
+    from tools import pmc_summarize
+
+    step_args = ["--size", str(args.size), "--batch", str(args.batch_per_gpu)] + (["--controlnet"] if args.controlnet else [])
+    for kv in args.opt:
+        step_args += ["--opt", kv]
+    tmp = tempfile.mkdtemp(prefix="msd_bench_pmc_")
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    acc = {}
+    t0 = time.time()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter.lower())
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   "python3", os.path.join(ROOT, "tools", "pmc_step.py")] + step_args
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            except subprocess.TimeoutExpired:
+                log(f"live traffic: the {counter} pass did not finish in 300 s; quoting profiles/ instead")
+                return None
+            if r.returncode != 0:
+                log(f"live traffic: the {counter} pass failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-400:]}")
+                return None
+            try:
+                acc[counter] = pmc_summarize.load(d, counter)
+            except SystemExit as e:
+                log(f"live traffic: {e}")
+                return None
+        res = pmc_summarize.summarise(acc["FETCH_SIZE"], acc["WRITE_SIZE"])
+        res["seconds"] = round(time.time() - t0, 1)
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _free_port() -> int:
@@ -212,6 +270,11 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the driver's plain `python bench.py --gpus N`: become the launcher BEFORE anything touches a GPU
         sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.backend == "nccl" and not args.stub_local
+            and not args.no_roofline and not args.quoted_traffic):
+        global LIVE_TRAFFIC   # (children first: nothing in this process has initialised the GPU yet)
+        LIVE_TRAFFIC = live_traffic(args)
 
     import torch
     import torch.distributed as dist
@@ -607,9 +670,14 @@ def kernel_roofline(sd, b, nsteps, control=False, size=512):
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
     # HBM-side bytes per launch come from the PMC pass committed under profiles/ (rocprofv3 --pmc cannot run
     # inside this process); null when the file is missing
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_rw = None, None, None
     tag = config_tag(b, size, control)
-    for rnd in range(9, 0, -1):   # newest committed PMC pass of THIS configuration (tools/measure_round.sh)
+    if LIVE_TRAFFIC and LIVE_TRAFFIC.get("conv_gemm"):
+        cg = LIVE_TRAFFIC["conv_gemm"]
+        traffic, traffic_rw = cg["hbm_bytes_per_launch"], [cg["read_bytes_per_launch"], cg["write_bytes_per_launch"]]
+        traffic_src = (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_step.py, child processes of this run "
+                       f"({cg['calls']} calls over 2 eager steps, {LIVE_TRAFFIC['seconds']} s)")
+    for rnd in (range(9, 0, -1) if traffic is None else ()):   # newest committed PMC pass of THIS configuration (tools/measure_round.sh)
         name = f"r{rnd}_pmc_traffic{tag}.json"
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -621,7 +689,7 @@ def kernel_roofline(sd, b, nsteps, control=False, size=512):
             continue
     roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> / dense_rowpanel_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": traffic_src, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_read_write": traffic_rw, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
             "gflop_per_launch": round(flop_per_launch / 1e9, 3)}
     if sclk:
         # profiles/r4_pmc_mfma.json: the matrix-pipe counter and this FLOP-derived figure agree within 5 % once both are taken over the

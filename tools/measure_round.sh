@@ -1,6 +1,7 @@
 #!/bin/bash
 # One measurement pass on the GPU box (run through gpurun), per BASELINE configuration that fits one GPU:
-#   the two PMC passes FIRST (so that the bench line quotes the traffic of this very build), then the bench line WITH its
+#   the two PMC passes FIRST (their summary goes to profiles/; the secondary configurations' bench lines quote it with
+#   --quoted-traffic, the headline bench line makes its own live passes, as the driver's run does), then the bench line WITH its
 #   roofline block; for the headline configuration also the rocprofv3 kernel-trace summary of the default bench command and a
 #   kernel-trace + marker-trace run split by roctx phase (prepare / denoise_loop / vae_decode / d2h).
 #   gpurun --timeout 1150 -- "bash tools/measure_round.sh r3 $(git rev-parse --short HEAD) [headline|b4|768|controlnet|all]"
@@ -57,17 +58,17 @@ if [ "$WHAT" = all ] || [ "$WHAT" = headline ]; then
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = b4 ]; then      # C3's per-GPU shape: batch 4 (fused cond+uncond batch 8)
     pmc _b4 --batch 4 || exit $?
-    $T 300 python bench.py --batch-per-gpu 4 --steps 3 --no-cpu-baseline > $OUT/${TAG}_bench_b4.json 2>> $OUT/bench_cfg.err
+    $T 300 python bench.py --batch-per-gpu 4 --steps 3 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_b4.json 2>> $OUT/bench_cfg.err
     echo "b4 done"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = 768 ]; then     # C4: 768x768, 50 steps
     pmc _768 --size 768 || exit $?
-    $T 400 python bench.py --size 768 --denoise-steps 50 --steps 2 --no-cpu-baseline > $OUT/${TAG}_bench_768.json 2>> $OUT/bench_cfg.err
+    $T 400 python bench.py --size 768 --denoise-steps 50 --steps 2 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_768.json 2>> $OUT/bench_cfg.err
     echo "768 done"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = controlnet ]; then   # C5's per-GPU shape: ControlNet, batch 1
     pmc _controlnet --controlnet || exit $?
-    $T 300 python bench.py --controlnet --steps 3 --no-cpu-baseline > $OUT/${TAG}_bench_controlnet.json 2>> $OUT/bench_cfg.err
+    $T 300 python bench.py --controlnet --steps 3 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_controlnet.json 2>> $OUT/bench_cfg.err
     echo "controlnet done"
 fi
 echo "configs done"

@@ -46,10 +46,8 @@ def load(dirname, counter):
     return acc
 
 
-def main():
-    fetch_dir, write_dir, out = sys.argv[1:4]
-    commit = sys.argv[4] if len(sys.argv) > 4 else None   # the build the counters were taken on (bench.py quotes it)
-    rd, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+def summarise(rd, wr):
+    """Per entry point: launches, KiB sums and corrected bytes per launch of the two passes (also called by bench.py on its own passes)."""
     res = {"_note": "rocprofv3 --pmc over tools/pmc_step.py (2 eager denoise steps, 512x512, batch 1 = fused cond+uncond batch 2); "
                     "bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x 1024; L2-miss bytes incl. Infinity-Cache hits"}
     for k in sorted(set(rd) | set(wr)):
@@ -59,6 +57,13 @@ def main():
         res[k] = {"kernel_launches": max(r["kernels"], w["kernels"]), "calls": calls, "fetch_size_kib_sum": round(r["kib"], 1),
                   "write_size_kib_sum": round(w["kib"], 1), "read_bytes_per_launch": round(read_b / calls),
                   "write_bytes_per_launch": round(write_b / calls), "hbm_bytes_per_launch": round((read_b + write_b) / calls)}
+    return res
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    commit = sys.argv[4] if len(sys.argv) > 4 else None   # the build the counters were taken on (bench.py quotes it)
+    res = summarise(load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE"))
     if commit:
         res["commit"] = commit
     with open(out, "w") as f:
