@@ -124,6 +124,51 @@ def test_algorithmic_flop_table():
     assert abs(bench.algorithmic_tflop_per_image(512, 25, controlnet=True) - 56.12) < 0.02
 
 
+def test_live_traffic_falls_back_without_a_profiler(monkeypatch, tmp_path, capsys):
+    """bench.py measures roofline.traffic with its own rocprofv3 --pmc child passes; where they cannot run (no rocprofv3 on PATH, or
+    the bench itself running under a profiler) it says so and quotes the committed summary instead of failing or hanging."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    args = bench.parse_args([])
+    monkeypatch.setenv("PATH", str(tmp_path))            # nothing executable in there
+    monkeypatch.delenv("ROCP_TOOL_LIBRARIES", raising=False)
+    assert bench.live_traffic(args) is None
+    assert "no rocprofv3" in capsys.readouterr().err
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.live_traffic(args) is None
+    assert "under a profiler" in capsys.readouterr().err
+
+
+def test_pmc_summary_arithmetic(tmp_path):
+    """The unit and gfx950 corrections of the PMC summary bench.py shares with tools/pmc_summarize.py: FETCH_SIZE KiB x 1024 x 2,
+    WRITE_SIZE KiB x 1024, per msd_conv_gemm CALL (a split-K reduction launch belongs to the call in front of it)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import pmc_summarize
+
+    def write(d, counter, rows):
+        os.makedirs(d)
+        with open(os.path.join(d, "1_counter_collection.csv"), "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for k, v in rows:
+                f.write(f'"{k}",{counter},{v}\n')
+
+    kernels = [("void conv_gemm_dma_kernel<64, 64>(x)", 100.0), ("void splitk_finalize_kernel<3>(y)", 20.0),
+               ("void conv3x3_halo_kernel<8, 80>(z)", 80.0), ("void gn_group_kernel<2, 4>(w)", 10.0)]
+    write(str(tmp_path / "f"), "FETCH_SIZE", kernels)
+    write(str(tmp_path / "w"), "WRITE_SIZE", [(k, v / 2) for k, v in kernels])
+    res = pmc_summarize.summarise(pmc_summarize.load(str(tmp_path / "f"), "FETCH_SIZE"), pmc_summarize.load(str(tmp_path / "w"), "WRITE_SIZE"))
+    cg = res["conv_gemm"]
+    assert cg["calls"] == 2 and cg["kernel_launches"] == 3
+    assert cg["read_bytes_per_launch"] == 200 * 1024 * 2 // 2 and cg["write_bytes_per_launch"] == 100 * 1024 // 2
+    assert cg["hbm_bytes_per_launch"] == cg["read_bytes_per_launch"] + cg["write_bytes_per_launch"]
+    assert res["group_norm"]["calls"] == 1
+
+
 def test_shard_bounds():
     from minsdtf_amd.dist import shard_bounds
 
