@@ -52,7 +52,14 @@ __device__ __forceinline__ void halo_wait(int later, bool halo) {
                         uint32_t hot_mg_tx, int hot_nkc, int hot_nk_per, int hot_c0, int hot_N
 #define HALO_HOT_ARGS(a) (a).a0, (a).w, (a).w_in, (a).h_in, ((uint32_t)(a).tiles_m | ((uint32_t)(a).tiles_n << 23) | ((uint32_t)((a).m_fast ? 1u : 0u) << 31)), \
                          (a).mg_tdiv, (a).mg_tps, (a).mg_tx, (a).nkc, (a).nk_per, (a).c0, (a).N
-template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1, int NL = 0>
+// PFX = 1 (`stages` 90 + depth: 3 taps per step, ring of 3, two loader waves): the K loop is ROTATED so that
+// no fragment read stands alone in front of the MFMAs it feeds.  In the form above a step is barrier -> reads of tap 0 -> {reads 1, MFMAs 0,
+// reads 2, MFMAs 1, MFMAs 2}: the first tap's reads (0.3-0.4 us on the LDS port, four waves at once) and the last tap's MFMAs overlap
+// nothing.  Rotated: reads 1 | MFMAs 0 | reads 2 | MFMAs 1 | wait + barrier (the NEXT filter row's weights are visible) | reads of the next
+// step's tap 0 | MFMAs 2 — every read is issued in front of MFMAs that do not depend on it.  The barrier in the middle of a step orders the
+// stage reuse: in front of it every wave has retired the reads of the step's own stage (lgkmcnt(0)), so that stage takes filter row it + 3
+// right behind the barrier and a row keeps two steps to land.  Same taps in the same order: the same bits.
+template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1, int NL = 0, int PFX = 0>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HALO_HOT_PARAMS, const CGArgs p) {
     const int hot_tiles_m = (int)(hot_pk_tiles & 0x7FFFFFu), hot_tiles_n = (int)((hot_pk_tiles >> 23) & 0xFFu), hot_m_fast = (int)(hot_pk_tiles >> 31);
     constexpr int TW = 16, BM = TH * TW;
@@ -177,7 +184,88 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HAL
     int cw = c_begin, tw = S - 1, sw = S - 1;   // (chunk, tap, stage) of the next weight tile to issue
     if (tw >= SPC) { tw -= SPC; ++cw; }
     int since_halo = 1 << 20;                   // iterations since a halo was issued
-    for (int it = 0; it < nkt; ++it) {
+    if constexpr (PFX) {
+        static_assert(TAPS == 3 && S == 3, "rotated loop: 3 taps per step, ring of 3 filter rows");
+        const int rw = cg_wrow(r);   // weight rows enter the MFMA in the order 0-3, 8-11, 4-7, 12-15 (cg_epilogue)
+        auto read_tap_at = [&](int hb, int stg, int ky, int kx, bf16x8 (&af)[2][MI], bf16x8 (&wf)[2][NJ]) {
+            const char* bH = smem + hb * H_BYTES;
+            const char* bW = smem + 2 * H_BYTES + stg * W_BYTES + kx * W1_BYTES + (wn * WNT + rw) * 128;
+            int hrow[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) hrow[i] = (wm * MI + i + ky) * HW_ + kx + r;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int wc = ((ks * 4 + g) ^ (rw >> 1)) << 4;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[ks][i] = *reinterpret_cast<const bf16x8*>(bH + hrow[i] * 128 + (((ks * 4 + g) ^ ((hrow[i] >> 1) & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bW + j * 16 * 128 + wc);
+            }
+        };
+        auto mfma_frags = [&](const bf16x8 (&af)[2][MI], const bf16x8 (&wf)[2][NJ]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+        };
+        bf16x8 fa[2][MI], wa[2][NJ], fb[2][MI], wb[2][NJ];
+        // The ring's third stage is filled in the prologue too: a stage is handed back at the barrier of the step that reads it (its
+        // last reads are retired by the lgkmcnt(0) in front of that barrier), so filter row it + 3 goes out in step it and a row has
+        // two steps to land, as in the lock-step form.
+        if (stages_tiles && S - 1 < nkt) {
+            issue_w(cw, tw, sw);
+            if (++tw == SPC) { tw = 0; ++cw; }
+            if (++sw == S) sw = 0;
+        }
+        // filter row 0 (+ the first halo) visible: only rows 1 and 2 are younger
+        if (stages_tiles) halo_wait<BR, HR, 2>(min(2, nkt - 1), false);
+        __builtin_amdgcn_s_barrier();
+        MSD_STAMP(2);
+        if (computes && nkt > 0) read_tap_at(0, 0, 0, 0, fa, wa);
+        bool halo_prev = false;   // a halo was issued in the previous step (it is younger than the row this step waits for)
+        // one step; X holds tap 0 on entry and the step leaves the next step's tap 0 in Y
+        auto step = [&](int it, bf16x8 (&xa)[2][MI], bf16x8 (&xw)[2][NJ], bf16x8 (&ya)[2][MI], bf16x8 (&yw)[2][NJ]) {
+#ifdef MSD_STAMPS
+            if (it == (nkt >> 1)) MSD_STAMP(5);
+#endif
+            if (computes) {
+                read_tap_at(hbuf, stage, tap, 1, ya, yw);
+                mfma_frags(xa, xw);
+                read_tap_at(hbuf, stage, tap, 2, xa, xw);
+                mfma_frags(ya, yw);
+            }
+            // every read of THIS step's stage has landed (tap 2's fragments wait in registers for their MFMAs behind the barrier) ...
+            if (computes) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ... and filter row it + 1 (with the halo its chunk starts with) has landed; younger in the queue and allowed to fly on:
+            // row it + 2 and, in a chunk's second step, the next chunk's halo issued one step ago
+            if (stages_tiles) halo_wait<BR, HR, 1>(it + 2 < nkt ? 1 : 0, halo_prev);
+            __builtin_amdgcn_s_barrier();
+            if (stages_tiles) {   // this step's stage and, at a chunk's first step, the other halo buffer are free now
+                halo_prev = tap == 0 && c + 1 < c_end;
+                if (halo_prev) issue_halo(c + 1, hbuf ^ 1);
+                if (it + S < nkt) {
+                    issue_w(cw, tw, sw);
+                    if (++tw == SPC) { tw = 0; ++cw; }
+                    if (++sw == S) sw = 0;
+                }
+            }
+            if (++stage == S) stage = 0;
+            if (++tap == SPC) { tap = 0; ++c; hbuf ^= 1; }
+            if (computes) {
+                if (it + 1 < nkt) read_tap_at(hbuf, stage, tap, 0, ya, yw);
+                mfma_frags(xa, xw);
+            }
+        };
+        for (int it = 0; it < nkt; it += 2) {
+            step(it, fa, wa, fb, wb);
+            if (it + 1 < nkt) step(it + 1, fb, wb, fa, wa);
+        }
+    }
+    for (int it = 0; !PFX && it < nkt; ++it) {
         // Retire W(it) (and, being older in the queue, the halo of this chunk).  Younger than W(it):
         // W(it+1) .. W(it+S-2) as far as they exist, plus the halo if one was issued in iterations
         // it-S+2 .. it-1 (loads complete in order, so "at most N outstanding" retires everything older).
@@ -304,7 +392,9 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HAL
     X(8, 80, 4, 1, 33, 0, 3, 0)  \
     X(8, 64, 4, 2, 33, 1, 3, 0)  \
     X(8, 80, 4, 1, 63, 0, 3, 2)  \
-    X(8, 64, 2, 2, 63, 0, 3, 2)
+    X(8, 64, 2, 2, 63, 0, 3, 2)  \
+    X(8, 80, 4, 1, 93, 0, 3, 2)  \
+    X(8, 64, 2, 2, 93, 0, 3, 2)
 
 template <int TH, int BN, int WGM, int WGN, int SC, int TAPS, int NL>
 static constexpr int halo_lds() {
@@ -322,7 +412,7 @@ int msd_conv_halo_init() {
     hipError_t e = hipSuccess;
 #define X(th, bn, wgm, wgn, st, var, taps, nl)                                                                         \
     if (e == hipSuccess)                                                                                              \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st % 30, taps, nl>), \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st % 30, taps, nl, (st >= 90)>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st, taps, nl>());
     MSD_HALO_CFGS(X)
 #undef X
@@ -354,7 +444,7 @@ int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int varian
     }
 #define X(th_, bn_, wgm, wgn, st, var, taps, nl)                                                                          \
     if (th == th_ && bn == bn_ && stages == st && variant == var) {                                                       \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps, nl>), grid, dim3((wgm * wgn + nl) * 64), \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps, nl, (st >= 90)>), grid, dim3((wgm * wgn + nl) * 64), \
                            (halo_lds<th_, bn_, wgm, wgn, st, taps, nl>()), stream, HALO_HOT_ARGS(a), a);                                    \
         return MSD_OK;                                                                                                    \
     }

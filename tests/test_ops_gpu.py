@@ -102,6 +102,14 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=8, W=16, c0=320, N=320, ks=3, tile_m=1128, tile_n=80, stages=63, same_as=(1128, 80, 0)),
     dict(B=1, H=16, W=32, c0=64, c1=64, N=100, ks=3, tile_m=1128, tile_n=64, stages=63, same_as=(1128, 64, 0)),
     dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, stages=63, splitk=2),
+    # ... rotated K loop (stages 90 + depth, with the loader waves): every fragment read in front of MFMAs that do not need it, the
+    # barrier in the middle of a step; same taps in the same order, the same bits
+    dict(B=2, H=8, W=16, c0=320, N=320, ks=3, tile_m=1128, tile_n=80, stages=93, same_as=(1128, 80, 0)),
+    dict(B=1, H=16, W=32, c0=64, c1=64, N=100, ks=3, tile_m=1128, tile_n=64, stages=93, same_as=(1128, 64, 0)),     # one chunk per tensor of the concat, ragged N
+    dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, stages=93, splitk=2),
+    dict(B=2, H=16, W=16, c0=64, N=128, ks=3, tile_m=1128, tile_n=64, stages=93, same_as=(1128, 64, 0)),            # a single chunk: 3 steps
+    dict(B=1, H=16, W=16, c0=320, N=160, ks=3, tile_m=1128, tile_n=80, stages=93, splitk=2, same_as=(1128, 80, 0)), # 5 chunks in slices of 3 + 2
+    dict(B=2, H=32, W=32, c0=192, c1=128, N=320, ks=3, tile_m=1128, tile_n=80, stages=93, same_as=(1128, 80, 0)),   # concat boundary inside the walk, 16 tiles per sample
     # wreg form (conv_wreg.hip; tile_m 4000 + rows): weights global -> VGPR from the fragment-major image (w_layout 2), all waves
     # split over N; the tile kernel's K walk and epilogue, so its bits
     dict(B=2, H=16, W=16, c0=64, N=128, ks=3, tile_m=4128, tile_n=128, stages=3, same_as=(128, 128, 0)),
