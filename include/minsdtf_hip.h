@@ -132,6 +132,8 @@ typedef struct MsdConvGemm {
                             2128x64:33; 60 + depth = the same with two loader waves that do all the staging: 1128x64:63 1128x80:63;
                             90 + depth = the 60s' form with the K loop rotated (a step's barrier sits between its second and third tap, the
                             next step's first fragments are read under the third tap's MFMAs; same taps in the same order, same bits): 1128x64:93 1128x80:93;
+                            150 + depth = the one-tap form rotated (the fragments of tap t + 1 are read under the MFMAs of tap t, every ring
+                            stage in flight; same bits): 1128x64:153/158 1128x128:153/156 1128x80:158 1256x80:153/155 1256x128:153;
                             wreg form (tile_m 4000 + rows): depth 3 / 4, + 10 = 8 waves (4256x128: a 2 x 4 wave grid),
                             + 20 = two K tiles (128 channels) per ring stage: 4064x64:4/23/24 4064x128:3/4/23/24 4064x256:3/4/23
                             4128x64:3/4/23 4128x128:3/4/13/23 4256x64:3 4256x128:13/14 */

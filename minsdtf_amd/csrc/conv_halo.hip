@@ -184,7 +184,79 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HAL
     int cw = c_begin, tw = S - 1, sw = S - 1;   // (chunk, tap, stage) of the next weight tile to issue
     if (tw >= SPC) { tw -= SPC; ++cw; }
     int since_halo = 1 << 20;                   // iterations since a halo was issued
-    if constexpr (PFX) {
+    if constexpr (PFX && TAPS == 1) {
+        // One tap per step (`stages` 150 + depth): the fragments of tap it + 1 are read under the MFMAs of tap it.  Per step: lgkmcnt(0) (the
+        // fragments of tap it — the last reads of stage it % S — are in registers) -> counted wait for tap it + 1's weights -> barrier ->
+        // DMA of tap it + S into the stage just handed back -> reads of tap it + 1 -> MFMAs of tap it.  The ring holds S taps in
+        // flight or landed instead of S - 1 (all S stages are filled in the prologue), so the prefetch costs no ring depth.
+        const int rw = cg_wrow(r);
+        auto read_tap_at = [&](int hb, int stg, int tp, bf16x8 (&af)[2][MI], bf16x8 (&wf)[2][NJ]) {
+            const int ky = (tp * 11) >> 5, kx = tp - ky * 3;   // (tp / 3 for tp < 9)
+            const char* bH = smem + hb * H_BYTES;
+            const char* bW = smem + 2 * H_BYTES + stg * W_BYTES + (wn * WNT + rw) * 128;
+            int hrow[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) hrow[i] = (wm * MI + i + ky) * HW_ + kx + r;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int wc = ((ks * 4 + g) ^ (rw >> 1)) << 4;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[ks][i] = *reinterpret_cast<const bf16x8*>(bH + hrow[i] * 128 + (((ks * 4 + g) ^ ((hrow[i] >> 1) & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bW + j * 16 * 128 + wc);
+            }
+        };
+        auto mfma_frags = [&](const bf16x8 (&af)[2][MI], const bf16x8 (&wf)[2][NJ]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+        };
+        bf16x8 fa[2][MI], wa[2][NJ], fb[2][MI], wb[2][NJ];
+        if (stages_tiles && S - 1 < nkt) {   // the ring's last stage too
+            issue_w(cw, tw, sw);
+            if (++tw == SPC) { tw = 0; ++cw; }
+            if (++sw == S) sw = 0;
+        }
+        if (stages_tiles) halo_wait<BR, HR, S - 1>(min(S - 1, nkt - 1), false);   // tap 0 and the first halo: everything younger may fly on
+        __builtin_amdgcn_s_barrier();
+        MSD_STAMP(2);
+        if (computes && nkt > 0) read_tap_at(0, 0, 0, fa, wa);
+        auto step = [&](int it, bf16x8 (&xa)[2][MI], bf16x8 (&xw)[2][NJ], bf16x8 (&ya)[2][MI], bf16x8 (&yw)[2][NJ]) {
+#ifdef MSD_STAMPS
+            if (it == (nkt >> 1)) MSD_STAMP(5);
+#endif
+            if (computes) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // tap it + 1 (and, at a chunk's last tap, the next chunk's halo) has landed; younger: taps it + 2 .. it + S - 1 and a halo
+            // issued within the last S - 2 steps
+            if (stages_tiles) halo_wait<BR, HR, S - 2>(max(0, min(S - 2, nkt - 2 - it)), since_halo <= S - 2);
+            __builtin_amdgcn_s_barrier();
+            if (stages_tiles) {
+                if (tap == 0 && c + 1 < c_end) { issue_halo(c + 1, hbuf ^ 1); since_halo = 0; }
+                if (it + S < nkt) {
+                    issue_w(cw, tw, sw);
+                    if (++tw == SPC) { tw = 0; ++cw; }
+                    if (++sw == S) sw = 0;
+                }
+            }
+            ++since_halo;
+            if (++stage == S) stage = 0;
+            if (++tap == SPC) { tap = 0; ++c; hbuf ^= 1; }
+            if (computes) {
+                if (it + 1 < nkt) read_tap_at(hbuf, stage, tap, ya, yw);
+                mfma_frags(xa, xw);
+            }
+        };
+        for (int it = 0; it < nkt; it += 2) {
+            step(it, fa, wa, fb, wb);
+            if (it + 1 < nkt) step(it + 1, fb, wb, fa, wa);
+        }
+    }
+    if constexpr (PFX && TAPS == 3) {
         static_assert(TAPS == 3 && S == 3, "rotated loop: 3 taps per step, ring of 3 filter rows");
         const int rw = cg_wrow(r);   // weight rows enter the MFMA in the order 0-3, 8-11, 4-7, 12-15 (cg_epilogue)
         auto read_tap_at = [&](int hb, int stg, int ky, int kx, bf16x8 (&af)[2][MI], bf16x8 (&wf)[2][NJ]) {
@@ -394,7 +466,15 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HAL
     X(8, 80, 4, 1, 63, 0, 3, 2)  \
     X(8, 64, 2, 2, 63, 0, 3, 2)  \
     X(8, 80, 4, 1, 93, 0, 3, 2)  \
-    X(8, 64, 2, 2, 93, 0, 3, 2)
+    X(8, 64, 2, 2, 93, 0, 3, 2)  \
+    X(8, 64, 2, 2, 153, 0, 1, 0) \
+    X(8, 64, 2, 2, 158, 0, 1, 0) \
+    X(8, 128, 2, 4, 153, 0, 1, 0) \
+    X(8, 128, 2, 4, 156, 0, 1, 0) \
+    X(16, 128, 4, 2, 153, 0, 1, 0) \
+    X(8, 80, 4, 1, 158, 0, 1, 0) \
+    X(16, 80, 4, 1, 153, 0, 1, 0) \
+    X(16, 80, 4, 1, 155, 0, 1, 0)
 
 template <int TH, int BN, int WGM, int WGN, int SC, int TAPS, int NL>
 static constexpr int halo_lds() {

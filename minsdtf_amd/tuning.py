@@ -29,7 +29,9 @@ HALO_TILES = ((1128, 64, 0), (1128, 128, 0), (1256, 128, 0), (1128, 80, 0), (125
               (1128, 64, 8), (1128, 128, 6), (1128, 80, 8), (1256, 80, 5), (2128, 64, 0), (2128, 80, 0),
               (1128, 64, 33), (1128, 64, 34), (1128, 80, 33), (2128, 64, 33),   # 30 + depth: 3 taps (a filter row) per K step
               (1128, 64, 63), (1128, 80, 63),   # 60 + depth: ... staged by two loader waves behind the compute waves
-              (1128, 64, 93), (1128, 80, 93))   # 90 + depth: the 60s' form with the K loop rotated (every fragment read issued in front of MFMAs that do not need it)
+              (1128, 64, 93), (1128, 80, 93),   # 90 + depth: the 60s' form with the K loop rotated (every fragment read issued in front of MFMAs that do not need it)
+              (1128, 64, 153), (1128, 64, 158), (1128, 128, 153), (1128, 128, 156), (1256, 128, 153), (1128, 80, 158),
+              (1256, 80, 153), (1256, 80, 155))   # 150 + depth: the one-tap form rotated (tap it + 1's fragments read under tap it's MFMAs)
 
 
 # (4000 + rows per workgroup, columns per workgroup, ring depth [+ 10: 8 waves] [+ 20: two K tiles per stage]): wreg form (csrc/conv_wreg.hip) — weights global ->

@@ -110,6 +110,17 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=16, W=16, c0=64, N=128, ks=3, tile_m=1128, tile_n=64, stages=93, same_as=(1128, 64, 0)),            # a single chunk: 3 steps
     dict(B=1, H=16, W=16, c0=320, N=160, ks=3, tile_m=1128, tile_n=80, stages=93, splitk=2, same_as=(1128, 80, 0)), # 5 chunks in slices of 3 + 2
     dict(B=2, H=32, W=32, c0=192, c1=128, N=320, ks=3, tile_m=1128, tile_n=80, stages=93, same_as=(1128, 80, 0)),   # concat boundary inside the walk, 16 tiles per sample
+    # ... and the one-tap form rotated (stages 150 + depth): tap it + 1's fragments read under tap it's MFMAs, all S stages in flight
+    dict(B=2, H=16, W=16, c0=192, N=128, ks=3, tile_m=1128, tile_n=64, stages=153, same_as=(1128, 64, 0)),
+    dict(B=1, H=16, W=32, c0=64, c1=64, N=100, ks=3, tile_m=1128, tile_n=64, stages=158, same_as=(1128, 64, 0)),    # ring deeper than a chunk's first steps, concat, ragged N
+    dict(B=2, H=16, W=16, c0=256, N=128, ks=3, tile_m=1128, tile_n=64, stages=153, splitk=2, same_as=(1128, 64, 0)),
+    dict(B=2, H=16, W=32, c0=128, c1=64, N=192, ks=3, tile_m=1128, tile_n=128, stages=153, same_as=(1128, 128, 0)),
+    dict(B=2, H=16, W=32, c0=128, c1=64, N=192, ks=3, tile_m=1128, tile_n=128, stages=156, splitk=2, same_as=(1128, 128, 0)),
+    dict(B=2, H=16, W=16, c0=128, N=256, ks=3, tile_m=1256, tile_n=128, stages=153, same_as=(1256, 128, 0)),
+    dict(B=1, H=32, W=32, c0=64, N=128, ks=3, tile_m=1256, tile_n=128, stages=153, same_as=(1256, 128, 0)),         # a single chunk: 9 steps
+    dict(B=1, H=16, W=16, c0=64, N=320, ks=3, tile_m=1128, tile_n=80, stages=158, same_as=(1128, 80, 0)),           # ring of 8 on a 9-step walk
+    dict(B=2, H=16, W=16, c0=320, N=320, ks=3, tile_m=1256, tile_n=80, stages=153, same_as=(1256, 80, 0)),
+    dict(B=2, H=16, W=16, c0=128, c1=192, N=160, ks=3, tile_m=1256, tile_n=80, stages=155, splitk=2, same_as=(1256, 80, 0)),
     # wreg form (conv_wreg.hip; tile_m 4000 + rows): weights global -> VGPR from the fragment-major image (w_layout 2), all waves
     # split over N; the tile kernel's K walk and epilogue, so its bits
     dict(B=2, H=16, W=16, c0=64, N=128, ks=3, tile_m=4128, tile_n=128, stages=3, same_as=(128, 128, 0)),
