@@ -123,7 +123,13 @@ typedef struct MsdConvGemm {
                             VGPR from the fragment-major image (w_layout 2, required: MSD_E_ARG with any other layout), only the
                             activation tile goes through LDS; tile_n x stages must name a built configuration (MSD_E_UNSUPPORTED
                             otherwise: there is no fallback, the other forms cannot read that image); N % 16 == 0.  Same K walk
-                            and epilogue as the tile kernel: the same results bit for bit */
+                            and epilogue as the tile kernel: the same results bit for bit;
+                            5000 + rows (5256 / 5128) = the big form (csrc/conv_big.hip) for M >= 8192: 256 x 256 / 256 x 160 / 256 x 128 /
+                            128 x 256 macro tiles on 8 waves whose two halves run one barrier apart (one multiplies while the other
+                            reads fragments and issues the LDS-DMAs of the K tile one or two ahead); w_layout 0 or 1; no ln_out;
+                            fewer than 2^24 input pixels; tile_n x stages must name a built configuration (MSD_E_UNSUPPORTED
+                            otherwise).  Same K walk and epilogue as the tile kernel: the same results bit for bit.
+                            tile_m >= 6000: MSD_E_ARG */
     int32_t stages;      /* 0 = default LDS ring depth of the tile; deeper rings built: 128x128:4 64x64:8 64x128:5 128x64:5
                             128x80:4; halo tiles 1128x64:8 1128x128:6 1128x80:8 1256x80:5 (an unknown depth = the default);
                             10 + depth = the tile on 8 waves (two per SIMD): 64x64:14 128x64:13 64x128:13;
@@ -136,7 +142,10 @@ typedef struct MsdConvGemm {
                             stage in flight; same bits): 1128x64:153/158 1128x128:153/156 1128x80:158 1256x80:153/155 1256x128:153;
                             wreg form (tile_m 4000 + rows): depth 3 / 4, + 10 = 8 waves (4256x128: a 2 x 4 wave grid),
                             + 20 = two K tiles (128 channels) per ring stage: 4064x64:4/23/24 4064x128:3/4/23/24 4064x256:3/4/23
-                            4128x64:3/4/23 4128x128:3/4/13/23 4256x64:3 4256x128:13/14 */
+                            4128x64:3/4/23 4128x128:3/4/13/23 4256x64:3 4256x128:13/14;
+                            big form (tile_m 5000 + rows): a configuration code, not a depth: 5256x256:0 (2 x 2 quadrant phases, 2 K-tile
+                            buffers) 5256x160:0/1/2 (quadrants x 3 buffers / row halves x 3 / quadrants x 2) 5256x128:0/1 5128x256:0/1
+                            (row halves / quadrants, 3 buffers) */
     const float* ln_in;      /* float2 [M][ln_in_slots] row-moment partials of the input rows, or NULL */
     const float* ln_colsum;  /* [N]: sum_k W[n][k] of the gamma-folded bf16 weights (with ln_in) */
     float* ln_out;           /* float2 [M][ln_out_slots] row-moment partials of the stored output, or NULL */

@@ -1,0 +1,481 @@
+// Implicit-GEMM convolution / dense layer on 256-row macro tiles for M >= 8192 ("big" form; round 5).
+//
+// Same contraction, K walk (64-channel tiles of one tap, ascending), MFMA operand placement and epilogue as conv_gemm.hip, so the
+// same bits (tests compare them): which form runs a layer is a per-(shape, batch) speed choice inside the layer's numerics class.
+// What changes is the shape of the K loop.  conv_gemm's tiles top out at 64 x 64 per wave and 256 x 128 per workgroup: at batch >= 4
+// its K step is bound by the L2 -> LDS bytes a CU can pull (48 KB per K tile in 0.79-0.88 us against 0.43 us of MFMA
+// time), and every wave of a workgroup is in the same phase (all read fragments, then all multiply).  Here:
+//   * macro tile 256 x 256 (128 FLOP per staged byte instead of 85), 256 x 160 for N = 320 / 640 / 960, 256 x 128, 128 x 256; 8 waves,
+//     each 128 x 64 (64 x 80, 64 x 64): 128 (80, 64) accumulator registers;
+//   * the wave's K tile is cut into PH phases (2 x 2 quadrants of the wave tile in snake order, or row parts): a phase reads only the
+//     fragments its quadrant needs (48-64 operand registers live, not 96), then issues its 8-20 MFMAs under s_setprio;
+//   * the two half-workgroups (waves 0-3 / 4-7 = the two waves of every SIMD) run ONE BARRIER APART: while one half issues its MFMA
+//     cluster the other issues fragment reads, address generation and LDS-DMAs.  Two raw s_barriers per phase keep the halves in
+//     that lock step (MI355X_MICROARCH.md, Two waves per SIMD: matrix beside memory is the pairing that pays);
+//   * operands go L2 -> LDS by LDS-DMA in NEED ORDER (the rows phase 0 reads first), ~2 DMAs per thread and phase, one whole K tile
+//     (NB = 2 buffers) or two (NB = 3) ahead; a counted s_waitcnt vmcnt(N) in front of the barrier that precedes the phase that
+//     reads a round retires exactly the rounds that phase needs - vmcnt never reaches 0 inside the loop;
+//   * the LDS image holds rows in need order ([A part 0 | A part 1 ..] and [W part 0 | W part 1]), 128-byte rows, 16-byte chunk
+//     index XOR (row >> 1) & 7 on the SOURCE address (LDS-DMA writes lane-linear), undone in the ds_read_b128 fragment reads.
+// Time is counted in SLOTS (barrier to barrier).  Half 0 runs LOAD(P) in slot 2P and MFMA(P) in slot 2P + 1, half 1 one slot later.
+// Hazards (BigGeo::hazards_ok holds them for every configuration built):
+//   RAW  every wave waits for the rounds phase P + 1 reads at the end of its LOAD(P) slot; the later half's LOAD(P) slot ends with the
+//        barrier in front of the earlier half's LOAD(P + 1), so both halves' DMAs have landed and are visible when either half reads;
+//   WAR  a round of a buffer is re-issued no earlier than 3 slots after the later half's read of its previous occupant was ISSUED
+//        (that read has returned at the lgkmcnt(0) which heads the slot in between).
+// No ln_out (LayerNorm-fold producer) epilogue: those layers have K = N <= 1280 and stay on the small tiles; the host refuses.
+#include <type_traits>
+#include "conv_common.h"
+
+#ifdef MSD_STAMPS
+extern "C" MSD_API int msd_debug_stamps_big(unsigned long long* host_out, int count) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count);
+}
+#endif
+
+// ---- geometry of a configuration (all compile-time) --------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int IH, int JH, int NB>
+struct BigGeo {
+    static_assert(WGM * WGN == 8, "8 waves");
+    static_assert(BM % (WGM * 16) == 0 && BN % (WGN * 16) == 0 && BM % 64 == 0 && BN % 32 == 0, "tile");
+    static_assert((JH == 1 && (IH == 2 || IH == 4)) || (JH == 2 && IH == 2), "phase structure");
+    static constexpr int WMT = BM / WGM, WNT = BN / WGN, MI = WMT / 16, NJ = WNT / 16;
+    static_assert(MI % IH == 0 && NJ >= JH && (MI <= 4 || MI % 4 == 0), "parts");
+    static constexpr int IHS = MI / IH;                              // row fragments per A part
+    static constexpr int JS0 = (NJ + JH - 1) / JH, JS1 = NJ - JS0;   // column fragments of W part 0 / 1
+    static constexpr int PH = IH * JH;                               // phases per K tile
+    static constexpr int APR = WGM * IHS * 16;                       // rows of one A part
+    static constexpr int WP0 = WGN * JS0 * 16;                       // rows of W part 0
+    static_assert(APR % 64 == 0, "an A part is a whole number of 64-row rounds");
+    static constexpr int ARP = APR / 64, AR = BM / 64;               // rounds per A part / per tile
+    static constexpr int WRF = BN / 64, WRH = (BN % 64) / 32, WR = WRF + WRH;   // full W rounds, a half round (32 rows) when BN % 64 == 32
+    static constexpr int G = AR + WR;                                // DMA rounds (= vector-memory operations per thread) per K tile
+    static constexpr int LEADT = NB - 1;                             // K tiles in flight ahead of the one being read
+    static constexpr int A_BYTES = BM * 128, ST_BYTES = (BM + BN) * 128;
+    static constexpr int LDS = NB * ST_BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS");
+    // need order: A part 0, all of W (part 0 then part 1), A parts 1 ..
+    static constexpr bool seq_is_a(int s) { return s < ARP || s >= ARP + WR; }
+    static constexpr int seq_round(int s) { return s < ARP ? s : (s < ARP + WR ? s - ARP : s - WR); }
+    // rounds issued in phase p, and up to and including it
+    static constexpr int g_of(int p) { return G / PH + (p < G % PH ? 1 : 0); }
+    static constexpr int cum(int p) { int c = 0; for (int q = 0; q <= p; ++q) c += g_of(q); return c; }
+    static constexpr int issue_phase(int s) { for (int p = 0; p < PH; ++p) if (s < cum(p)) return p; return PH - 1; }
+    // highest sequence index phase p (or an earlier one) reads
+    static constexpr int need(int p) {
+        if (JH == 2) return p == 0 ? ARP + (WP0 - 1) / 64 : (p == 1 ? ARP + WR - 1 : G - 1);
+        return ARP * (p + 1) + WR - 1;
+    }
+    // phase in which the rows of sequence element s are read (the later one, for a W round that straddles both parts)
+    static constexpr int read_phase(int s) {
+        if (s < ARP) return 0;
+        if (s < ARP + WR) return (JH == 2 && (s - ARP + 1) * 64 > WP0) ? 1 : 0;
+        const int part = 1 + (s - ARP - WR) / ARP;
+        return JH == 2 ? 2 : part;
+    }
+    static constexpr bool hazards_ok() {
+        for (int s = 0; s < G; ++s) {
+            int np = 0;
+            while (need(np) < s) ++np;
+            if (LEADT * PH + np - issue_phase(s) < 3) return false;      // RAW lead: >= 3 phases between issue and first read
+            // WAR: issue slot 2 (PH t + is) >= 2 (PH (t + LEADT - NB) + lr) + 1 + 3  <=>  is >= lr - PH + 2
+            if (issue_phase(s) < read_phase(s) - PH + 2) return false;
+        }
+        return true;
+    }
+    static_assert(hazards_ok(), "issue schedule violates the lead / reuse rules");
+};
+
+__device__ __forceinline__ void big_wait(int n) {   // s_waitcnt vmcnt(n), n wave-uniform in [0, 31]: the loop's tail and the prologue only
+    switch (n) {
+#define W1(x) case x: wait_vmcnt<x>(); break;
+#define W8(b) W1(b) W1(b + 1) W1(b + 2) W1(b + 3) W1(b + 4) W1(b + 5) W1(b + 6) W1(b + 7)
+        W8(0) W8(8) W8(16) W8(24)
+#undef W8
+#undef W1
+        default: wait_vmcnt<32>(); break;   // (stricter than asked: n > 32 never occurs with G <= 8, LEADT <= 2)
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int IH, int JH, int NB, bool DENSE>
+__global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGArgs p) {
+    CG_HOT_UNPACK;
+    using Geo = BigGeo<BM, BN, WGM, WGN, IH, JH, NB>;
+    constexpr int MI = Geo::MI, NJ = Geo::NJ, IHS = Geo::IHS, JS0 = Geo::JS0, JS1 = Geo::JS1, PH = Geo::PH;
+    constexpr int AR = Geo::AR, WRF = Geo::WRF, WR = Geo::WR, G = Geo::G, LEADT = Geo::LEADT;
+    constexpr int WMT = Geo::WMT, WNT = Geo::WNT, APR = Geo::APR, WP0 = Geo::WP0;
+    constexpr int A_BYTES = Geo::A_BYTES, ST_BYTES = Geo::ST_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int grp = wave >> 2;   // waves w and w + 4 share a SIMD: the two halves are the two waves of every SIMD
+    const int r = lane & 15, g = lane >> 4;
+    MSD_STAMP(0);
+    const int tile = xcd_remap(blockIdx.x, hot_tiles_m * hot_tiles_n);
+    const int tdiv = hot_m_fast ? hot_tiles_m : hot_tiles_n;
+    const int tq = udiv_magic(tile, tdiv, hot_mg_tdiv), tr = tile - tq * tdiv;
+    const int tile_n = hot_m_fast ? tq : tr;
+    const int tile_m = hot_m_fast ? tr : tq;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kt_begin = blockIdx.y * hot_nk_per;
+    const int kt_end = min(hot_nk, kt_begin + hot_nk_per);
+    const int nkt = kt_end - kt_begin;
+
+    // ---- loader coordinates.  A round k: LDS row (need order) 64 k + 8 wave + (lane >> 3), chunk position lane & 7 ----------------
+    const int cpos = lane & 7, lr8 = lane >> 3;
+    // swizzled SOURCE chunk in bytes; the same for every full round: (row >> 1) & 7 with row = 64 k + 8 wave + lr8
+    const uint32_t asrc2 = (uint32_t)((cpos ^ ((4 * wave + (lane >> 4)) & 7)) * 16);
+    const char* zero = reinterpret_cast<const char*>(g_zero_page) + cpos * 16;
+    const int Hl = p.upsample ? 2 * p.h_in : p.h_in;
+    const int Wl = p.upsample ? 2 * p.w_in : p.w_in;
+    // general form: st0 = pixel index of the row's tap (0, 0) (may be negative at the image border), st1 = 9-bit mask of the taps that
+    // lie inside the image; upsampling convs: st0 = the sample's first pixel, st1 = (ay + 2) | (ax + 2) << 16 (0: row past M).
+    // DENSE: st0 / st1 = byte offsets of the row from a0 / a1.
+    int st0[AR], st1[AR];
+#pragma unroll
+    for (int k = 0; k < AR; ++k) {
+        const int q = 64 * k + 8 * wave + lr8;                     // need-order row
+        const int part = q / APR, rem = q - part * APR;
+        const int wmr = rem / (IHS * 16), rr = rem - wmr * (IHS * 16);
+        const int m = m0 + wmr * WMT + part * (IHS * 16) + rr;
+        if constexpr (DENSE) {
+            const uint32_t mc = (uint32_t)min(m, hot_M - 1);       // rows past M re-read the last row: never stored
+            st0[k] = (int)(mc * (uint32_t)hot_c0 * 2u + asrc2);
+            st1[k] = (int)(mc * (uint32_t)hot_c1 * 2u + asrc2);
+        } else if (m < hot_M) {
+            const int b = udiv_magic(m, p.hw_out, p.mg_hw);
+            const int remp = m - b * p.hw_out;
+            const int y = udiv_magic(remp, p.w_out, p.mg_w);
+            const int x = remp - y * p.w_out;
+            const int ay = y * p.stride - p.pad, ax = x * p.stride - p.pad;
+            if (p.upsample) {
+                st0[k] = b * p.h_in * p.w_in;
+                st1[k] = (ay + 2) | ((ax + 2) << 16);
+            } else {
+                st0[k] = b * p.h_in * p.w_in + ay * p.w_in + ax;
+                int mask = 0;
+                if (p.ksize == 3) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int ky = t / 3, kx = t - ky * 3;
+                        if ((unsigned)(ay + ky) < (unsigned)Hl && (unsigned)(ax + kx) < (unsigned)Wl) mask |= 1 << t;
+                    }
+                } else {
+                    mask = ((unsigned)ay < (unsigned)Hl && (unsigned)ax < (unsigned)Wl) ? 1 : 0;
+                }
+                st1[k] = mask;
+            }
+        } else {
+            st0[k] = 0;
+            st1[k] = 0;   // no tap valid (upsampling form: ay = ax = -2, every tap outside the image)
+        }
+    }
+    // W round k: row 64 k + 8 wave + lr8 of the W region (the half round: 64 k + 4 wave + lr8, lanes < 32)
+    uint32_t woff[WR];
+#pragma unroll
+    for (int k = 0; k < WR; ++k) {
+        const bool half = k >= WRF;
+        const int q = 64 * k + (half ? 4 : 8) * wave + lr8;
+        const int part = (JS1 > 0 && q >= WP0) ? 1 : 0;
+        const int qq = q - part * WP0;
+        const int js = part ? JS1 : JS0;
+        const int wnr = qq / (js * 16), rr = qq - wnr * (js * 16);
+        const int n = n0 + wnr * WNT + part * JS0 * 16 + rr;
+        woff[k] = (uint32_t)min(n, hot_N - 1) * hot_w_rs + (uint32_t)((cpos ^ ((q >> 1) & 7)) * 16);   // columns past N re-read the last weight row (never stored)
+    }
+    const uint32_t ldsA_wave = lds0 + (uint32_t)(wave * 8) * 128u;
+    const uint32_t ldsW_wave = lds0 + A_BYTES + (uint32_t)(wave * 8) * 128u;
+    const uint32_t ldsWh_wave = lds0 + A_BYTES + (uint32_t)(wave * 4) * 128u;
+
+    // per-K-tile scalars of the A loader (wave-uniform), prepared when the tile's first round is issued
+    struct TileA { uint64_t sb; uint32_t csrc2; int dpix; int tapbit; int ky, kx; bool first; uint32_t cb; int kt; };
+    auto tile_a = [&](int kt) {
+        TileA t;
+        t.kt = kt;
+        if constexpr (DENSE) {
+            const int c = kt * 64;
+            t.first = c < hot_c0;
+            t.cb = (uint32_t)(t.first ? c : c - hot_c0) * 2u;
+            t.sb = 0; t.csrc2 = 0; t.dpix = 0; t.tapbit = 0; t.ky = t.kx = 0;
+            return t;
+        } else {
+            const bool extra = kt >= p.nk_main;   // shortcut operand (a2 | a3) read at the output pixel: the centre / only tap
+            const int tap = extra ? 0 : udiv_magic(kt, p.nkc, p.mg_nkc);
+            const int c = extra ? (kt - p.nk_main) * 64 : (kt - tap * p.nkc) * 64;
+            const int ky = p.ksize == 3 ? (extra ? p.pad : (tap * 11) >> 5) : 0;
+            const int kx = p.ksize == 3 ? (extra ? p.pad : tap - ky * 3) : 0;
+            const int cA = extra ? p.c2 : hot_c0;
+            const bool first = c < cA;
+            const uint64_t base = (uint64_t)(extra ? (first ? p.a2 : p.a3) : (first ? hot_a0 : hot_a1));
+            const int csrc = first ? cA : (extra ? p.K - p.nk_main * 64 - p.c2 : hot_c1), coff = first ? c : c - cA;
+            t.sb = base + (uint64_t)(uint32_t)(coff * 2);
+            t.csrc2 = (uint32_t)csrc * 2u;
+            t.dpix = ky * p.w_in + kx;
+            t.tapbit = 1 << (ky * 3 + kx);
+            t.ky = ky; t.kx = kx; t.first = first; t.cb = 0;
+            return t;
+        }
+    };
+    auto issue_a_round = [&](const TileA& t, int k, uint32_t lds_dst) {
+        if constexpr (DENSE) {
+            dma16s(t.first ? hot_a0 : hot_a1, (uint32_t)(t.first ? st0[k] : st1[k]) + t.cb, lds_dst);
+        } else {
+            uint32_t off;
+            bool ok;
+            if (p.upsample) {   // (wave-uniform) nearest x2: the tap's pixel is ((y - 1 + ky) >> 1, (x - 1 + kx) >> 1), not row + constant
+                int iy = (st1[k] & 0xFFFF) - 2 + t.ky, ix = (int)((uint32_t)st1[k] >> 16) - 2 + t.kx;
+                ok = ((unsigned)iy < (unsigned)Hl) && ((unsigned)ix < (unsigned)Wl);
+                iy = min(max(iy, 0), Hl - 1) >> 1; ix = min(max(ix, 0), Wl - 1) >> 1;
+                off = (uint32_t)(st0[k] + iy * p.w_in + ix) * t.csrc2 + asrc2;
+            } else {            // pixel = row's tap-(0,0) pixel + a per-tile constant; validity = one bit of the row's mask
+                ok = (st1[k] & t.tapbit) != 0;
+                off = __umul24((uint32_t)(st0[k] + t.dpix), t.csrc2) + asrc2;   // (pixels < 2^24, row bytes < 2^24: host-checked; a masked lane may hold garbage)
+            }
+            const uint64_t a = ok ? t.sb + off : (uint64_t)zero;
+            dma16(reinterpret_cast<const void*>(a), lds_dst);
+        }
+    };
+    // one round of the need-order sequence (S compile-time) of K tile described by `t` into buffer `ib`
+    auto issue_seq = [&](auto S_, const TileA& t, int ib) {
+        constexpr int S = decltype(S_)::value;
+        constexpr int k = Geo::seq_round(S);
+        const uint32_t boff = (uint32_t)ib * (uint32_t)ST_BYTES + (uint32_t)k * 8192u;
+        if constexpr (Geo::seq_is_a(S)) {
+            issue_a_round(t, k, ldsA_wave + boff);
+        } else if constexpr (k < WRF) {
+            dma16s(hot_w, woff[k] + (uint32_t)t.kt * hot_w_ks, ldsW_wave + boff);
+        } else {
+            dma16sm(hot_w, woff[k] + (uint32_t)t.kt * hot_w_ks, ldsWh_wave + boff, 0xFFFFFFFFull);
+        }
+    };
+    auto issue_range = [&](auto LO_, auto HI_, const TileA& t, int ib) {   // rounds [LO, HI) of the sequence
+        constexpr int LO = decltype(LO_)::value, HI = decltype(HI_)::value;
+        if constexpr (LO < HI) {
+            issue_seq(std::integral_constant<int, LO>{}, t, ib);
+            if constexpr (LO + 1 < HI) issue_seq(std::integral_constant<int, LO + 1>{}, t, ib);
+            if constexpr (LO + 2 < HI) issue_seq(std::integral_constant<int, LO + 2>{}, t, ib);
+            if constexpr (LO + 3 < HI) issue_seq(std::integral_constant<int, LO + 3>{}, t, ib);
+            if constexpr (LO + 4 < HI) issue_seq(std::integral_constant<int, LO + 4>{}, t, ib);
+            if constexpr (LO + 5 < HI) issue_seq(std::integral_constant<int, LO + 5>{}, t, ib);
+            if constexpr (LO + 6 < HI) issue_seq(std::integral_constant<int, LO + 6>{}, t, ib);
+            if constexpr (LO + 7 < HI) issue_seq(std::integral_constant<int, LO + 7>{}, t, ib);
+            static_assert(HI - LO <= 8, "rounds per call");
+        }
+    };
+
+    // ---- accumulators in chunks of EC row fragments (the epilogue runs once per chunk: conv_wreg.hip) ---------------------------
+    constexpr int EC = MI < 4 ? MI : 4, EH = MI / EC;
+    f32x4 acc[EH][NJ][EC];
+#pragma unroll
+    for (int h = 0; h < EH; ++h)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < EC; ++i) acc[h][j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: K tiles 0 .. LEADT - 1 whole ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int tt = 0; tt < LEADT; ++tt)
+        if (tt < nkt) {
+            const TileA t = tile_a(kt_begin + tt);
+            issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, G>{}, t, tt);
+        }
+    MSD_STAMP(1);
+    big_wait((G - 1 - Geo::need(0)) + (min(nkt, LEADT) - 1) * G);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // the second half runs one slot behind the first
+
+    // ---- fragment addressing ----------------------------------------------------------------------------------------------------
+    const int rw = cg_wrow(r);   // weight rows enter the MFMA in the order 0-3, 8-11, 4-7, 12-15 (cg_epilogue)
+    const int aoffs = (wm * IHS * 16 + r) * 128;                       // + part * APR * 128 + ii * 2048
+    const int woffs0 = A_BYTES + (wn * JS0 * 16 + rw) * 128;           // + jj * 2048
+    const int woffs1 = A_BYTES + (WP0 + wn * JS1 * 16 + rw) * 128;
+    const int ca0 = ((g ^ (r >> 1)) << 4), ca1 = (((4 + g) ^ (r >> 1)) << 4);
+    const int cw0 = ((g ^ (rw >> 1)) << 4), cw1 = (((4 + g) ^ (rw >> 1)) << 4);
+    bf16x8 af[2][IHS], wf0[2][JS0], wf1[2][JS1 > 0 ? JS1 : 1];
+    auto load_a = [&](int part, int rb) {
+        const char* b = smem + rb * ST_BYTES + aoffs + part * (APR * 128);
+#pragma unroll
+        for (int ii = 0; ii < IHS; ++ii) {
+            af[0][ii] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + ca0);
+            af[1][ii] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + ca1);
+        }
+    };
+    auto load_w0 = [&](int rb) {
+        const char* b = smem + rb * ST_BYTES + woffs0;
+#pragma unroll
+        for (int jj = 0; jj < JS0; ++jj) {
+            wf0[0][jj] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + cw0);
+            wf0[1][jj] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + cw1);
+        }
+    };
+    auto load_w1 = [&](int rb) {
+        const char* b = smem + rb * ST_BYTES + woffs1;
+#pragma unroll
+        for (int jj = 0; jj < JS1; ++jj) {
+            wf1[0][jj] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + cw0);
+            wf1[1][jj] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + cw1);
+        }
+    };
+    // MFMAs of (A part ip, W part jp): ks outermost, so every accumulator sees the K tile's two halves in ascending order
+    auto mfma_part = [&](auto IP_, auto JP_) {
+        constexpr int ip = decltype(IP_)::value, jp = decltype(JP_)::value;
+        constexpr int js = jp ? JS1 : JS0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < js; ++jj)
+#pragma unroll
+                for (int ii = 0; ii < IHS; ++ii) {
+                    const int i = ip * IHS + ii, j = jp * JS0 + jj;
+                    if constexpr (jp == 0)
+                        acc[i / EC][j][i % EC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[ks][jj], af[ks][ii], acc[i / EC][j][i % EC], 0, 0, 0);
+                    else
+                        acc[i / EC][j][i % EC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[ks][jj], af[ks][ii], acc[i / EC][j][i % EC], 0, 0, 0);
+                }
+    };
+
+    // ---- K loop -------------------------------------------------------------------------------------------------------------------
+    int rb = 0, ib = LEADT % NB;   // buffer being read / being filled
+    TileA nt = tile_a(kt_begin + min(LEADT, max(nkt - 1, 0)));
+    auto phase = [&](auto P_, int rem) {
+        constexpr int P = decltype(P_)::value;
+        // -- LOAD slot: this phase's fragments, then this phase's share of the K tile LEADT ahead, then the wait for the next phase's rounds
+        if constexpr (JH == 2) {
+            if constexpr (P == 0) { load_w0(rb); load_a(0, rb); }
+            if constexpr (P == 1) load_w1(rb);
+            if constexpr (P == 2) load_a(1, rb);
+        } else {
+            if constexpr (P == 0) load_w0(rb);
+            load_a(P, rb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (rem >= LEADT) {
+            constexpr int LO = P == 0 ? 0 : Geo::cum(P - 1), HI = Geo::cum(P);
+            issue_range(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, nt, ib);
+        }
+        if constexpr (P + 1 < PH) {
+            if constexpr (Geo::need(P + 1) > Geo::need(P)) {
+                constexpr int base = G - 1 - Geo::need(P + 1);
+                if (rem >= LEADT) wait_vmcnt<(base + (LEADT - 1) * G + Geo::cum(P) < 63 ? base + (LEADT - 1) * G + Geo::cum(P) : 63)>();
+                else big_wait(base + rem * G);
+            }
+        } else {
+            constexpr int base = G - 1 - Geo::need(0);
+            if (rem >= LEADT) wait_vmcnt<(base + (LEADT - 1) * G < 63 ? base + (LEADT - 1) * G : 63)>();
+            else if (rem >= 1) big_wait(base + (rem - 1) * G);
+        }
+        __builtin_amdgcn_s_barrier();
+        // -- MFMA slot
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (JH == 2) {
+            if constexpr (P == 0) mfma_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            if constexpr (P == 1) mfma_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            if constexpr (P == 2) mfma_part(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            if constexpr (P == 3) mfma_part(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        } else {
+            mfma_part(std::integral_constant<int, P>{}, std::integral_constant<int, 0>{});
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int t = 0; t < nkt; ++t) {
+        const int rem = nkt - 1 - t;
+#ifdef MSD_STAMPS
+        if (t == 0) MSD_STAMP(2);
+        if (t == (nkt >> 1)) MSD_STAMP(5);
+#endif
+        phase(std::integral_constant<int, 0>{}, rem);
+        phase(std::integral_constant<int, 1>{}, rem);
+        if constexpr (PH == 4) {
+            phase(std::integral_constant<int, 2>{}, rem);
+            phase(std::integral_constant<int, 3>{}, rem);
+        }
+        if (++rb == NB) rb = 0;
+        if (++ib == NB) ib = 0;
+        if (rem > LEADT) nt = tile_a(kt_begin + t + 1 + LEADT);
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // (the first half's extra barrier: both halves have passed the same number)
+    MSD_STAMP(3);
+
+    auto epilogue_chunk = [&](auto H_) {   // (explicit instances: left as a loop, hipcc does not unroll it and acc[h] goes to scratch)
+        constexpr int h = decltype(H_)::value;
+        int mrow[EC];
+#pragma unroll
+        for (int i = 0; i < EC; ++i) mrow[i] = m0 + wm * WMT + (h * EC + i) * 16;
+        cg_epilogue<EC, NJ, false, DENSE>(p, acc[h], mrow, n0 + wn * WNT, r, g, reinterpret_cast<float*>(smem), wn, WGN, wm * WMT + h * EC * 16, BM, tile_n);
+    };
+    epilogue_chunk(std::integral_constant<int, 0>{});
+    if constexpr (EH > 1) epilogue_chunk(std::integral_constant<int, 1>{});
+    static_assert(EH <= 2, "epilogue chunks");
+#ifdef MSD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
+    MSD_STAMP(4);
+#endif
+}
+
+// ---- configurations: (BM, BN, WGM, WGN, IH, JH, NB, code); selected by tile_m = 5000 + BM, tile_n = BN, stages = code --------------
+#ifndef MSD_BIG_CFGS
+#define MSD_BIG_CFGS(X)          \
+    X(256, 256, 2, 4, 2, 2, 2, 0) \
+    X(256, 160, 4, 2, 2, 2, 3, 0) \
+    X(256, 160, 4, 2, 2, 1, 3, 1) \
+    X(256, 160, 4, 2, 2, 2, 2, 2) \
+    X(256, 128, 4, 2, 2, 1, 3, 0) \
+    X(256, 128, 4, 2, 2, 2, 3, 1) \
+    X(128, 256, 2, 4, 2, 1, 3, 0) \
+    X(128, 256, 2, 4, 2, 2, 3, 1)
+#endif
+
+constexpr int big_lds(int bm, int bn, int nb) { return nb * (bm + bn) * 128; }   // = BigGeo<...>::LDS
+
+static bool g_big_attr_done = false;
+static int msd_conv_big_init() {
+    if (g_big_attr_done) return MSD_OK;
+    hipError_t e = hipSuccess;
+#define X(bm, bn, wgm, wgn, ih, jh, nb, code)                                                                                 \
+    if (e == hipSuccess)                                                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<bm, bn, wgm, wgn, ih, jh, nb, false>),         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big_lds(bm, bn, nb));         \
+    if (e == hipSuccess)                                                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<bm, bn, wgm, wgn, ih, jh, nb, true>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big_lds(bm, bn, nb));
+    MSD_BIG_CFGS(X)
+#undef X
+    if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_big): %s", hipGetErrorString(e));
+    g_big_attr_done = true;
+    return MSD_OK;
+}
+
+// 16-column blocks per wave of the configuration a (bm, bn, code) request selects, 0 if it is not built
+int msd_conv_big_nj(int bm, int bn, int code) {
+#define X(bm_, bn_, wgm, wgn, ih, jh, nb, code_) if (bm == bm_ && bn == bn_ && code == code_) return bn_ / wgn / 16;
+    MSD_BIG_CFGS(X)
+#undef X
+    return 0;
+}
+
+// Launch for an already validated argument block (tiles_m / tiles_n / m_fast / nk_per / nslices set by msd_conv_gemm).
+int msd_conv_big_launch(const CGArgs& a, int bm, int bn, int code, int slices, bool dense, hipStream_t stream) {
+    int rc = msd_conv_big_init();
+    if (rc) return rc;
+    const dim3 grid(a.tiles_m * a.tiles_n, slices);
+#define X(bm_, bn_, wgm, wgn, ih, jh, nb, code_)                                                                              \
+    if (bm == bm_ && bn == bn_ && code == code_) {                                                                            \
+        if (dense)                                                                                                            \
+            hipLaunchKernelGGL((conv_big_kernel<bm_, bn_, wgm, wgn, ih, jh, nb, true>), grid, dim3(512),                      \
+                               big_lds(bm_, bn_, nb), stream, CG_HOT_ARGS(a), a);                        \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((conv_big_kernel<bm_, bn_, wgm, wgn, ih, jh, nb, false>), grid, dim3(512),                     \
+                               big_lds(bm_, bn_, nb), stream, CG_HOT_ARGS(a), a);                        \
+        return MSD_OK;                                                                                                        \
+    }
+    MSD_BIG_CFGS(X)
+#undef X
+    MSD_FAIL(MSD_E_UNSUPPORTED, "conv_big: no %d x %d configuration with code %d", bm, bn, code);
+}

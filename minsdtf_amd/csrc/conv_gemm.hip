@@ -344,6 +344,12 @@ constexpr int NUM_TILE_CFGS = 19;
 int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int variant, int slices, hipStream_t stream);
 int msd_conv_wreg_nj(int bm, int bn, int stages);   // 16-column blocks per wave of a built configuration, 0: not built
 int msd_conv_wreg_launch(const CGArgs& a, int bm, int bn, int stages, int slices, bool dense, hipStream_t stream);
+int msd_conv_big_nj(int bm, int bn, int code);      // conv_big.hip: 16-column blocks per wave of a built configuration, 0: not built
+int msd_conv_big_launch(const CGArgs& a, int bm, int bn, int code, int slices, bool dense, hipStream_t stream);
+// tile_m ranges of the forms (one predicate each, mirrored by minsdtf_amd/tuning.py form_of): [1000, 3000) halo tiles, [3000, 4000)
+// row panels, [4000, 5000) wreg, [5000, 6000) big; anything from 6000 up is refused
+static inline bool cg_is_wreg(int tile_m) { return tile_m >= 4000 && tile_m < 5000; }
+static inline bool cg_is_big(int tile_m) { return tile_m >= 5000 && tile_m < 6000; }
 bool msd_conv_rowpanel_eligible(const CGArgs& a, int rows, int wg_cols);
 int msd_conv_rowpanel_launch(CGArgs a, int rows, int wg_cols, hipStream_t stream);
 
@@ -371,7 +377,7 @@ int msd_conv_gemm_init() {
 
 // tile width the launch will use (same rules as msd_conv_gemm below)
 static int cg_effective_bn(const MsdConvGemm* q) {
-    if (q->tile_m >= 4000) return q->tile_n;      // wreg form (conv_wreg.hip): the request IS the tile (the launch fails if it is not built)
+    if (cg_is_wreg(q->tile_m) || cg_is_big(q->tile_m)) return q->tile_n;   // wreg / big form: the request IS the tile (the launch fails if it is not built)
     int bn = q->tile_m >= 3000 ? 64 : q->tile_n;   // (a row-panel request that is not eligible runs on the 128x64 tile)
     if (bn == 0) bn = (q->N % 128 == 0 || q->N > 1024) ? 128 : 64;
     if (bn == 80 && q->act == MSD_ACT_GEGLU) bn = 64;
@@ -481,7 +487,16 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     // (again, with the shortcut channels in K: the weight loader's 32-bit byte offsets are n * K * 2 + ...)
     if ((long long)a.N * a.K * 2 >= (1ll << 32) - 4096) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: an operand of 4 GB or more");
     if (q->w_layout < 0 || q->w_layout > 2) MSD_FAIL(MSD_E_ARG, "conv_gemm: w_layout %d", q->w_layout);
-    const bool wreg = q->tile_m >= 4000 && q->tile_m < 5000;
+    if (q->tile_m >= 6000 || q->tile_m < 0) MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_m %d names no kernel form", q->tile_m);
+    const bool wreg = cg_is_wreg(q->tile_m), big = cg_is_big(q->tile_m);
+    if (big) {
+        if (!msd_conv_big_nj(q->tile_m - 5000, q->tile_n, q->stages))
+            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: no big-tile configuration %d x %d code %d", q->tile_m - 5000, q->tile_n, q->stages);
+        if (q->ln_out) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the big-tile form has no LayerNorm-producer epilogue (ln_out)");
+        // its general loader forms pixel * row bytes with a 24-bit multiply
+        if ((long long)q->batch * q->h_in * q->w_in >= (1ll << 24) || (long long)(q->c0 > q->c1 ? q->c0 : q->c1) * 2 >= (1ll << 24))
+            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: big-tile form needs fewer than 2^24 input pixels");
+    }
     if (wreg != (q->w_layout == 2))
         MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_m %d with w_layout %d (the fragment-major weight image, w_layout 2, is read by the wreg form, tile_m 4000 + rows, and by nothing else)",
                  q->tile_m, q->w_layout);
@@ -498,7 +513,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         if (!msd_aligned16(q->ln_colsum) || (((uintptr_t)q->ln_in) & 7u)) MSD_FAIL(MSD_E_ALIGN, "conv_gemm: ln_in / ln_colsum alignment");
     }
     if (q->ln_out) {
-        if (q->split_mode || q->out_dtype != MSD_OUT_BF16 || q->act != MSD_ACT_NONE || q->ksize != 1 || (q->tile_m >= 1000 && q->tile_m < 3000) ||
+        if (q->split_mode || q->out_dtype != MSD_OUT_BF16 || q->act != MSD_ACT_NONE || q->ksize != 1 || (q->tile_m >= 1000 && q->tile_m < 3000) || big ||
             (((uintptr_t)q->ln_out) & 7u))
             MSD_FAIL(MSD_E_ARG, "conv_gemm: ln_out needs a plain 1x1 launch with a bf16 output and no activation");
         if (q->ln_out_slots != msd_conv_gemm_ln_slots(q))
@@ -576,6 +591,28 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
             MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold, GEGLU and the q|k|v^T split run on the 1x1 / Dense form only");
         if (!cg_hot_ok(a)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: tile / K-tile / channel counts beyond the packed launch arguments (K tiles, channels < 65536; row tiles < 2^23; column tiles < 256)");
         rc = msd_conv_wreg_launch(a, wbm, wbn, q->stages, slices, dense, stream);
+        if (rc) return rc;
+        MSD_CHECK_LAUNCH();
+        if (slices > 1) {
+            launch_finalize(a, slices, stream);
+            MSD_CHECK_LAUNCH();
+        }
+        return MSD_OK;
+    }
+    if (big) {   // 256-row macro tiles, staggered half-workgroups: conv_big.hip
+        const int bbm = q->tile_m - 5000, bbn = q->tile_n;
+        if (q->act == MSD_ACT_GEGLU && (msd_conv_big_nj(bbm, bbn, q->stages) % 2)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: GEGLU needs x | gate fragment pairs per wave");
+        a.tiles_m = (a.M + bbm - 1) / bbm;
+        a.tiles_n = (a.N + bbn - 1) / bbn;
+        a.m_fast = (a.N > a.M) ? 1 : 0;
+        a.mg_tdiv = udiv_magic_of(a.m_fast ? a.tiles_m : a.tiles_n);
+        a.mg_tps = a.mg_tx = 0;
+        const bool needs_dense = q->ln_in || q->act == MSD_ACT_GEGLU || q->split_mode;
+        const bool dense = !q->rowvec && !q->a2 && q->ksize == 1 && q->stride == 1 && !q->upsample && q->h_out == q->h_in && q->w_out == q->w_in;
+        if (needs_dense && !dense)
+            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold, GEGLU and the q|k|v^T split run on the 1x1 / Dense form only");
+        if (!cg_hot_ok(a)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: tile / K-tile / channel counts beyond the packed launch arguments (K tiles, channels < 65536; row tiles < 2^23; column tiles < 256)");
+        rc = msd_conv_big_launch(a, bbm, bbn, q->stages, slices, dense, stream);
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
         if (slices > 1) {

@@ -384,10 +384,19 @@ class Emitter:
             wn = wkey or name
             kw.update(w=self.W[wn + ".lnw"], bias=self.W[wn + ".lnb"], ln_in=ln_in[0], ln_in_slots=ln_in[1],
                       ln_colsum=self.W[wn + ".lncs"], ln_eps=EPS, w_layout=self.w_layout(wn + ".lnw"))
-        if tile_m >= 4000:   # wreg form (csrc/conv_wreg.hip): reads the fragment-major image of the same matrix
+        if tuning.is_wreg(tile_m):   # wreg form (csrc/conv_wreg.hip): reads the fragment-major image of the same matrix
             wk = (wkey or name) + (".lnw" if ln_in is not None else ".w")
             frag = getattr(self.W, "fragment_major", None)
-            kw.update(w=frag(wk) if frag is not None else self.W[wk], w_layout=2)
+            if frag is not None:
+                kw.update(w=frag(wk), w_layout=2)
+            elif self.W[wk] is None:    # the tuner's tensor-less shape walk
+                kw.update(w=None, w_layout=2)
+            else:                       # a plain mapping of real tensors: convert, never re-label a row / chunk-major matrix
+                from . import packing
+                src = self.W[wk]
+                if self.w_layout(wk) == 1:
+                    raise ValueError(f"{wk}: the wreg form needs packing.PackedWeights (a chunk-major tensor in a plain mapping cannot be re-laid)")
+                kw.update(w=packing.fragment_major(src), w_layout=2)
         if ln_out:
             slots = ops.conv_gemm_ln_slots(N=N, tile_n=tile_n, tile_m=tile_m, ksize=ksize, act=act)
             out.ln = (p.alloc(M * slots * 8), slots)

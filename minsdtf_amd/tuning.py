@@ -44,6 +44,29 @@ WREG_TILES = ((4128, 128, 3), (4128, 128, 4), (4128, 64, 3), (4128, 64, 4), (406
               (4256, 128, 13), (4256, 128, 14))
 
 
+# (5000 + rows per workgroup, columns per workgroup, configuration code): big form (csrc/conv_big.hip) for M >= 8192 — 8 waves in two
+# half-workgroups one barrier apart; the tile kernel's K walk and epilogue (same bits), no LayerNorm-producer epilogue
+BIG_TILES = ((5256, 256, 0), (5256, 160, 0), (5256, 160, 1), (5256, 160, 2), (5256, 128, 0), (5256, 128, 1), (5128, 256, 0), (5128, 256, 1))
+BIG_MIN_ROWS = 4096   # rows (M) below which the tuner does not try the big form
+
+
+def is_halo(tile_m: int) -> bool:
+    return 1000 <= tile_m < 3000
+
+
+def is_rowpanel(tile_m: int) -> bool:
+    return 3000 <= tile_m < 4000
+
+
+def is_wreg(tile_m: int) -> bool:
+    """The same ranges as csrc/conv_gemm.hip cg_is_wreg / cg_is_big (tile_m >= 6000 is refused there)."""
+    return 4000 <= tile_m < 5000
+
+
+def is_big(tile_m: int) -> bool:
+    return 5000 <= tile_m < 6000
+
+
 # (rows per workgroup + 3000, columns per workgroup): row-panel Dense kernel (csrc/conv_rowpanel.hip) for the LayerNorm-
 # consumer GEMMs of the transformer blocks (K = 320 / 640, 128 rows per workgroup)
 ROWPANEL_ROWS = {320: (3128,), 640: (3128,)}
@@ -118,11 +141,13 @@ def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int, ln_produce
     the column tile (how the moments are grouped into partials).  `ln_producer` = False for the shapes that never do — the
     GEGLU and q|k|v projections, the keys ending in "n": their column tile orders nothing.  The table holds ONE class per
     layer shape for all batch sizes (tools/tune_conv.py)."""
-    if 3000 <= tile_m < 4000:   # row-panel Dense kernel: the tile kernel's bits (a launch it cannot take runs on the 128x64 tile)
+    if tile_m >= 6000:
+        raise ValueError(f"tile_m {tile_m} names no kernel form")
+    if is_rowpanel(tile_m):   # row-panel Dense kernel: the tile kernel's bits (a launch it cannot take runs on the 128x64 tile)
         return (False, splitk, 64 if (ksize == 1 and ln_producer) else 0)
-    if tile_m >= 4000:   # wreg form: the tile kernel's K walk and epilogue, partials per column tile as requested
+    if is_wreg(tile_m) or is_big(tile_m):   # wreg / big form: the tile kernel's K walk and epilogue, partials per column tile as requested
         return (False, splitk, tile_n if (ksize == 1 and ln_producer) else 0)
-    return (tile_m >= 1000, splitk, tile_n if (ksize == 1 and ln_producer) else 0)
+    return (is_halo(tile_m), splitk, tile_n if (ksize == 1 and ln_producer) else 0)
 
 
 def key_is_ln_producer(key: str) -> bool:

@@ -152,6 +152,28 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=3, H=12, W=20, c0=64, N=192, ks=3, tile_m=4256, tile_n=128, stages=13, same_as=(256, 128, 0)),         # ragged M (720) and N
     dict(B=2, H=16, W=16, c0=128, c1=64, N=128, ks=3, tile_m=4256, tile_n=128, stages=14, upsample=True, same_as=(256, 128, 0)),
     dict(B=3, H=12, W=20, c0=128, N=320, ks=1, tile_m=4256, tile_n=128, stages=13, same_as=(128, 128, 0)),        # dense loader
+    # big form (conv_big.hip: tile_m 5000 + rows; 8 waves in two half-workgroups one barrier apart, operands by LDS-DMA in need order):
+    # the tile kernel's K walk and epilogue, so the tile kernel's bits
+    dict(B=2, H=16, W=16, c0=64, N=256, ks=3, tile_m=5256, tile_n=256, stages=0, same_as=(128, 128, 0)),           # 2 row tiles, 9 K tiles
+    dict(B=3, H=12, W=20, c0=128, N=272, ks=3, tile_m=5256, tile_n=256, stages=0, same_as=(128, 128, 0)),          # ragged M (720) and N (17 blocks), 18 K tiles
+    dict(B=3, H=12, W=20, c0=128, N=320, ks=3, tile_m=5256, tile_n=160, stages=0, same_as=(128, 64, 0)),           # 256 x 160, quadrant phases, 3 buffers
+    dict(B=3, H=12, W=20, c0=128, N=320, ks=3, tile_m=5256, tile_n=160, stages=1, same_as=(128, 64, 0)),           # ... row-half phases
+    dict(B=3, H=12, W=20, c0=128, N=320, ks=3, tile_m=5256, tile_n=160, stages=2, same_as=(128, 64, 0)),           # ... quadrants, 2 buffers
+    dict(B=2, H=16, W=16, c0=64, c1=64, N=100, ks=3, tile_m=5256, tile_n=128, stages=0, same_as=(128, 64, 0)),     # concat, N < the column tile
+    dict(B=2, H=16, W=16, c0=64, c1=64, N=192, ks=3, tile_m=5256, tile_n=128, stages=1, same_as=(128, 64, 0)),
+    dict(B=2, H=12, W=20, c0=64, N=272, ks=3, tile_m=5128, tile_n=256, stages=0, same_as=(128, 128, 0)),           # 128-row tiles, ragged M (480)
+    dict(B=2, H=12, W=20, c0=64, N=512, ks=3, tile_m=5128, tile_n=256, stages=1, same_as=(128, 128, 0)),
+    dict(B=2, H=16, W=16, c0=64, N=256, ks=1, tile_m=5256, tile_n=256, stages=0, same_as=(128, 128, 0)),           # dense loader, ONE K tile (nothing to prefetch)
+    dict(B=2, H=16, W=16, c0=128, N=320, ks=1, tile_m=5256, tile_n=160, stages=0, same_as=(128, 64, 0)),           # two K tiles = the prologue's whole lead (3 buffers)
+    dict(B=2, H=16, W=16, c0=64, c1=128, N=320, ks=1, tile_m=5256, tile_n=160, stages=1, same_as=(128, 64, 0)),    # 1x1 over a concat, 3 K tiles
+    dict(B=3, H=12, W=20, c0=320, N=320, ks=1, tile_m=5256, tile_n=256, stages=0, same_as=(128, 64, 0)),           # 5 K tiles, 2 buffers, ragged M and N
+    dict(B=2, H=32, W=32, c0=64, N=160, ks=3, stride=2, tile_m=5256, tile_n=160, stages=0, same_as=(128, 64, 0)),  # stride 2
+    dict(B=2, H=32, W=32, c0=64, N=128, ks=3, stride=2, asym=True, tile_m=5256, tile_n=128, stages=0, same_as=(128, 64, 0)),
+    dict(B=2, H=8, W=8, c0=128, c1=64, N=256, ks=3, upsample=True, tile_m=5256, tile_n=256, stages=0, same_as=(128, 128, 0)),   # nearest x2 in the loader
+    dict(B=2, H=8, W=8, c0=128, N=160, ks=3, upsample=True, tile_m=5256, tile_n=160, stages=1, same_as=(128, 64, 0)),
+    dict(B=2, H=16, W=16, c0=64, N=256, ks=3, f32out=True, act="silu", tile_m=5256, tile_n=256, stages=0, same_as=(128, 128, 0)),
+    dict(B=2, H=16, W=16, c0=128, N=320, ks=3, splitk=3, tile_m=5256, tile_n=160, stages=0, same_as=(128, 64, 0)), # 18 K tiles in 3 slices of 6
+    dict(B=2, H=16, W=16, c0=64, N=256, ks=3, splitk=4, tile_m=5256, tile_n=256, stages=0, same_as=(128, 128, 0)), # slices of 3, 3, 3, 0 -> 3 slices
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing
@@ -191,7 +213,7 @@ def test_conv_gemm(gpu, case):
     ws = torch.empty(max(1, splitk * M * N), dtype=torch.float32, device=d)
     step = torch.tensor([2], dtype=torch.int32, device=d)
     biasd, tembd, residd = bias.to(d), temb.to(d), resid.to(torch.bfloat16).to(d)   # (a Call holds addresses, not tensors)
-    wreg = case.get("tile_m", 0) >= 4000
+    wreg = 4000 <= case.get("tile_m", 0) < 5000
     wmain = packing.fragment_major(wp) if wreg else wp
     call = ops.conv_gemm(a0=x0d, a1=x1d, c1=c1, w=wmain, w_layout=2 if wreg else 0, out=out, batch=B, h_in=H, w_in=W, c0=c0, N=N, ksize=ks, stride=stride,
                          upsample=ups, bias=biasd, rowvec=tembd, rv_step_stride=B * N, rv_batch_stride=N,
@@ -232,6 +254,9 @@ def test_conv_gemm(gpu, case):
     dict(B=2, H=8, W=8, c=192, cx0=128, cx1=64, N=192, ks=3, splitk=3, tile_m=4128, tile_n=128, stages=3),   # wreg form (fragment-major weights)
     dict(B=1, H=16, W=16, c=64, cx0=64, cx1=0, N=320, ks=3, tile_m=4064, tile_n=256, stages=4),
     dict(B=2, H=8, W=8, c=192, cx0=128, cx1=64, N=192, ks=3, splitk=3, tile_m=4064, tile_n=128, stages=23),   # ... two K tiles per stage
+    dict(B=3, H=12, W=20, c=128, cx0=64, cx1=0, N=320, ks=3, tile_m=5256, tile_n=160, stages=0),              # big form, ragged M
+    dict(B=2, H=16, W=16, c=192, cx0=128, cx1=64, N=256, ks=3, splitk=3, tile_m=5256, tile_n=256, stages=0),  # ... shortcut over a concat, split-K across both parts
+    dict(B=2, H=16, W=16, c=64, cx0=128, cx1=0, N=256, ks=1, tile_m=5128, tile_n=256, stages=0),              # ... 1x1 main part
 ])
 def test_conv_gemm_shortcut_operand(gpu, case):
     """conv(h) + conv1x1(x) as one contraction (diffusion_model.py:34-38,50): K = taps of h, then the channels of x."""
@@ -258,7 +283,7 @@ def test_conv_gemm_shortcut_operand(gpu, case):
     from minsdtf_amd import packing
 
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=d)
-    wreg = case.get("tile_m", 0) >= 4000
+    wreg = 4000 <= case.get("tile_m", 0) < 5000
     wmain = packing.fragment_major(wcat) if wreg else wcat
     call = ops.conv_gemm(a0=keep[0], w=wmain, w_layout=2 if wreg else 0, out=out, batch=B, h_in=H, w_in=W, c0=c, N=N, ksize=ks, bias=keep[3],
                          a2=keep[1], c2=cx0, a3=keep[2], c3=cx1, workspace=keep[4], workspace_floats=keep[4].numel(), splitk=sk,
@@ -266,7 +291,8 @@ def test_conv_gemm_shortcut_operand(gpu, case):
     run_calls(call)
     close(out.reshape(B, H, W, N), ref, what=str(case))
     # chunk-major weights on the same tile (wreg: on the tile kernel): storage order / kernel form only, the same bits
-    other = dict(tile_m=64, tile_n=128) if wreg else dict(tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0))
+    big = case.get("tile_m", 0) >= 5000
+    other = dict(tile_m=64, tile_n=128) if (wreg or big) else dict(tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0))
     out2 = torch.full_like(out, float("nan"))
     run_calls(ops.conv_gemm(a0=keep[0], w=packing.chunk_major(wcat), w_layout=1, out=out2, batch=B, h_in=H, w_in=W, c0=c, N=N, ksize=ks,
                             bias=keep[3], a2=keep[1], c2=cx0, a3=keep[2], c3=cx1, workspace=keep[4], workspace_floats=keep[4].numel(),
@@ -274,12 +300,14 @@ def test_conv_gemm_shortcut_operand(gpu, case):
     assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "weight layout / kernel form changed the bits"
 
 
-@pytest.mark.parametrize("tile", [(0, 0), (128, 160), (64, 128), (3128, 320), (4128, 128), (4064, 256)])   # heuristic tile, the 128x160 tile (16x16 level), 64x128, row panels, wreg
+@pytest.mark.parametrize("tile", [(0, 0), (128, 160), (64, 128), (3128, 320), (4128, 128), (4064, 256), (5256, 256), (5128, 256), (5256, 128)])   # heuristic tile, the 128x160 tile (16x16 level), 64x128, row panels, wreg, big
 def test_conv_gemm_geglu(gpu, tile):
     from minsdtf_amd import ops, packing
 
     torch.manual_seed(2)
     M, C = (192, 64) if not 3000 <= tile[0] < 4000 else (200, 320)   # (the row-panel kernel takes K = 320 / 640)
+    if tile[0] >= 5000:
+        M, C = 600, 128   # three ragged 256-row tiles, two K tiles
     x = bf(torch.randn(M, C))
     w = bf(torch.randn(C, 8 * C) / math.sqrt(C))
     b = torch.randn(8 * C) * 0.1
@@ -288,7 +316,7 @@ def test_conv_gemm_geglu(gpu, tile):
     ref = a * 0.5 * gate * (1 + torch.tanh(gate * 0.7978845608 * (1 + 0.044715 * gate ** 2)))
     wp, bp = packing.pack_geglu(w.numpy(), b.numpy(), gpu)
     out = torch.full((M, 4 * C), float("nan"), dtype=torch.bfloat16, device=gpu)
-    wreg = tile[0] >= 4000
+    wreg = 4000 <= tile[0] < 5000
     call = ops.conv_gemm(a0=x.to(torch.bfloat16).to(gpu), w=packing.fragment_major(wp) if wreg else wp, w_layout=2 if wreg else 0, out=out, batch=1,
                          h_in=M, w_in=1, c0=C, N=8 * C, bias=bp, act=ops.ACT_GEGLU, tile_m=tile[0], tile_n=tile[1], stages=3 if wreg else 0)
     run_calls(call)
@@ -329,6 +357,10 @@ def test_conv_gemm_geglu(gpu, tile):
     dict(M=300, C=320, tile=(4128, 64, 23), mode="geglu", ctile=(4064, 128, 23), csame=True, psame=True),  # two K tiles per stage, 5 tiles
     dict(M=136, C=1280, tile=(4064, 64, 24), mode="qkv", ctile=(4064, 256, 23), csame=True, psame=True),
     dict(M=600, C=320, tile=(4256, 128, 13), mode="geglu", ctile=(4256, 128, 14), csame=True),            # 2 x 4 wave grid: producer partials from both wave rows
+    # consumer on the big form (conv_big.hip; it has no producer epilogue): the tile kernel's bits
+    dict(M=600, C=320, tile=(128, 64, 0), mode="geglu", ctile=(5256, 256, 0), csame=True),
+    dict(M=520, C=640, tile=(64, 64, 0), mode="qkv", ctile=(5256, 160, 0), csame=True),                   # q | k | v^T split from 5 blocks per wave
+    dict(M=300, C=320, tile=(128, 80, 0), mode="dense", ctile=(5128, 256, 1), csame=True),
 ])
 def test_conv_gemm_layer_norm_fold(gpu, case):
     """LayerNormalization folded into the GEMMs around it (diffusion_model.py:84-88 + Dense): the producer
@@ -343,7 +375,7 @@ def test_conv_gemm_layer_norm_fold(gpu, case):
     ckw = dict(tile_m=ctm, tile_n=ctn, stages=cstg)
 
     def lay(w, tile_m):   # the weight image a launch reads: fragment-major for the wreg form
-        return dict(w=packing.fragment_major(w), w_layout=2) if tile_m >= 4000 else dict(w=w)
+        return dict(w=packing.fragment_major(w), w_layout=2) if 4000 <= tile_m < 5000 else dict(w=w)
 
     x = bf(torch.randn(M, C))
     res = bf(torch.randn(M, C) * 2 + 0.5)                      # non-zero row means
