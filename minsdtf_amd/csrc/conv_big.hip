@@ -28,9 +28,28 @@
 #include "conv_common.h"
 
 #ifdef MSD_STAMPS
+// (tools/big_stamps.py, `make stamps` library only.)  Beside the workgroup timeline of conv_common.h: waves 0 and 4 (the first wave of
+// either half) sum the shader clock between fixed points of every phase - 0 fragment reads issued, 1 DMAs issued, 2 counted wait
+// passed, 3 barrier passed, 4 MFMAs issued (fragments landed), 5 second barrier passed - rows [workgroup & 1023][half][8].
+static __device__ unsigned long long g_bstamps[1024 * 2 * 8];
 extern "C" MSD_API int msd_debug_stamps_big(unsigned long long* host_out, int count) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count);
 }
+extern "C" MSD_API int msd_debug_phase_stamps_big(unsigned long long* host_out, int count) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * (size_t)count);
+}
+// (stamps 0-3 sit among ds_reads that are still in flight: their values are only read after the lgkmcnt(0) of BSTAMP_END and must stay
+//  in the SGPRs the instruction named - no spill in between; stamps 4-6 wait for themselves: the MFMA slot waits lgkmcnt(0) anyway)
+#define BSTAMP(i) do { if ((i) < 4) asm volatile("s_memtime %0" : "=s"(bst[i]) : : "memory"); else asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bst[i]) : : "memory"); } while (0)
+#define BSTAMP_END()                                                              \
+    do {                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) bsum[i_] += bst[i_ + 1] - bst[i_]; \
+        ++bsum[6];                                                                \
+    } while (0)
+#else
+#define BSTAMP(i)
+#define BSTAMP_END()
 #endif
 
 // ---- geometry of a configuration (all compile-time) --------------------------------------------------------------------------
@@ -61,6 +80,13 @@ struct BigGeo {
     static constexpr int g_of(int p) { return G / PH + (p < G % PH ? 1 : 0); }
     static constexpr int cum(int p) { int c = 0; for (int q = 0; q <= p; ++q) c += g_of(q); return c; }
     static constexpr int issue_phase(int s) { for (int p = 0; p < PH; ++p) if (s < cum(p)) return p; return PH - 1; }
+    // position of A round `s` among the A rounds its phase issues, and the most A rounds any phase issues
+    static constexpr int a_index_in_phase(int s) { int n = 0; for (int q = (issue_phase(s) == 0 ? 0 : cum(issue_phase(s) - 1)); q < s; ++q) n += seq_is_a(q) ? 1 : 0; return n; }
+    static constexpr int max_a_per_phase() {
+        int best = 0;
+        for (int p = 0; p < PH; ++p) { int n = 0; for (int q = (p == 0 ? 0 : cum(p - 1)); q < cum(p); ++q) n += seq_is_a(q) ? 1 : 0; best = n > best ? n : best; }
+        return best;
+    }
     // highest sequence index phase p (or an earlier one) reads
     static constexpr int need(int p) {
         if (JH == 2) return p == 0 ? ARP + (WP0 - 1) / 64 : (p == 1 ? ARP + WR - 1 : G - 1);
@@ -97,9 +123,12 @@ __device__ __forceinline__ void big_wait(int n) {   // s_waitcnt vmcnt(n), n wav
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int IH, int JH, int NB, bool DENSE>
+// LD = loader form: 0 general (tap / padding / stride / concat / shortcut-operand addresses), 1 dense (1x1 / Dense: a row is one pixel's
+// channel vector), 2 general with nearest x2 upsampling (the tap's pixel is not "row + constant": its own address arithmetic)
+template <int BM, int BN, int WGM, int WGN, int IH, int JH, int NB, int LD>
 __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGArgs p) {
     CG_HOT_UNPACK;
+    constexpr bool DENSE = LD == 1, UPS = LD == 2;
     using Geo = BigGeo<BM, BN, WGM, WGN, IH, JH, NB>;
     constexpr int MI = Geo::MI, NJ = Geo::NJ, IHS = Geo::IHS, JS0 = Geo::JS0, JS1 = Geo::JS1, PH = Geo::PH;
     constexpr int AR = Geo::AR, WRF = Geo::WRF, WR = Geo::WR, G = Geo::G, LEADT = Geo::LEADT;
@@ -129,8 +158,8 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
     // swizzled SOURCE chunk in bytes; the same for every full round: (row >> 1) & 7 with row = 64 k + 8 wave + lr8
     const uint32_t asrc2 = (uint32_t)((cpos ^ ((4 * wave + (lane >> 4)) & 7)) * 16);
     const char* zero = reinterpret_cast<const char*>(g_zero_page) + cpos * 16;
-    const int Hl = p.upsample ? 2 * p.h_in : p.h_in;
-    const int Wl = p.upsample ? 2 * p.w_in : p.w_in;
+    const int Hl = UPS ? 2 * p.h_in : p.h_in;
+    const int Wl = UPS ? 2 * p.w_in : p.w_in;
     // general form: st0 = pixel index of the row's tap (0, 0) (may be negative at the image border), st1 = 9-bit mask of the taps that
     // lie inside the image; upsampling convs: st0 = the sample's first pixel, st1 = (ay + 2) | (ax + 2) << 16 (0: row past M).
     // DENSE: st0 / st1 = byte offsets of the row from a0 / a1.
@@ -151,7 +180,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
             const int y = udiv_magic(remp, p.w_out, p.mg_w);
             const int x = remp - y * p.w_out;
             const int ay = y * p.stride - p.pad, ax = x * p.stride - p.pad;
-            if (p.upsample) {
+            if constexpr (UPS) {
                 st0[k] = b * p.h_in * p.w_in;
                 st1[k] = (ay + 2) | ((ax + 2) << 16);
             } else {
@@ -191,7 +220,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
     const uint32_t ldsWh_wave = lds0 + A_BYTES + (uint32_t)(wave * 4) * 128u;
 
     // per-K-tile scalars of the A loader (wave-uniform), prepared when the tile's first round is issued
-    struct TileA { uint64_t sb; uint32_t csrc2; int dpix; int tapbit; int ky, kx; bool first; uint32_t cb; int kt; };
+    struct TileA { uint64_t sb; uint32_t csrc2; int dpix; int tapbit; int ky, kx; bool first; uint32_t cb; int kt; };   // kt: the WEIGHT tile's index
     auto tile_a = [&](int kt) {
         TileA t;
         t.kt = kt;
@@ -203,8 +232,16 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
             return t;
         } else {
             const bool extra = kt >= p.nk_main;   // shortcut operand (a2 | a3) read at the output pixel: the centre / only tap
-            const int tap = extra ? 0 : udiv_magic(kt, p.nkc, p.mg_nkc);
-            const int c = extra ? (kt - p.nk_main) * 64 : (kt - tap * p.nkc) * 64;
+            int tap, cidx;
+            if (p.kmajor) {   // chunk-major walk (3x3, no shortcut operand: host): K step kt = tap kt % 9 of chunk kt / 9
+                cidx = udiv_magic(kt, 9, 0x1C71C71Cu);
+                tap = kt - cidx * 9;
+                t.kt = tap * p.nkc + cidx;   // the weight matrix keeps its (tap, channel) column order
+            } else {
+                tap = extra ? 0 : udiv_magic(kt, p.nkc, p.mg_nkc);
+                cidx = kt - tap * p.nkc;
+            }
+            const int c = extra ? (kt - p.nk_main) * 64 : cidx * 64;
             const int ky = p.ksize == 3 ? (extra ? p.pad : (tap * 11) >> 5) : 0;
             const int kx = p.ksize == 3 ? (extra ? p.pad : tap - ky * 3) : 0;
             const int cA = extra ? p.c2 : hot_c0;
@@ -219,13 +256,15 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
             return t;
         }
     };
-    auto issue_a_round = [&](const TileA& t, int k, uint32_t lds_dst) {
+    // source of A round k of the K tile described by `t`: a 64-bit address (general forms; the zero page for a tap outside the image)
+    // or a 32-bit byte offset from a0 / a1 (dense).  Computed one phase ahead of its DMA, inside the MFMA slot (see `phase`).
+    auto addr_a_round = [&](const TileA& t, int k) -> uint64_t {
         if constexpr (DENSE) {
-            dma16s(t.first ? hot_a0 : hot_a1, (uint32_t)(t.first ? st0[k] : st1[k]) + t.cb, lds_dst);
+            return (uint64_t)((uint32_t)(t.first ? st0[k] : st1[k]) + t.cb);
         } else {
             uint32_t off;
             bool ok;
-            if (p.upsample) {   // (wave-uniform) nearest x2: the tap's pixel is ((y - 1 + ky) >> 1, (x - 1 + kx) >> 1), not row + constant
+            if constexpr (UPS) {   // nearest x2: the tap's pixel is ((y - 1 + ky) >> 1, (x - 1 + kx) >> 1)
                 int iy = (st1[k] & 0xFFFF) - 2 + t.ky, ix = (int)((uint32_t)st1[k] >> 16) - 2 + t.kx;
                 ok = ((unsigned)iy < (unsigned)Hl) && ((unsigned)ix < (unsigned)Wl);
                 iy = min(max(iy, 0), Hl - 1) >> 1; ix = min(max(ix, 0), Wl - 1) >> 1;
@@ -234,36 +273,55 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
                 ok = (st1[k] & t.tapbit) != 0;
                 off = __umul24((uint32_t)(st0[k] + t.dpix), t.csrc2) + asrc2;   // (pixels < 2^24, row bytes < 2^24: host-checked; a masked lane may hold garbage)
             }
-            const uint64_t a = ok ? t.sb + off : (uint64_t)zero;
-            dma16(reinterpret_cast<const void*>(a), lds_dst);
+            // branch-free select (a conditional expression becomes an exec-masked block, which cuts the MFMA slot's basic block in two
+            // and keeps the scheduler from spreading this arithmetic over the MFMA gaps)
+            const uint32_t m32 = ok ? 0xFFFFFFFFu : 0u;
+            const uint64_t m64 = ((uint64_t)m32 << 32) | m32;
+            return ((t.sb + off) & m64) | ((uint64_t)zero & ~m64);
         }
     };
+    auto fire_a_round = [&](const TileA& t, uint64_t a, uint32_t lds_dst) {
+        if constexpr (DENSE) dma16s(t.first ? hot_a0 : hot_a1, (uint32_t)a, lds_dst);
+        else dma16(reinterpret_cast<const void*>(a), lds_dst);
+    };
+    auto issue_a_round = [&](const TileA& t, int k, uint32_t lds_dst) { fire_a_round(t, addr_a_round(t, k), lds_dst); };
     // one round of the need-order sequence (S compile-time) of K tile described by `t` into buffer `ib`
-    auto issue_seq = [&](auto S_, const TileA& t, int ib) {
+    constexpr int PA = Geo::max_a_per_phase();   // A rounds a phase issues at most: their sources are prepared one phase ahead
+    uint64_t pa[PA > 0 ? PA : 1];
+    auto issue_seq = [&](auto S_, const TileA& t, int ib, auto PRE_) {   // PRE: the A sources were prepared (the loop; the prologue computes them in place)
         constexpr int S = decltype(S_)::value;
         constexpr int k = Geo::seq_round(S);
         const uint32_t boff = (uint32_t)ib * (uint32_t)ST_BYTES + (uint32_t)k * 8192u;
         if constexpr (Geo::seq_is_a(S)) {
-            issue_a_round(t, k, ldsA_wave + boff);
+            if constexpr (decltype(PRE_)::value) fire_a_round(t, pa[Geo::a_index_in_phase(S)], ldsA_wave + boff);
+            else issue_a_round(t, k, ldsA_wave + boff);
         } else if constexpr (k < WRF) {
             dma16s(hot_w, woff[k] + (uint32_t)t.kt * hot_w_ks, ldsW_wave + boff);
         } else {
             dma16sm(hot_w, woff[k] + (uint32_t)t.kt * hot_w_ks, ldsWh_wave + boff, 0xFFFFFFFFull);
         }
     };
-    auto issue_range = [&](auto LO_, auto HI_, const TileA& t, int ib) {   // rounds [LO, HI) of the sequence
+    auto issue_range = [&](auto LO_, auto HI_, const TileA& t, int ib, auto PRE_) {   // rounds [LO, HI) of the sequence
         constexpr int LO = decltype(LO_)::value, HI = decltype(HI_)::value;
         if constexpr (LO < HI) {
-            issue_seq(std::integral_constant<int, LO>{}, t, ib);
-            if constexpr (LO + 1 < HI) issue_seq(std::integral_constant<int, LO + 1>{}, t, ib);
-            if constexpr (LO + 2 < HI) issue_seq(std::integral_constant<int, LO + 2>{}, t, ib);
-            if constexpr (LO + 3 < HI) issue_seq(std::integral_constant<int, LO + 3>{}, t, ib);
-            if constexpr (LO + 4 < HI) issue_seq(std::integral_constant<int, LO + 4>{}, t, ib);
-            if constexpr (LO + 5 < HI) issue_seq(std::integral_constant<int, LO + 5>{}, t, ib);
-            if constexpr (LO + 6 < HI) issue_seq(std::integral_constant<int, LO + 6>{}, t, ib);
-            if constexpr (LO + 7 < HI) issue_seq(std::integral_constant<int, LO + 7>{}, t, ib);
+            issue_seq(std::integral_constant<int, LO>{}, t, ib, PRE_);
+            if constexpr (LO + 1 < HI) issue_seq(std::integral_constant<int, LO + 1>{}, t, ib, PRE_);
+            if constexpr (LO + 2 < HI) issue_seq(std::integral_constant<int, LO + 2>{}, t, ib, PRE_);
+            if constexpr (LO + 3 < HI) issue_seq(std::integral_constant<int, LO + 3>{}, t, ib, PRE_);
+            if constexpr (LO + 4 < HI) issue_seq(std::integral_constant<int, LO + 4>{}, t, ib, PRE_);
+            if constexpr (LO + 5 < HI) issue_seq(std::integral_constant<int, LO + 5>{}, t, ib, PRE_);
+            if constexpr (LO + 6 < HI) issue_seq(std::integral_constant<int, LO + 6>{}, t, ib, PRE_);
+            if constexpr (LO + 7 < HI) issue_seq(std::integral_constant<int, LO + 7>{}, t, ib, PRE_);
             static_assert(HI - LO <= 8, "rounds per call");
         }
+    };
+    // sources of the A rounds phase Q issues, for the K tile described by `t`
+    auto prep_phase = [&](auto Q_, const TileA& t) {
+        constexpr int Q = decltype(Q_)::value;
+        constexpr int LO = Q == 0 ? 0 : Geo::cum(Q - 1), HI = Geo::cum(Q);
+#pragma unroll
+        for (int sq = LO; sq < HI; ++sq)
+            if (Geo::seq_is_a(sq)) pa[Geo::a_index_in_phase(sq)] = addr_a_round(t, Geo::seq_round(sq));
     };
 
     // ---- accumulators in chunks of EC row fragments (the epilogue runs once per chunk: conv_wreg.hip) ---------------------------
@@ -281,7 +339,7 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
     for (int tt = 0; tt < LEADT; ++tt)
         if (tt < nkt) {
             const TileA t = tile_a(kt_begin + tt);
-            issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, G>{}, t, tt);
+            issue_range(std::integral_constant<int, 0>{}, std::integral_constant<int, G>{}, t, tt, std::false_type{});
         }
     MSD_STAMP(1);
     big_wait((G - 1 - Geo::need(0)) + (min(nkt, LEADT) - 1) * G);
@@ -339,10 +397,15 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
     };
 
     // ---- K loop -------------------------------------------------------------------------------------------------------------------
+#ifdef MSD_STAMPS
+    unsigned long long bst[7], bsum[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     int rb = 0, ib = LEADT % NB;   // buffer being read / being filled
-    TileA nt = tile_a(kt_begin + min(LEADT, max(nkt - 1, 0)));
+    TileA nt = tile_a(kt_begin + min(LEADT, max(nkt - 1, 0))), ntn = nt;   // K tile being issued / the next one
+    prep_phase(std::integral_constant<int, 0>{}, nt);
     auto phase = [&](auto P_, int rem) {
         constexpr int P = decltype(P_)::value;
+        BSTAMP(0);
         // -- LOAD slot: this phase's fragments, then this phase's share of the K tile LEADT ahead, then the wait for the next phase's rounds
         if constexpr (JH == 2) {
             if constexpr (P == 0) { load_w0(rb); load_a(0, rb); }
@@ -353,10 +416,12 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
             load_a(P, rb);
         }
         __builtin_amdgcn_sched_barrier(0);
+        BSTAMP(1);
         if (rem >= LEADT) {
             constexpr int LO = P == 0 ? 0 : Geo::cum(P - 1), HI = Geo::cum(P);
-            issue_range(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, nt, ib);
+            issue_range(std::integral_constant<int, LO>{}, std::integral_constant<int, HI>{}, nt, ib, std::true_type{});
         }
+        BSTAMP(2);
         if constexpr (P + 1 < PH) {
             if constexpr (Geo::need(P + 1) > Geo::need(P)) {
                 constexpr int base = G - 1 - Geo::need(P + 1);
@@ -368,10 +433,15 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
             if (rem >= LEADT) wait_vmcnt<(base + (LEADT - 1) * G < 63 ? base + (LEADT - 1) * G : 63)>();
             else if (rem >= 1) big_wait(base + (rem - 1) * G);
         }
+        BSTAMP(3);
         __builtin_amdgcn_s_barrier();
-        // -- MFMA slot
+        BSTAMP(4);
+        // -- MFMA slot.  The address arithmetic of the NEXT phase's A rounds rides in it: a MFMA holds the issue port 8 cycles of its 16, the
+        //    VALU work of two sources fits the gaps, and the LOAD slot (which the other half's MFMAs wait behind) is left with bare DMAs
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (P + 1 < PH) prep_phase(std::integral_constant<int, P + 1>{}, nt);
+        else prep_phase(std::integral_constant<int, 0>{}, ntn);
         if constexpr (JH == 2) {
             if constexpr (P == 0) mfma_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
             if constexpr (P == 1) mfma_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -380,12 +450,26 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
         } else {
             mfma_part(std::integral_constant<int, P>{}, std::integral_constant<int, 0>{});
         }
+        // interleave: one MFMA, then up to two of the address-arithmetic VALU instructions (left alone hipcc puts all of them in front
+        // of the first MFMA, where they cost their full issue time with the matrix pipe idle)
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+        }
+        // (pin: the sources are "used" here, or hipcc sinks their arithmetic into the LOAD slot's issue block, next to the DMAs)
+#pragma unroll
+        for (int q = 0; q < (PA > 0 ? PA : 1); ++q) asm volatile("" : "+v"(pa[q]));
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        BSTAMP(5);
         __builtin_amdgcn_s_barrier();
+        BSTAMP(6);
+        BSTAMP_END();
     };
     for (int t = 0; t < nkt; ++t) {
         const int rem = nkt - 1 - t;
+        if (rem > LEADT) ntn = tile_a(kt_begin + t + 1 + LEADT);
 #ifdef MSD_STAMPS
         if (t == 0) MSD_STAMP(2);
         if (t == (nkt >> 1)) MSD_STAMP(5);
@@ -398,10 +482,17 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
         }
         if (++rb == NB) rb = 0;
         if (++ib == NB) ib = 0;
-        if (rem > LEADT) nt = tile_a(kt_begin + t + 1 + LEADT);
+        nt = ntn;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // (the first half's extra barrier: both halves have passed the same number)
     MSD_STAMP(3);
+#ifdef MSD_STAMPS
+    if ((wave & 3) == 0 && lane == 0) {
+        unsigned long long* dst = g_bstamps + ((size_t)(blockIdx.x & 1023) * 2 + grp) * 8;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dst[i] = bsum[i];
+    }
+#endif
 
     auto epilogue_chunk = [&](auto H_) {   // (explicit instances: left as a loop, hipcc does not unroll it and acc[h] goes to scratch)
         constexpr int h = decltype(H_)::value;
@@ -440,10 +531,13 @@ static int msd_conv_big_init() {
     hipError_t e = hipSuccess;
 #define X(bm, bn, wgm, wgn, ih, jh, nb, code)                                                                                 \
     if (e == hipSuccess)                                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<bm, bn, wgm, wgn, ih, jh, nb, false>),         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, big_lds(bm, bn, nb));         \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<bm, bn, wgm, wgn, ih, jh, nb, 0>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big_lds(bm, bn, nb));                             \
     if (e == hipSuccess)                                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<bm, bn, wgm, wgn, ih, jh, nb, true>),          \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<bm, bn, wgm, wgn, ih, jh, nb, 1>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, big_lds(bm, bn, nb));                             \
+    if (e == hipSuccess)                                                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<bm, bn, wgm, wgn, ih, jh, nb, 2>),             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, big_lds(bm, bn, nb));
     MSD_BIG_CFGS(X)
 #undef X
@@ -468,11 +562,14 @@ int msd_conv_big_launch(const CGArgs& a, int bm, int bn, int code, int slices, b
 #define X(bm_, bn_, wgm, wgn, ih, jh, nb, code_)                                                                              \
     if (bm == bm_ && bn == bn_ && code == code_) {                                                                            \
         if (dense)                                                                                                            \
-            hipLaunchKernelGGL((conv_big_kernel<bm_, bn_, wgm, wgn, ih, jh, nb, true>), grid, dim3(512),                      \
-                               big_lds(bm_, bn_, nb), stream, CG_HOT_ARGS(a), a);                        \
+            hipLaunchKernelGGL((conv_big_kernel<bm_, bn_, wgm, wgn, ih, jh, nb, 1>), grid, dim3(512),                         \
+                               big_lds(bm_, bn_, nb), stream, CG_HOT_ARGS(a), a);                                             \
+        else if (a.upsample)                                                                                                  \
+            hipLaunchKernelGGL((conv_big_kernel<bm_, bn_, wgm, wgn, ih, jh, nb, 2>), grid, dim3(512),                         \
+                               big_lds(bm_, bn_, nb), stream, CG_HOT_ARGS(a), a);                                             \
         else                                                                                                                  \
-            hipLaunchKernelGGL((conv_big_kernel<bm_, bn_, wgm, wgn, ih, jh, nb, false>), grid, dim3(512),                     \
-                               big_lds(bm_, bn_, nb), stream, CG_HOT_ARGS(a), a);                        \
+            hipLaunchKernelGGL((conv_big_kernel<bm_, bn_, wgm, wgn, ih, jh, nb, 0>), grid, dim3(512),                         \
+                               big_lds(bm_, bn_, nb), stream, CG_HOT_ARGS(a), a);                                             \
         return MSD_OK;                                                                                                        \
     }
     MSD_BIG_CFGS(X)

@@ -20,6 +20,7 @@ struct CGArgs {
     const float* ln_in; const float* ln_colsum; float* ln_out;   // LayerNorm fold (minsdtf_hip.h)
     int ln_in_slots, ln_out_slots;
     float ln_eps, ln_inv_k;
+    int kmajor;            // conv_big.hip: 1 = walk K chunk-major (for every 64-channel chunk its 9 taps: the halo-tile kernel's order, so its bits), 0 = tap-major
     uint32_t w_rs, w_ks;   // weight addressing in bytes: row (output column) stride, K-chunk stride ([N][K]: 2K, 128; chunk-major: 128, 128 N)
 };
 

@@ -489,9 +489,13 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     if (q->w_layout < 0 || q->w_layout > 2) MSD_FAIL(MSD_E_ARG, "conv_gemm: w_layout %d", q->w_layout);
     if (q->tile_m >= 6000 || q->tile_m < 0) MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_m %d names no kernel form", q->tile_m);
     const bool wreg = cg_is_wreg(q->tile_m), big = cg_is_big(q->tile_m);
+    // big form, stages code + 10: chunk-major K walk (the halo-tile kernel's order and numerics class)
+    const bool big_km = big && q->stages >= 10;
+    const int big_code = big_km ? q->stages - 10 : q->stages;
     if (big) {
-        if (!msd_conv_big_nj(q->tile_m - 5000, q->tile_n, q->stages))
-            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: no big-tile configuration %d x %d code %d", q->tile_m - 5000, q->tile_n, q->stages);
+        if (big_km && (q->ksize != 3 || q->a2)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the chunk-major walk of the big-tile form is for 3x3 convs without a shortcut operand");
+        if (!msd_conv_big_nj(q->tile_m - 5000, q->tile_n, big_code))
+            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: no big-tile configuration %d x %d code %d", q->tile_m - 5000, q->tile_n, big_code);
         if (q->ln_out) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the big-tile form has no LayerNorm-producer epilogue (ln_out)");
         // its general loader forms pixel * row bytes with a 24-bit multiply
         if ((long long)q->batch * q->h_in * q->w_in >= (1ll << 24) || (long long)(q->c0 > q->c1 ? q->c0 : q->c1) * 2 >= (1ll << 24))
@@ -534,15 +538,17 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
                         (th == 8 || th == 16) && (q->h_in % th) == 0;
         if (ok) halo_th = th;
     }
-    if (halo_th) {  // split-K is over 64-channel chunks (each = 9 K steps)
+    a.kmajor = big_km ? 1 : 0;
+    if (halo_th || big_km) {  // split-K is over 64-channel chunks (each = 9 K steps)
         if (splitk > a.nkc) splitk = a.nkc;
         a.nk_per = (a.nkc + splitk - 1) / splitk;
     } else {
         if (splitk > a.nk) splitk = a.nk;
         a.nk_per = (a.nk + splitk - 1) / splitk;
     }
-    const int slices = halo_th ? (a.nkc + a.nk_per - 1) / a.nk_per : (a.nk + a.nk_per - 1) / a.nk_per;
+    const int slices = (halo_th || big_km) ? (a.nkc + a.nk_per - 1) / a.nk_per : (a.nk + a.nk_per - 1) / a.nk_per;
     a.nslices = slices;
+    if (big_km) a.nk_per *= 9;   // (the big form counts K tiles, nine per chunk)
     if (slices > 1) {
         if (q->split_mode || q->act == MSD_ACT_GEGLU) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: split-K needs plain mode");
         if ((long long)a.M * a.N / 4 >= (1ll << 31)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: split-K output too large");
@@ -601,7 +607,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     }
     if (big) {   // 256-row macro tiles, staggered half-workgroups: conv_big.hip
         const int bbm = q->tile_m - 5000, bbn = q->tile_n;
-        if (q->act == MSD_ACT_GEGLU && (msd_conv_big_nj(bbm, bbn, q->stages) % 2)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: GEGLU needs x | gate fragment pairs per wave");
+        if (q->act == MSD_ACT_GEGLU && (msd_conv_big_nj(bbm, bbn, big_code) % 2)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: GEGLU needs x | gate fragment pairs per wave");
         a.tiles_m = (a.M + bbm - 1) / bbm;
         a.tiles_n = (a.N + bbn - 1) / bbn;
         a.m_fast = (a.N > a.M) ? 1 : 0;
@@ -612,7 +618,7 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         if (needs_dense && !dense)
             MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold, GEGLU and the q|k|v^T split run on the 1x1 / Dense form only");
         if (!cg_hot_ok(a)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: tile / K-tile / channel counts beyond the packed launch arguments (K tiles, channels < 65536; row tiles < 2^23; column tiles < 256)");
-        rc = msd_conv_big_launch(a, bbm, bbn, q->stages, slices, dense, stream);
+        rc = msd_conv_big_launch(a, bbm, bbn, big_code, slices, dense, stream);
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
         if (slices > 1) {

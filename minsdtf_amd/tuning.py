@@ -47,6 +47,8 @@ WREG_TILES = ((4128, 128, 3), (4128, 128, 4), (4128, 64, 3), (4128, 64, 4), (406
 # (5000 + rows per workgroup, columns per workgroup, configuration code): big form (csrc/conv_big.hip) for M >= 8192 — 8 waves in two
 # half-workgroups one barrier apart; the tile kernel's K walk and epilogue (same bits), no LayerNorm-producer epilogue
 BIG_TILES = ((5256, 256, 0), (5256, 160, 0), (5256, 160, 1), (5256, 160, 2), (5256, 128, 0), (5256, 128, 1), (5128, 256, 0), (5128, 256, 1))
+# ... code + 10: the chunk-major K walk = the halo-tile kernel's order of sums (3x3, stride 1, no upsampling, no shortcut operand): its numerics class
+BIG_TILES_CHUNK_MAJOR = ((5256, 256, 10), (5256, 160, 10), (5256, 160, 11), (5256, 128, 10), (5128, 256, 10))
 BIG_MIN_ROWS = 4096   # rows (M) below which the tuner does not try the big form
 
 
@@ -126,6 +128,12 @@ def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_spli
             ent = fam[min(fam, key=lambda b: (abs(b - batch) / (b + batch), b))]
             if int(ent[0]) == 256 and M < 1024:   # (the 256-row tile needs >= 1024 rows)
                 ent = [128] + list(ent[1:])
+            if is_big(int(ent[0])) and M < BIG_MIN_ROWS:   # (a 256-row macro tile on a small launch: the same class on small tiles)
+                stg = int(ent[3]) if len(ent) > 4 else 0
+                if stg >= 10 and w_in % 16 == 0 and h_in % 8 == 0:
+                    ent = [1128, 80 if N % 80 == 0 else 64, int(ent[2]), 0, 0.0]
+                elif stg < 10:
+                    ent = [128, 128 if N % 128 == 0 else 64, int(ent[2]), 0, 0.0]
     if ent is not None:
         bm, bn, sk = int(ent[0]), int(ent[1]), int(ent[2])
         stages = int(ent[3]) if len(ent) > 4 else 0   # [bm, bn, splitk, stages, us] (older tables: [bm, bn, splitk, us])
@@ -135,7 +143,7 @@ def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_spli
     return heuristic(M // max(1, batch), N, nk, allow_split)
 
 
-def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int, ln_producer: bool = True) -> Tuple[bool, int, int]:
+def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int, ln_producer: bool = True, stages: int = 0) -> Tuple[bool, int, int]:
     """The part of a launch configuration that decides the ORDER of the layer's fp32 sums: kernel family (halo-tile 3x3
     kernel: chunk-major K walk), split-K slices, and for the 1x1 / dense layers that may PRODUCE LayerNorm-fold row moments
     the column tile (how the moments are grouped into partials).  `ln_producer` = False for the shapes that never do — the
@@ -143,6 +151,8 @@ def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int, ln_produce
     layer shape for all batch sizes (tools/tune_conv.py)."""
     if tile_m >= 6000:
         raise ValueError(f"tile_m {tile_m} names no kernel form")
+    if is_big(tile_m) and stages >= 10:   # big form walking K chunk-major: the halo-tile kernel's sums
+        return (True, splitk, 0)
     if is_rowpanel(tile_m):   # row-panel Dense kernel: the tile kernel's bits (a launch it cannot take runs on the 128x64 tile)
         return (False, splitk, 64 if (ksize == 1 and ln_producer) else 0)
     if is_wreg(tile_m) or is_big(tile_m):   # wreg / big form: the tile kernel's K walk and epilogue, partials per column tile as requested

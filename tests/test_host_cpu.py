@@ -364,7 +364,7 @@ def test_tuning_table_pins_one_numerics_class_per_layer():
     for key, ent in table.items():
         b, rest = key.split("x", 1)
         ks = int(re.search(r"k(\d)s", rest).group(1))
-        fams.setdefault(rest, set()).add(tuning.numerics_class(ks, int(ent[0]), int(ent[1]), int(ent[2]), tuning.key_is_ln_producer(key)))
+        fams.setdefault(rest, set()).add(tuning.numerics_class(ks, int(ent[0]), int(ent[1]), int(ent[2]), tuning.key_is_ln_producer(key), stages=int(ent[3]) if len(ent) > 4 else 0))
     bad = {k: v for k, v in fams.items() if len(v) != 1}
     assert not bad, bad
     # an unmeasured batch lands in the same class as the measured ones; an unknown layer falls back per SAMPLE

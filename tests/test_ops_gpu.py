@@ -174,6 +174,13 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=2, H=16, W=16, c0=64, N=256, ks=3, f32out=True, act="silu", tile_m=5256, tile_n=256, stages=0, same_as=(128, 128, 0)),
     dict(B=2, H=16, W=16, c0=128, N=320, ks=3, splitk=3, tile_m=5256, tile_n=160, stages=0, same_as=(128, 64, 0)), # 18 K tiles in 3 slices of 6
     dict(B=2, H=16, W=16, c0=64, N=256, ks=3, splitk=4, tile_m=5256, tile_n=256, stages=0, same_as=(128, 128, 0)), # slices of 3, 3, 3, 0 -> 3 slices
+    # ... walking K chunk-major (stages code + 10): the HALO-tile kernel's order of sums, so that kernel's bits
+    dict(B=2, H=16, W=16, c0=192, N=128, ks=3, tile_m=5256, tile_n=128, stages=10, same_as=(1128, 64, 0)),
+    dict(B=1, H=16, W=32, c0=64, c1=64, N=100, ks=3, tile_m=5256, tile_n=128, stages=10, same_as=(1128, 64, 0)),        # one chunk per tensor of the concat, ragged N
+    dict(B=3, H=16, W=16, c0=320, N=320, ks=3, tile_m=5256, tile_n=160, stages=11, same_as=(1128, 80, 0)),              # 45 K steps
+    dict(B=2, H=16, W=16, c0=256, N=256, ks=3, splitk=2, tile_m=5256, tile_n=256, stages=10, same_as=(1128, 64, 0)),    # split over chunks: 2 + 2
+    dict(B=2, H=16, W=16, c0=320, N=160, ks=3, splitk=2, tile_m=5256, tile_n=160, stages=10, same_as=(1128, 80, 0)),    # 5 chunks in slices of 3 + 2
+    dict(B=2, H=16, W=16, c0=128, c1=192, N=256, ks=3, tile_m=5128, tile_n=256, stages=10, same_as=(1256, 128, 0)),     # concat boundary inside the walk
 ])
 def test_conv_gemm(gpu, case):
     from minsdtf_amd import ops, packing

@@ -34,7 +34,7 @@ def main():
     lib = _lib.load()
     lib.msd_init()
     lib.msd_set_option(b"conv_dense", args.dense)
-    for fn in (lib.msd_debug_stamps, lib.msd_debug_stamps_halo, lib.msd_debug_stamps_wreg):
+    for fn in (lib.msd_debug_stamps, lib.msd_debug_stamps_halo, lib.msd_debug_stamps_wreg, lib.msd_debug_stamps_big, lib.msd_debug_phase_stamps_big):
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_int]
     dev = torch.device("cuda:0")
@@ -55,7 +55,8 @@ def main():
         res = torch.randn(M, N, device=dev).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32)
-        wreg = tm >= 4000   # wreg form: tile 4000 + rows, fragment-major weights
+        wreg = 4000 <= tm < 5000   # wreg form: tile 4000 + rows, fragment-major weights
+        big = tm >= 5000           # big form (conv_big.hip): tile 5000 + rows
         if wreg:
             from minsdtf_amd import packing
 
@@ -70,7 +71,7 @@ def main():
         bm = (tm % 1000) if tm >= 1000 else tm
         nwg = ((M + bm - 1) // bm) * ((N + tn - 1) // tn) * sk
         buf = np.zeros(16 * 8192, np.uint64)
-        rc = (lib.msd_debug_stamps_halo if halo else lib.msd_debug_stamps_wreg if wreg else lib.msd_debug_stamps)(buf.ctypes.data, buf.size)
+        rc = (lib.msd_debug_stamps_halo if halo else lib.msd_debug_stamps_wreg if wreg else lib.msd_debug_stamps_big if big else lib.msd_debug_stamps)(buf.ctypes.data, buf.size)
         assert rc == 0, rc
         t = buf.reshape(8192, 16)[:min(nwg, 8192)].astype(np.int64)
         t0 = t[:, 0].min()
@@ -98,6 +99,21 @@ def main():
             print(f"   one K step: ds_read + DMA issue     {pct(t[:, 13] - t[:, 12])}")
             print(f"   one K step: fragments landed        {pct(t[:, 14] - t[:, 13])}")
             print(f"   one K step: MFMAs issued + retired  {pct(t[:, 15] - t[:, 14])}")
+        if big:   # shader-clock sums per phase of waves 0 / 4 (the first wave of either half-workgroup)
+            pb = np.zeros(1024 * 2 * 8, np.uint64)
+            assert lib.msd_debug_phase_stamps_big(pb.ctypes.data, pb.size) == 0
+            pr = pb.reshape(1024, 2, 8)[:min(nwg, 1024)].astype(np.float64)
+            names = ("fragment reads issued", "DMAs issued", "counted wait", "barrier 1", "MFMAs issued", "barrier 2")
+            for hh in (0, 1):
+                nph = pr[:, hh, 6]
+                ok = nph > 0
+                tot = 0.0
+                line = []
+                for i in range(6):
+                    v = (pr[ok, hh, i] / nph[ok]).mean()
+                    tot += v
+                    line.append(f"{names[i]} {v:6.0f}")
+                print(f"   half {hh}: cycles per phase: " + " | ".join(line) + f" | sum {tot:6.0f}  ({nph[ok].mean():.0f} phases)")
         print(f"   workgroup lifetime                   {pct(t[:, 4] - t[:, 0])}")
         print(f"   exit time after first entry          {pct(t[:, 4] - t0)}")
         print(f"   kernel span {us(t[:, 4].max() - t0):.2f} us; per K tile in the loop {us(np.median(t[:, 3] - t[:, 2])) / max(1, nk - 1):.3f} us",

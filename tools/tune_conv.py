@@ -109,7 +109,7 @@ def wreg_nj(bm, bn, stg):
     return bn // 16 // waves_n
 
 
-def tune_one(shape, iters=10):
+def tune_one(shape, iters=10, only=None, sks_only=None):
     from minsdtf_amd import ops, tuning
 
     batch, h_in, w_in, cin, N, ks, stride, ups, allow_split, cx = shape
@@ -136,10 +136,19 @@ def tune_one(shape, iters=10):
         cands += [(rows, cols, 0) for rows in tuning.ROWPANEL_ROWS[cin] for cols in tuning.ROWPANEL_COLS if N % cols == 0]
     if N % 16 == 0 and not os.environ.get("MSD_TUNE_NO_WREG"):   # wreg form (fragment-major weights straight to registers)
         cands += [t for t in tuning.WREG_TILES if not (t[1] > 64 and N <= 64)]
+    # big form (256-row macro tiles): not for the LayerNorm-producer Dense layers (K = N, 1x1: it has no ln_out epilogue)
+    if M >= tuning.BIG_MIN_ROWS and not (ks == 1 and allow_split and cin == N and not cx) and not os.environ.get("MSD_TUNE_NO_BIG"):
+        cands += [t for t in tuning.BIG_TILES if not (t[1] == 160 and N % 160) and not (t[1] > 128 and N <= 128)]
+        if ks == 3 and stride == 1 and not ups and not cx:   # ... walking K chunk-major: the halo-tile kernel's class
+            cands += [t for t in tuning.BIG_TILES_CHUNK_MAJOR if not (t[1] == 160 and N % 160) and not (t[1] > 128 and N <= 128)]
+    if only is not None:
+        cands = [t for t in cands if only(t)]
     frag = None
     for (bm, bn, stg) in cands:
-        if bm >= 4000 and allow_split is False and wreg_nj(bm, bn, stg) % 2:
+        if 4000 <= bm < 5000 and allow_split is False and wreg_nj(bm, bn, stg) % 2:
             continue   # (the 'n' shapes include GEGLU, which pairs the two blocks of a wave)
+        if bm >= 5000 and allow_split is False and bn == 160:
+            continue   # (5 blocks per wave: no x | gate pairs)
         if bm < 3000:
             if bm == 256 and M < 1024:
                 continue
@@ -154,18 +163,20 @@ def tune_one(shape, iters=10):
             # candidates from the PER-SAMPLE shape, so every batch of a layer is measured on the same set of slice counts
             bme = bm % 1000 if bm >= 1000 else bm
             tiles = ((M // batch + bme - 1) // bme) * ((N + bn - 1) // bn)
-            kmax = (cin // 64) if 1000 <= bm < 3000 else nk // 4   # the halo kernel splits over 64-channel chunks
+            kmax = (cin // 64) if (1000 <= bm < 3000 or (bm >= 5000 and stg >= 10)) else nk // 4   # the halo kernel (and the chunk-major big form) split over 64-channel chunks
             sks += [s for s in (2, 3, 4, 6, 8, 12, 16) if s <= kmax and tiles * s <= 2048 and tiles < 512]
+        if sks_only is not None:
+            sks = [s for s in sks_only if s == 1 or allow_split]
         for sk in sks:
             wsf = torch.empty(max(1, sk * M * N), device=dev, dtype=torch.float32) if sk > 1 else None
-            if bm >= 4000 and frag is None:
+            if 4000 <= bm < 5000 and frag is None:
                 from minsdtf_amd import packing
 
                 frag = [packing.fragment_major(w) for w in ws_]
             calls = [ops.conv_gemm(a0=x, w=w, out=out, batch=batch, h_in=h_in, w_in=w_in, c0=cin, N=N, ksize=ks, stride=stride,
                                    upsample=ups, bias=bias, workspace=wsf, workspace_floats=0 if wsf is None else wsf.numel(),
-                                   splitk=sk, tile_m=bm, tile_n=bn, stages=stg, a2=xx, c2=cx, w_layout=2 if bm >= 4000 else 0)
-                     for w in (frag if bm >= 4000 else ws_)]
+                                   splitk=sk, tile_m=bm, tile_n=bn, stages=stg, a2=xx, c2=cx, w_layout=2 if 4000 <= bm < 5000 else 0)
+                     for w in (frag if 4000 <= bm < 5000 else ws_)]
             for c in calls[:2]:
                 c(st.cuda_stream)
             torch.cuda.synchronize()
@@ -186,11 +197,11 @@ def tune_one(shape, iters=10):
 BATCH_WEIGHT = {1: 1.0, 2: 4.0, 4: 1.5, 8: 2.0}   # fused cond+uncond batch: 2 = the headline batch-1 run, 8 = 4 images per GPU
 
 
-def numerics_class(shape, bm, bn, sk):
+def numerics_class(shape, bm, bn, sk, stg=0):
     """What of a configuration changes the order of the fp32 sums (see the module docstring)."""
     from minsdtf_amd import tuning
 
-    return tuning.numerics_class(shape[5], bm, bn, sk, ln_producer=bool(shape[8]))   # (shape[8] = allow_split: False for GEGLU / q|k|v)
+    return tuning.numerics_class(shape[5], bm, bn, sk, ln_producer=bool(shape[8]), stages=stg)   # (shape[8] = allow_split: False for GEGLU / q|k|v)
 
 
 def pin_classes(shapes, all_results):
@@ -205,7 +216,7 @@ def pin_classes(shapes, all_results):
         per_class = collections.defaultdict(dict)   # class -> {shape: best result}
         for s in members:
             for r in all_results[s]:
-                c = numerics_class(s, r[1], r[2], r[3])
+                c = numerics_class(s, r[1], r[2], r[3], r[4])
                 if s not in per_class[c] or r[0] < per_class[c][s][0]:
                     per_class[c][s] = r
         full = {c: d for c, d in per_class.items() if len(d) == len(members)}

@@ -219,13 +219,13 @@ def main():
     fam_class = {}
     for s in shapes:
         us, bm, bn, sk, stg = chosen[s]
-        fam_class[key_of_shape[s].split("x", 1)[1]] = tune_conv.numerics_class(s, bm, bn, sk)
+        fam_class[key_of_shape[s].split("x", 1)[1]] = tune_conv.numerics_class(s, bm, bn, sk, stg)
     for key, res in micro.items():
         fam = key.split("x", 1)[1]
         if key in insitu or fam not in fam_class:
             continue
         s = parse_key(key)
-        inclass = [r for r in res if tune_conv.numerics_class(s, int(r[1]), int(r[2]), int(r[3])) == fam_class[fam]]
+        inclass = [r for r in res if tune_conv.numerics_class(s, int(r[1]), int(r[2]), int(r[3]), int(r[4])) == fam_class[fam]]
         if not inclass:
             raise SystemExit(f"{key}: stage 1 has no result in the family's class {fam_class[fam]}")
         r = inclass[0]
