@@ -185,16 +185,11 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
                 st1[k] = (ay + 2) | ((ax + 2) << 16);
             } else {
                 st0[k] = b * p.h_in * p.w_in + ay * p.w_in + ax;
-                int mask = 0;
-                if (p.ksize == 3) {
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const int ky = t / 3, kx = t - ky * 3;
-                        if ((unsigned)(ay + ky) < (unsigned)Hl && (unsigned)(ax + kx) < (unsigned)Wl) mask |= 1 << t;
-                    }
-                } else {
-                    mask = ((unsigned)ay < (unsigned)Hl && (unsigned)ax < (unsigned)Wl) ? 1 : 0;
-                }
+                // bit 3 ky + kx = tap (ky, kx) lies inside the image: the outer product of a row mask and a column mask
+                const int xm = ((unsigned)ax < (unsigned)Wl ? 1 : 0) | ((unsigned)(ax + 1) < (unsigned)Wl ? 2 : 0) | ((unsigned)(ax + 2) < (unsigned)Wl ? 4 : 0);
+                int mask = (unsigned)ay < (unsigned)Hl ? xm : 0;
+                if (p.ksize == 3) mask |= ((unsigned)(ay + 1) < (unsigned)Hl ? xm << 3 : 0) | ((unsigned)(ay + 2) < (unsigned)Hl ? xm << 6 : 0);
+                else mask &= 1;
                 st1[k] = mask;
             }
         } else {
@@ -325,7 +320,8 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
     };
 
     // ---- accumulators in chunks of EC row fragments (the epilogue runs once per chunk: conv_wreg.hip) ---------------------------
-    constexpr int EC = MI < 4 ? MI : 4, EH = MI / EC;
+    // (EC = 2 here, 4 in conv_wreg: with 256 registers per wave the epilogue's operand loads for four row fragments spill 240-350 registers)
+    constexpr int EC = 2, EH = MI / EC;
     f32x4 acc[EH][NJ][EC];
 #pragma unroll
     for (int h = 0; h < EH; ++h)
@@ -503,7 +499,9 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
     };
     epilogue_chunk(std::integral_constant<int, 0>{});
     if constexpr (EH > 1) epilogue_chunk(std::integral_constant<int, 1>{});
-    static_assert(EH <= 2, "epilogue chunks");
+    if constexpr (EH > 2) epilogue_chunk(std::integral_constant<int, 2>{});
+    if constexpr (EH > 3) epilogue_chunk(std::integral_constant<int, 3>{});
+    static_assert(EH <= 4 && MI % EC == 0, "epilogue chunks");
 #ifdef MSD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
     MSD_STAMP(4);
