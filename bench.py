@@ -70,6 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the packed broadcast and the all-gather through torch.distributed even at world size 1 (a one-rank "
                          "RCCL process group): exercises the multi-GPU exchange path on a one-GPU box")
+    ap.add_argument("--fail-rank", type=int, default=-1,
+                    help="self-test of the failure path: this rank raises right after init_process_group, in front of its first collective")
     ap.add_argument("--stub-local", action="store_true",
                     help="replace the GPU pipeline by a trivial per-sample generator (launcher / sharding self-test; the "
                          "line is marked stub and is not a measurement)")
@@ -153,6 +155,7 @@ def launch_ranks(n: int, argv) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSD_BENCH_LAUNCHER="self")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only mode this host driver supports for RCCL
+        env.setdefault("NCCL_DEBUG", "WARN")                # RCCL's own reason for a failed init / collective reaches the log verbatim
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
     log(f"launcher: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
@@ -301,9 +304,17 @@ def main(argv=None):
         if world == 1:   # a one-rank group needs its own rendezvous: a free local port, nothing inherited
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
-    mdist.init(args.backend, force=args.force_collectives)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")   # (torchrun-launched ranks: as launch_ranks sets it)
+    try:
+        mdist.init(args.backend, force=args.force_collectives)
+    except Exception as e:   # the first place a rank meets RCCL: say which rank, with what IPC mode, and die (the launcher ends the others)
+        log(f"[rank {rank}] init_process_group({args.backend}) FAILED: {type(e).__name__}: {e} "
+            f"(HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, NCCL_DEBUG={os.environ.get('NCCL_DEBUG')})")
+        raise
     n_ranks_seen = mdist.world_size()
     assert n_ranks_seen == world, (n_ranks_seen, world)
+    if args.fail_rank >= 0 and rank == args.fail_rank:   # (launcher / failure-path self-test: tests/test_dist_cpu.py)
+        raise RuntimeError(f"[rank {rank}] --fail-rank: raising in front of the first collective")
 
     size, nsteps, b = args.size, args.denoise_steps, args.batch_per_gpu
     h = size // 8
@@ -363,10 +374,19 @@ def main(argv=None):
     if sd is not None:
         sd.scheduler.set_timesteps(nsteps)
 
-    def one_job():
-        return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases, per_sample=hints)
+    first = [True]
 
-    elapsed, img = timed_jobs(one_job, args.steps, args.warmup, dev)   # (returns after a device synchronise: img has landed)
+    def one_job():
+        if not first[0]:
+            return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases, per_sample=hints)
+        first[0] = False
+        try:   # the first broadcast / all-gather: where an IPC or topology problem of RCCL shows
+            return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases, per_sample=hints)
+        except Exception as e:
+            log(f"[rank {rank}] first job FAILED: {type(e).__name__}: {e} (HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})")
+            raise
+
+    elapsed, img, per_rank_ms = timed_jobs(one_job, args.steps, args.warmup, dev)   # (returns after a device synchronise: img has landed)
     if not stub:
         check_job_flags()
     assert tuple(img.shape) == out_shape and img.dtype == torch.uint8 and (rank != 0 or img.device.type == "cpu")
@@ -385,6 +405,8 @@ def main(argv=None):
         "n_ranks_seen": n_ranks_seen, "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
         "launcher": os.environ.get("MSD_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "external" if world > 1 else "none"),
         "rank_devices": rank_devices(dev, world),
+        "per_rank_ms": per_rank_ms,   # each rank's own elapsed over the timed jobs (its last job drained), rank order
+        "ipc_mode": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "NCCL_DEBUG": os.environ.get("NCCL_DEBUG")},
     }
     if args.force_collectives:
         out["collectives_forced"] = True   # broadcast + all-gather ran through the process group at every job, also at world 1
@@ -514,12 +536,13 @@ def check_job_flags():
     from minsdtf_amd import engine
 
     if _host_out.get("flags") is not None:
-        engine.check_gn_sync(_host_out["flags"].cpu())
+        engine.check_gn_sync(_host_out["flags"].cpu(), group_wide=True)   # (every rank gets here once: the verdict is the group's)
 
 
 def timed_jobs(one_job, steps, warmup, dev):
     """The bench contract's timing: `warmup` untimed jobs, then exactly `steps` jobs bracketed by a barrier + device
-    synchronise on both sides; returns (MAX over ranks of the elapsed seconds, last job's result)."""
+    synchronise on both sides; returns (MAX over ranks of the elapsed seconds, last job's result, every rank's own elapsed
+    milliseconds in rank order: a straggler shows in the line)."""
     import torch
     import torch.distributed as dist
 
@@ -538,13 +561,22 @@ def timed_jobs(one_job, steps, warmup, dev):
     t_start = time.perf_counter()
     for _ in range(steps):
         img = one_job()
+    own = time.perf_counter() - t_start    # this rank's own jobs (before the closing barrier makes everyone wait for the slowest)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t_start
     barrier()
     elapsed = time.perf_counter() - t_start
+    per_rank = [round(1e3 * own, 3)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, img
+        mine = torch.tensor([own], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [round(1e3 * float(x.item()), 3) for x in every]
+    return elapsed, img, per_rank
 
 
 def algorithmic_tflop_per_image(size, nsteps, controlnet=False):

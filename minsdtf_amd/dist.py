@@ -52,8 +52,8 @@ def shard_bounds(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous split; the global batch must divide evenly (weak scaling: fixed work per GPU)."""
     if global_batch % world:
         raise ValueError(f"global batch {global_batch} is not divisible by the {world} ranks of the initialised torch.distributed "
-                         "process group: under a process group `batch_size` is the GLOBAL batch, sharded over the ranks; for "
-                         "independent replicas per rank set `shard_batch = False` on the StableDiffusion object")
+                         "process group: with `shard_batch = True` `batch_size` is the GLOBAL batch, sharded over the ranks; "
+                         "for independent replicas per rank leave `shard_batch` at its default (False)")
     per = global_batch // world
     return rank * per, (rank + 1) * per
 

@@ -239,35 +239,60 @@ TRACE = os.environ.get("MSD_TRACE", "0") == "1"
 # a non-zero word raises: the pipeline never returns an image computed from abandoned moments with a clean return code.
 _gn_sync_plans: "weakref.WeakSet[Plan]" = weakref.WeakSet()
 GN_GIVE_UP_WORD = 8
+# Bumped by every reported give-up: plan caches (StableDiffusion._engines, the models' bound plans) key on it, so the job a caller
+# retries after the exception is RECORDED AGAIN - with the cluster kernel switched off (check_gn_sync sets gn_cluster = 0 for the
+# rest of the process): the retry does not meet the hazard a second time.
+GN_EPOCH = 0
 
 
 def gn_sync_flags(device=None) -> Optional[torch.Tensor]:
     """Device int32 tensor with the give-up word of every live plan on `device` that owns a cluster-GroupNorm sync block
     (None when there is none).  Stream-ordered: queue it behind the job, copy it with the job's D2H, hand it to
     check_gn_sync() once the copy has landed."""
-    plans = [p for p in _gn_sync_plans if device is None or torch.device(p.device) == torch.device(device)]
+    plans = _gn_plans_on(device)
     if not plans:
         return None
     words = [p._gn_sync_buf.tensor(torch.int32, (GN_GIVE_UP_WORD + 1,))[GN_GIVE_UP_WORD:] for p in plans]
     return torch.cat(words)
 
 
-def check_gn_sync(flags=None, device=None) -> None:
+def _gn_plans_on(device):
+    return [p for p in _gn_sync_plans if device is None or torch.device(p.device) == torch.device(device)]
+
+
+def check_gn_sync(flags=None, device=None, group_wide: bool = False) -> None:
     """Raise HipExtensionError if any cluster GroupNorm launch since the last check gave up (`flags`: the HOST copy of a
-    gn_sync_flags() tensor; None = read them now, synchronously).  The words are cleared when they are reported."""
+    gn_sync_flags() tensor; None = read them now, synchronously).  `group_wide` (the sharded jobs: generate_image, bench.py —
+    calls that every rank of the process group makes once per job): under a process group whose exchanges run
+    (dist.collectives_on) the verdict is the MAXIMUM over the ranks: a rank whose slice is corrupt has already shipped it to
+    every rank in the all-gather, so every rank must raise - together, or the others hang in the next job's broadcast.  Only
+    the words of the plans that were read (those on `device`) are cleared, and the process stops using the cluster kernel
+    (GN_EPOCH)."""
+    global GN_EPOCH
     if flags is None:
         dev_flags = gn_sync_flags(device)
-        if dev_flags is None:
-            return
-        flags = dev_flags.cpu()
-    if int(flags.max()) == 0:
+        flags = None if dev_flags is None else dev_flags.cpu()
+    worst = 0 if flags is None else int(flags.max())
+    from . import dist as mdist
+
+    if group_wide and mdist.collectives_on():   # (every rank calls this once per job, after its D2H: a matched collective)
+        import torch.distributed as tdist
+
+        backend_cuda = tdist.get_backend() == "nccl"
+        t = torch.tensor([worst], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if backend_cuda else "cpu")
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        worst = int(t.item())
+    if worst == 0:
         return
-    for p in list(_gn_sync_plans):
+    for p in _gn_plans_on(device):
         p._gn_sync_buf.tensor(torch.int32, (GN_GIVE_UP_WORD + 1,))[GN_GIVE_UP_WORD].zero_()
+    GN_EPOCH += 1
+    _lib.check(_lib.load().msd_set_option(b"gn_cluster", 0), "gn_cluster")
     raise _lib.HipExtensionError(
         "msd_group_norm: a workgroup of the cluster GroupNorm gave up waiting for its group's partial moments (sync word [8] "
-        "set): this job's result is wrong and has been discarded.  The one-workgroup-per-group path has no exchange: "
-        "msd_set_option('gn_cluster', 0)")
+        "set, on this rank or another one of the process group): this job's result is wrong and has been discarded.  The cluster "
+        "kernel is now off for this process (msd_set_option('gn_cluster', 0): the one-workgroup-per-group path has no exchange) "
+        "and the launch plans will be recorded again: retry the call")
 
 
 def _block_of(call_name: str) -> str:

@@ -15,8 +15,9 @@ properties, same return value (``uint8 (B, H, W, 3)``).  What differs is where t
   what a maintainer gets by only swapping the model classes; tests use it to check that both
   routes agree.
 
-* Under a ``torch.distributed`` process group ``generate_image`` shards the batch over the ranks (SURVEY.md §8e;
-  ``shard_batch``): one packed broadcast of rank 0's inputs, no traffic inside a step, one all-gather of the result.
+* With ``model.shard_batch = True`` (default False = the reference's semantics: every process runs the batch it was given),
+  under a ``torch.distributed`` process group ``generate_image`` treats ``batch_size`` as the GLOBAL batch and shards it over
+  the ranks: one packed broadcast of rank 0's inputs, no traffic inside a step, one all-gather of the result.
 
 Also on this path: ``image_to_image`` (VAE encoder + shortened schedule), ``inpaint`` (latent blend
 inside the sampler kernel, pixel blend before the uint8 cast), the TCD sampler, and the CLIP text models behind
@@ -398,9 +399,11 @@ class StableDiffusionBase:
         self.text_frontend = None
         self.bpe_path = None  # local copy of CLIP's bpe_simple_vocab_16e6.txt.gz (or $MSD_BPE_PATH) for string prompts
         self.unconditional_context = None  # (77, 768) embedding of the empty prompt, supplied by the caller
-        # True: under an initialised torch.distributed process group generate_image() treats batch_size as the GLOBAL batch
-        # and shards it over the ranks; False: every rank runs the whole batch on its own (independent replicas)
-        self.shard_batch = True
+        # False (default, the reference's meaning of batch_size: stable_diffusion.py:384-397 tiles one prompt to the batch THIS
+        # process runs): every rank of a process group runs the whole batch on its own (independent replicas).
+        # True (opt in; bench.py's jobs call dist.generate_sharded directly): under an initialised torch.distributed process
+        # group generate_image() treats batch_size as the GLOBAL batch and shards it over the ranks.
+        self.shard_batch = False
 
     # ---- public entry points (reference :84-139)
     def text_to_image(self, prompt, negative_prompt=None, batch_size=1, num_steps=50, unconditional_guidance_scale=7.5,
@@ -640,9 +643,10 @@ class StableDiffusionBase:
                        diffusion_noise=None, seed=None, negative_embedding=None, control_net_image=None, inpaint_mask=None,
                        mask_blur_strength=None, reference_image=None, reference_image_strength=0.8, guidance_rescale=0.0,
                        callback=None, host_loop=False, return_latent=False):
-        """Reference :317-486.  `batch_size` is the GLOBAL batch: under an initialised torch.distributed process group
-        (and ``shard_batch`` left on) every rank calls this with the same arguments, rank 0's inputs are broadcast, each
-        rank denoises + decodes its contiguous slice and every rank returns the whole gathered batch (minsdtf_amd/dist.py)."""
+        """Reference :317-486.  With ``self.shard_batch = True`` under an initialised torch.distributed process group
+        `batch_size` is the GLOBAL batch: every rank calls this with the same arguments, rank 0's inputs are broadcast, each
+        rank denoises + decodes its contiguous slice and every rank returns the whole gathered batch (minsdtf_amd/dist.py).
+        Default (False): the reference's meaning, this process runs all `batch_size` samples."""
         if diffusion_noise is not None and seed is not None:
             raise ValueError("`diffusion_noise` and `seed` should not both be passed to `generate_image`. `seed` is only "
                              "used to generate diffusion noise when it's not already user-specified.")
@@ -693,7 +697,7 @@ class StableDiffusionBase:
         # ---- device loop, sharded over the process group when there is one --------------------------------
         from . import dist as mdist
 
-        world = mdist.world_size() if getattr(self, "shard_batch", True) else 1
+        world = mdist.world_size() if getattr(self, "shard_batch", False) else 1
         tcd_global = bool(self.active_tcd and world > 1)
         per_sample, shared = {}, {}   # name -> array; insertion order = argument order of `local`
         if hint is not None:
@@ -731,11 +735,13 @@ class StableDiffusionBase:
             return self.image_decoder.decode_to_uint8(eng.latent)
 
         out = mdist.generate_sharded(local, context, unconditional_context, start_latent, dev,
-                                     per_sample=list(per_sample.values()), shared=list(shared.values()), shard=world > 1)
+                                     per_sample=list(per_sample.values()), shared=list(shared.values()),
+                                     # (a one-rank group with FORCE_COLLECTIVES still takes the real exchanges: tests/test_rccl_gpu.py)
+                                     shard=world > 1 or (getattr(self, "shard_batch", False) and mdist.collectives_on()))
         flags = engine.gn_sync_flags(dev) if out.device.type == "cuda" else None   # queued behind the job, read with its D2H
         host = out.cpu().numpy()
-        if flags is not None:
-            engine.check_gn_sync(flags.cpu())   # a cluster GroupNorm that gave up: raise, never return that image
+        if flags is not None:   # a cluster GroupNorm that gave up - on ANY rank of a sharded job: raise, never return that image
+            engine.check_gn_sync(flags.cpu(), device=dev, group_wide=world > 1 or mdist.collectives_on())
         return host
 
     def _engine(self, B, tc, tu, steps, g, phi, control, inpaint=False) -> DenoiseEngine:
@@ -743,7 +749,7 @@ class StableDiffusionBase:
         # load_synthetic() / LoRA reload on any of the models it was built from must retire it
         wver = (self.diffusion_model.weights_version,) + ((self.control_net.weights_version, self.hint_net.weights_version)
                                                            if control else ())
-        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams, inpaint, self.active_tcd, wver)
+        key = (B, tc, tu, steps, g, phi, control, self.denoise_streams, inpaint, self.active_tcd, wver, engine.GN_EPOCH)
         eng = self._engines.get(key)
         if eng is None:
             eng = DenoiseEngine(self.diffusion_model, B, tc, tu, steps, g, phi,
@@ -794,7 +800,9 @@ class StableDiffusionBase:
 
 
 class StableDiffusion(StableDiffusionBase):
-    """Reference ``StableDiffusion`` (stable_diffusion.py:575-725) with HIP-backed models."""
+    """Reference ``StableDiffusion`` (stable_diffusion.py:575-725) with HIP-backed models; `batch_size` means what it means in the
+    reference (the samples THIS process runs) unless ``shard_batch`` is set to True, which makes it the global batch of the
+    initialised torch.distributed process group ("More than one GPU")."""
 
     def __init__(self, img_height=512, img_width=512, jit_compile=False, clip_skip=-1, unet_ckpt=None, text_encoder_ckpt=None,
                  vae_ckpt=None, lora_path=None, controlnet_path=None, active_tcd=False, device=None):

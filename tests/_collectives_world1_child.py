@@ -76,17 +76,37 @@ def main():
         from minsdtf_amd.stable_diffusion import StableDiffusion
 
         sd = StableDiffusion(64, 64, jit_compile=True, device=dev)
+        sd.shard_batch = True   # (opt in: the default keeps the reference's replica semantics)
         sd.diffusion_model.load_synthetic(seed=0)
         sd.image_decoder.load_synthetic(seed=0)
         ctx = rng.standard_normal((77, 768)).astype(np.float32)
         sd.unconditional_context = rng.standard_normal((77, 768)).astype(np.float32)
         noise = rng.standard_normal((2, 8, 8, 4)).astype(np.float32)
         kw = dict(batch_size=2, num_steps=3, unconditional_guidance_scale=7.5, diffusion_noise=noise, guidance_rescale=0.7)
+        # count the exchanges: the forced run must really broadcast its packed inputs and all-gather its images (a comparison of
+        # the short-cut path with itself would pass as well)
+        calls = {"broadcast": 0, "all_gather_into_tensor": 0}
+        real = {k: getattr(dist, k) for k in calls}
+
+        def counted(name):
+            def f(*a, **k):
+                calls[name] += 1
+                return real[name](*a, **k)
+            return f
+
+        for k in calls:
+            setattr(dist, k, counted(k))
         t0 = time.perf_counter()
         forced = sd.generate_image(ctx, **kw)
         info["pipeline_s"] = round(time.perf_counter() - t0, 2)
+        assert calls["broadcast"] >= 1 and calls["all_gather_into_tensor"] >= 1, f"generate_image took the single-process short cut: {calls}"
+        info["pipeline_collectives"] = dict(calls)
         mdist.FORCE_COLLECTIVES = False
+        n0 = dict(calls)
         plain = sd.generate_image(ctx, **kw)
+        assert calls == n0, "the un-forced run must not touch the process group"
+        for k in calls:
+            setattr(dist, k, real[k])
         mdist.FORCE_COLLECTIVES = True
         assert forced.shape == (2, 64, 64, 3) and forced.dtype == np.uint8
         assert np.array_equal(forced, plain), "the collectives changed the images"

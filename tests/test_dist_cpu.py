@@ -91,8 +91,9 @@ def _bench_worker(rank, world, port, gb, out_dir):
         assert isinstance(z, torch.Tensor) and z.shape[0] == gb // world   # device-resident slice of the ONE broadcast buffer
         return _fake_generate(c, u, z)
 
-    elapsed, img = bench.timed_jobs(lambda: bench.sharded_job(local, ctx, unc, noise, dev), steps=3, warmup=1, dev=dev)
+    elapsed, img, per_rank = bench.timed_jobs(lambda: bench.sharded_job(local, ctx, unc, noise, dev), steps=3, warmup=1, dev=dev)
     assert calls["n"] == 4 and elapsed > 0
+    assert len(per_rank) == world and all(0 < ms <= elapsed * 1e3 + 1e-6 for ms in per_rank)   # every rank's own time, none above the MAX
     np.save(os.path.join(out_dir, f"bench_{rank}.npy"), np.asarray([elapsed]))
     np.save(os.path.join(out_dir, f"bimg_{rank}.npy"), img.numpy())
     dist.barrier()
@@ -273,6 +274,8 @@ def _api_worker(rank, world, port, out_dir):
     mdist.init("gloo")
     for tcd in (False, True):
         p = _stub_pipeline(tcd)
+        assert p.shard_batch is False                         # the default is the reference's meaning of batch_size (replicas)
+        p.shard_batch = True                                  # opt in: batch_size = the GLOBAL batch
         for name, kw in _api_cases(rank).items():
             np.random.seed(77 + rank)   # TCD draws: rank 0's stream must be the one every sample sees
             got = p.generate_image(**kw)
@@ -344,6 +347,9 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["launcher"] == "self" and out["stub"] is True
     assert [d["rank"] for d in out["rank_devices"]] == [0, 1] and len({d["pid"] for d in out["rank_devices"]}) == 2
     assert out["config"]["global_batch"] == 2 and out["steps"] == 2 and out["value"] > 0
+    # what a first real SCALE run needs to be diagnosable: every rank's own time, and the IPC mode the ranks ran with
+    assert len(out["per_rank_ms"]) == 2 and all(0 < ms <= out["ms_per_step"] * out["steps"] + 1e-3 for ms in out["per_rank_ms"])
+    assert out["ipc_mode"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and out["ipc_mode"]["NCCL_DEBUG"]
     one = _run_bench("--gpus", "1", "--batch-per-gpu", "2", "--backend", "gloo", "--stub-local", "--steps", "1", "--controlnet", "--size", "64")
     assert one.returncode == 0, one.stderr[-2000:]
     ref = json.loads(one.stdout.strip().splitlines()[-1])
@@ -360,6 +366,22 @@ def test_bench_launcher_reports_a_failed_rank():
     r = _run_bench("--gpus", "2", "--steps", "1")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+
+
+@pytest.mark.timeout(300)
+def test_bench_rank_that_raises_before_its_first_collective_world2():
+    """A rank that dies after init_process_group, in front of its first collective (what an RCCL IPC failure looks like from
+    outside): its message reaches stderr verbatim, the launcher ends the OTHER rank (which sits in the broadcast), the exit
+    code is non-zero and there is no JSON line - no retry, no hang."""
+    import time
+
+    t0 = time.time()
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--stub-local", "--steps", "1", "--fail-rank", "1", timeout=240)
+    assert r.returncode != 0
+    assert "--fail-rank: raising in front of the first collective" in r.stderr
+    assert "launcher: rank 1 exited with code" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert time.time() - t0 < 200
 
 
 @pytest.mark.timeout(120)

@@ -720,15 +720,31 @@ def test_group_norm_cluster_give_up_is_loud(gpu):
         plan.run(st)
         torch.cuda.synchronize()
         assert int(words[0, engine.GN_GIVE_UP_WORD]) == 1 and int(words[used[5], engine.GN_GIVE_UP_WORD]) == 1
+        epoch = engine.GN_EPOCH
         with pytest.raises(_lib.HipExtensionError, match="gave up"):
             engine.check_gn_sync(device=gpu)
         assert int(words[0, engine.GN_GIVE_UP_WORD]) == 0        # reported once, then cleared
         engine.check_gn_sync(device=gpu)
+        # the in-process answer: plan caches are retired (they key on the epoch) and a plan recorded from now on does not use the
+        # cluster kernel, so the caller's retry cannot meet the same hazard
+        assert engine.GN_EPOCH == epoch + 1
+        plan2 = engine.Plan(gpu)
+        e2 = engine.Emitter(plan2, {"n.g": torch.ones(C, device=gpu), "n.b": torch.zeros(C, device=gpu)})
+        x2 = plan2.act(B, H, W, C)
+        y2 = e2.group_norm(x2, "n", True)
+        plan2.finalize()
+        x2.buf.tensor(torch.bfloat16, (B, H * W, C)).copy_(x.buf.tensor(torch.bfloat16, (B, H * W, C)))
+        plan2.run(st)
+        torch.cuda.synchronize()
+        w2 = plan2._gn_sync_buf.tensor(torch.int32, (B * ops.GN_SYNC_WORDS_PER_SAMPLE,)).view(-1, 64)
+        assert int(torch.count_nonzero(w2[:, 0])) == 0, "a plan recorded after the give-up still ran the cluster kernel"
+        close(y2.buf.tensor(torch.bfloat16, (B, H * W, C)).float().cpu(), good.float().cpu(), what="three-launch GroupNorm after the give-up")
         # the groups that were not disturbed still carry the right numbers
         got = y.buf.tensor(torch.bfloat16, (B, H * W, C))
         assert torch.equal(got[..., :50].view(torch.int16), good[..., :50].view(torch.int16))
     finally:
         lib.msd_set_option(b"gn_poll_limit", 1 << 18)
+        lib.msd_set_option(b"gn_cluster", 256)           # (the default: the rest of the suite runs the cluster kernel again)
         words[used[5], 0] += P - 1                       # back on a multiple of P (the plan dies with the test anyway)
 
 
