@@ -79,6 +79,68 @@ def parse_args(argv=None):
 
 
 LIVE_TRAFFIC = None   # summary of this run's own PMC passes (live_traffic), read by kernel_roofline
+LIVE_INGRAPH = None   # family durations per fused step inside the replayed whole-loop hipGraph (in_graph_trace), read by kernel_roofline
+
+
+def in_graph_trace(args):
+    """What the dominant family costs INSIDE the captured loop: `rocprofv3 --kernel-trace` (no counters) over tools/pmc_step.py
+    --graph-loops 1 - the whole denoise loop as one hipGraph, captured and replayed twice exactly as the timed region replays it -
+    started as a child process before this process has touched the GPU; the family's kernel durations (split-K reductions included)
+    summed by tools/trace_family.py and divided by the fused steps in the trace.  None (reason on stderr) when it cannot run here."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        log("in-graph trace: this process is itself running under a profiler; no in-graph figure")
+        return None
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        log("in-graph trace: no rocprofv3 on PATH; no in-graph figure")
+        return None
+    from tools import trace_family
+
+    loops = 1
+    step_args = ["--size", str(args.size), "--batch", str(args.batch_per_gpu), "--denoise-steps", str(args.denoise_steps),
+                 "--graph-loops", str(loops)] + (["--controlnet"] if args.controlnet else [])
+    for kv in args.opt:
+        step_args += ["--opt", kv]
+    tmp = tempfile.mkdtemp(prefix="msd_bench_trace_")
+    t0 = time.time()
+    try:
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, "kt"), "--",
+               "python3", os.path.join(ROOT, "tools", "pmc_step.py")] + step_args
+        try:
+            r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, timeout=400)
+        except subprocess.TimeoutExpired:
+            log("in-graph trace: the pass did not finish in 400 s; no in-graph figure")
+            return None
+        if r.returncode != 0:
+            log(f"in-graph trace: the pass failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-400:]}")
+            return None
+        try:
+            per = trace_family.load(os.path.join(tmp, "kt"))
+        except SystemExit as e:
+            log(f"in-graph trace: {e}")
+            return None
+        steps = (loops + 1) * args.denoise_steps
+        fam = trace_family.summarise(per, steps)
+        fam["seconds"] = round(time.time() - t0, 1)
+        keep = os.environ.get("MSD_BENCH_KEEP_TRACE")   # tools/measure_round.sh: the same trace becomes profiles/rN_bench_kernel_stats<tag>.{csv,md}
+        if keep:
+            try:
+                tag = config_tag(args.batch_per_gpu, args.size, args.controlnet)
+                title = (f"kernels of the replayed whole-loop hipGraph, {steps} fused steps ({loops + 1} loops x {args.denoise_steps}), "
+                         f"{args.size}x{args.size}, batch {args.batch_per_gpu}/GPU{', ControlNet' if args.controlnet else ''}: the child pass of "
+                         f"`python bench.py` that roofline.achieved_in_graph is computed from")
+                trace_family.write_csv(per, keep + f"_bench_kernel_stats{tag}.csv")
+                trace_family.write_md(per, keep + f"_bench_kernel_stats{tag}.md", title, fam)
+            except OSError as e:
+                log(f"in-graph trace: could not keep the trace summary: {e}")
+        return fam
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def live_traffic(args):
@@ -276,8 +338,11 @@ def main(argv=None):
 
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.backend == "nccl" and not args.stub_local
             and not args.no_roofline and not args.quoted_traffic):
-        global LIVE_TRAFFIC   # (children first: nothing in this process has initialised the GPU yet)
+        global LIVE_TRAFFIC, LIVE_INGRAPH   # (children first: nothing in this process has initialised the GPU yet)
         LIVE_TRAFFIC = live_traffic(args)
+        LIVE_INGRAPH = in_graph_trace(args)
+    elif (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.backend == "nccl" and not args.stub_local and not args.no_roofline):
+        LIVE_INGRAPH = in_graph_trace(args)   # (--quoted-traffic: the counters are quoted from profiles/, the in-graph trace is still this run's)
 
     import torch
     import torch.distributed as dist
@@ -395,7 +460,7 @@ def main(argv=None):
     value = images / elapsed
     tflop_per_image = algorithmic_tflop_per_image(size, nsteps, args.controlnet)
     out = {
-        "metric": "512x512 images/sec (whole node), SD1.5 25-step txt2img",
+        "metric": (f"{size}x{size} images/sec (whole node), SD1.5 {nsteps}-step txt2img" + (" + ControlNet" if args.controlnet else "")),
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -719,10 +784,23 @@ def kernel_roofline(sd, b, nsteps, control=False, size=512):
             break
         except (OSError, ValueError):
             continue
-    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> / dense_rowpanel_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
+    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> / dense_rowpanel_kernel<*> / conv_wreg_kernel<*> / conv_big_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+            "achieved_is": "back to back: the step's conv / dense calls alone under one HIP-event pair (no norm / attention launches between them)",
             "traffic": traffic, "traffic_source": traffic_src, "traffic_read_write": traffic_rw, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),
             "gflop_per_launch": round(flop_per_launch / 1e9, 3)}
+    if LIVE_INGRAPH and LIVE_INGRAPH.get("conv_gemm"):
+        # the same family inside the replayed whole-loop graph (norm / attention launches between its kernels, operands as the
+        # producers left them): kernel-trace durations of this run's own child pass, split-K reductions included
+        fam = LIVE_INGRAPH["conv_gemm"]
+        us_step = fam["us_per_step"]
+        flop_step = g["flop"]   # algorithmic FLOP of one fused step's conv / dense calls
+        roof["achieved_in_graph"] = round(flop_step / (us_step * 1e-6) / 1e12, 2)
+        roof["frac_in_graph"] = round(roof["achieved_in_graph"] / MFMA_PEAK_TFLOPS, 4)
+        roof["in_graph"] = {"family_us_per_fused_step": us_step, "dispatches_per_fused_step": fam["dispatches_per_step"],
+                            "fused_steps_in_trace": LIVE_INGRAPH["_steps"], "tflop_per_fused_step": round(flop_step / 1e12, 4),
+                            "source": f"live: rocprofv3 --kernel-trace over tools/pmc_step.py --graph-loops 1 (child process of this run, {LIVE_INGRAPH['seconds']} s)",
+                            "all_families_us_per_fused_step": {k: v["us_per_step"] for k, v in LIVE_INGRAPH.items() if isinstance(v, dict) and "us_per_step" in v}}
     if sclk:
         # profiles/r4_pmc_mfma.json: the matrix-pipe counter and this FLOP-derived figure agree within 5 % once both are taken over the
         # kernels' own intervals at the clock actually held; `frac` stays priced at the 2.4 GHz spec peak

@@ -7,7 +7,7 @@
 #   gpurun --timeout 1150 -- "bash tools/measure_round.sh r3 $(git rev-parse --short HEAD) [headline|b4|768|controlnet|all]"
 # Outputs under gpurun_out/final/; copy what should be judged into profiles/.
 set -o pipefail
-TAG=${1:-r4}
+TAG=${1:-r5}
 COMMIT=${2:-unknown}
 WHAT=${3:-all}
 OUT=gpurun_out/final
@@ -43,7 +43,7 @@ if [ "$WHAT" = mfma ]; then
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = headline ]; then
     pmc "" || exit $?
-    $T 400 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench_n1.err || exit 1
+    MSD_BENCH_KEEP_TRACE=$OUT/${TAG}_graph $T 500 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/bench_n1.err || exit 1
     echo "bench n1 done"; head -c 330 $OUT/${TAG}_bench_n1.json; echo
     $T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/prof_bench.log 2>&1 || exit 2
     ST=$(ls $OUT/prof/*/*kernel_stats.csv 2>/dev/null | head -1)
@@ -58,17 +58,17 @@ if [ "$WHAT" = all ] || [ "$WHAT" = headline ]; then
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = b4 ]; then      # C3's per-GPU shape: batch 4 (fused cond+uncond batch 8)
     pmc _b4 --batch 4 || exit $?
-    $T 300 python bench.py --batch-per-gpu 4 --steps 3 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_b4.json 2>> $OUT/bench_cfg.err
+    MSD_BENCH_KEEP_TRACE=$OUT/${TAG}_graph $T 400 python bench.py --batch-per-gpu 4 --steps 3 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_b4.json 2>> $OUT/bench_cfg.err
     echo "b4 done"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = 768 ]; then     # C4: 768x768, 50 steps
     pmc _768 --size 768 || exit $?
-    $T 400 python bench.py --size 768 --denoise-steps 50 --steps 2 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_768.json 2>> $OUT/bench_cfg.err
+    MSD_BENCH_KEEP_TRACE=$OUT/${TAG}_graph $T 600 python bench.py --size 768 --denoise-steps 50 --steps 2 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_768.json 2>> $OUT/bench_cfg.err
     echo "768 done"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = controlnet ]; then   # C5's per-GPU shape: ControlNet, batch 1
     pmc _controlnet --controlnet || exit $?
-    $T 300 python bench.py --controlnet --steps 3 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_controlnet.json 2>> $OUT/bench_cfg.err
+    MSD_BENCH_KEEP_TRACE=$OUT/${TAG}_graph $T 400 python bench.py --controlnet --steps 3 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_controlnet.json 2>> $OUT/bench_cfg.err
     echo "controlnet done"
 fi
 echo "configs done"

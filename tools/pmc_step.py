@@ -23,6 +23,11 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--controlnet", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="msd_set_option switch, e.g. --opt gn_cluster=0")
+    ap.add_argument("--graph-loops", type=int, default=0,
+                    help="instead of two eager steps: capture the WHOLE 25-step loop as one hipGraph (as bench.py runs it) and replay it "
+                         "this many times - for `rocprofv3 --kernel-trace` (no --pmc: counter collection under a replayed graph does not "
+                         "finish); the trace then holds the kernels exactly as they run inside the timed region")
+    ap.add_argument("--denoise-steps", type=int, default=25)
     ap.add_argument("--calls-json", default=None,
                     help="write, in launch order, the algorithmic FLOP of every msd_conv_gemm call this process makes and the "
                          "shader clock sampled from sysfs while the steps run (tools/pmc_mfma.py joins it with the kernel trace)")
@@ -63,9 +68,9 @@ def main():
                     except (OSError, ValueError, IndexError):
                         pass
                 time.sleep(0.002)
-    size, steps, B = args.size, 25, args.batch
+    size, steps, B = args.size, args.denoise_steps, args.batch
     dev = torch.device("cuda:0")
-    sd = StableDiffusion(size, size, jit_compile=False, device=dev)
+    sd = StableDiffusion(size, size, jit_compile=args.graph_loops > 0, device=dev)
     sd.diffusion_model.load_synthetic(seed=0)
     hint = None
     if args.controlnet:
@@ -85,7 +90,16 @@ def main():
         th = threading.Thread(target=sample_clock, daemon=True)
         th.start()
     n_before = len(conv_log)
-    eng.run_steps(2, None)
+    if args.graph_loops > 0:
+        eng.run_steps(steps, None)   # capture + first replay (in the trace: the eager capture pass is not dispatched)
+        torch.cuda.synchronize()
+        for _ in range(args.graph_loops):
+            eng.step_ptr.zero_()
+            eng.run_steps(steps, None)
+        torch.cuda.synchronize()
+        print(f"graph loops {args.graph_loops + 1} steps {steps}")
+    else:
+        eng.run_steps(2, None)
     torch.cuda.synchronize()
     if args.calls_json:
         import json

@@ -19,7 +19,7 @@ import sys
 def klass(name):
     if "splitk_finalize" in name:
         return "conv_gemm", False
-    if "conv_gemm" in name or "conv3x3_halo" in name or "dense_rowpanel" in name:
+    if "conv_gemm" in name or "conv3x3_halo" in name or "dense_rowpanel" in name or "conv_wreg" in name or "conv_big" in name:
         return "conv_gemm", True
     if name.startswith("void gn_") or name.startswith("gn_"):
         return "group_norm", "stats" not in name and "finalize" not in name
