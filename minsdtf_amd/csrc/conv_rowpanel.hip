@@ -158,8 +158,13 @@ __global__ __launch_bounds__(256) void dense_rowpanel_kernel(const bf16_t* hot_a
     for (int step = 0; step < nsteps; ++step) {
         // Retire weight tile `step`.  Younger in the queue, in issue order: the KC DMAs of tile step + 1, then the stores
         // of the previous step's epilogue; vmcnt(KC) therefore lets stores (and what is left of the KC) stay in flight.
+        // The LAST step has no tile step + 1 behind it: the KC youngest operations are then the two previous epilogues' stores AND
+        // the youngest DMAs of tile `step` itself, so vmcnt(KC) would let the step read a tile that has not landed (round 5: found
+        // as a 1-in-400 run-to-run difference of the GEGLU projections when their weights came from HBM; never seen on hot
+        // weights).  It waits for everything.
         if (step) {
-            wait_vmcnt<KC>();
+            if (step + 1 < nsteps) wait_vmcnt<KC>();
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();   // tile `step` visible to all waves; stage (step - 1) % S free
         }
         if (step + 2 < nsteps) {
