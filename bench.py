@@ -424,8 +424,10 @@ def main(argv=None):
         def local(c, u, z, *hint):
             """This rank's slice: prepare -> 25-step loop -> decode.  c / u / z (/ hint) arrive as device tensors (N > 1:
             views of the one broadcast buffer) or host arrays (N = 1)."""
+            # (the engine is built once, by the first warm-up job, OUTSIDE the phase range: building it re-lays weights out for the wreg
+            #  form - torch index / copy kernels, 3 per matrix - which a by-phase trace would otherwise book under `prepare` of every job)
+            eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, args.controlnet)
             with phase("prepare", args.sync_phases):   # uploads + context K/V, time-embedding tables (+ HintNet)
-                eng = sd._engine(b, c.shape[1], u.shape[1], nsteps, 7.5, 0.7, args.controlnet)
                 eng.prepare(eng.contexts(u, c), z, sd.scheduler, None, 0, hint[0] if hint else None)
             with phase("denoise_loop", args.sync_phases):
                 eng.run_steps(nsteps, None)

@@ -37,12 +37,24 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const float* hot_eps, fl
     const bool cfg = hot_guidance > 0.0f;
     const float* u = hot_eps + (size_t)b * hot_n;
     const float* c = cfg ? hot_eps + (size_t)(hot_batch + b) * hot_n : u;
-    float ru[NPT > 0 ? NPT : 1], rc[NPT > 0 ? NPT : 1], rl[NPT > 0 ? NPT : 1];
+    // 16-byte accesses (n = h * w * 4 is a multiple of 4): thread t owns elements 4 (t + 1024 k) .. + 3.  One CU issues every load of
+    // its sample: as 4-byte accesses that was 48 wave-instructions per wave x 16 waves through one address unit, most of the
+    // launch's 19.8 us at 64x64 (round 5)
+    // (KEEP_L: the latent is prefetched with eps only where the registers allow it: 1024 threads = 128 registers per lane; at NPT = 36
+    //  three arrays spill, so the latent is read in the update pass instead)
+    constexpr bool KEEP_L = NPT <= 16;
+    float ru[NPT > 0 ? NPT : 1], rc[NPT > 0 ? NPT : 1], rl[(NPT > 0 && KEEP_L) ? NPT : 1];
     if (NPT > 0) {   // everything this thread touches, issued up front
 #pragma unroll
-        for (int k = 0; k < NPT; ++k) {
-            const int i = min(t + k * 1024, hot_n - 1);
-            ru[k] = u[i]; rc[k] = c[i]; rl[k] = lat[i];
+        for (int k = 0; k < NPT / 4; ++k) {
+            const int i = min(4 * (t + k * 1024), hot_n - 4);
+            const float4 a = *reinterpret_cast<const float4*>(u + i), bq = *reinterpret_cast<const float4*>(c + i);
+            ru[4 * k] = a.x; ru[4 * k + 1] = a.y; ru[4 * k + 2] = a.z; ru[4 * k + 3] = a.w;
+            rc[4 * k] = bq.x; rc[4 * k + 1] = bq.y; rc[4 * k + 2] = bq.z; rc[4 * k + 3] = bq.w;
+            if constexpr (KEEP_L) {
+                const float4 l = *reinterpret_cast<const float4*>(lat + i);
+                rl[4 * k] = l.x; rl[4 * k + 1] = l.y; rl[4 * k + 2] = l.z; rl[4 * k + 3] = l.w;
+            }
         }
     }
     float factor = 1.0f;
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const float* hot_eps, fl
         if (NPT > 0) {
 #pragma unroll
             for (int k = 0; k < NPT; ++k)
-                if (t + k * 1024 < hot_n) acc(ru[k], rc[k]);
+                if (4 * (t + (k >> 2) * 1024) < hot_n) acc(ru[k], rc[k]);   // (a quad is inside the sample or outside it)
         } else {
             for (int i = t; i < hot_n; i += 1024) acc(u[i], c[i]);
         }
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const float* hot_eps, fl
         const float std_cfg = (float)sqrt(vg) + 1e-5f;
         factor = p.rescale * (std_text / std_cfg) + (1.0f - p.rescale);
     }
-    auto update = [&](int i, float cu, float cc, float l) {
+    auto value = [&](int i, float cu, float cc, float l) {
         const float e = cfg ? (cu + hot_guidance * (cc - cu)) * factor : cu;
         const float x0 = (l - nr * e) / sr;
         float x = ca * x0 + cb * e;
@@ -97,14 +109,22 @@ __global__ __launch_bounds__(1024) void cfg_step_kernel(const float* hot_eps, fl
             const float org = sr * p.ip_init[i] + nr * p.ip_noise[(size_t)b * hot_n + i];
             x = org * (1.0f - m) + x * m;
         }
-        lat[i] = x;
+        return x;
     };
     if (NPT > 0) {
 #pragma unroll
-        for (int k = 0; k < NPT; ++k)
-            if (t + k * 1024 < hot_n) update(t + k * 1024, ru[k], rc[k], rl[k]);
+        for (int k = 0; k < NPT / 4; ++k) {
+            const int i = 4 * (t + k * 1024);
+            if (i < hot_n) {
+                float4 l;
+                if constexpr (KEEP_L) l = make_float4(rl[4 * k], rl[4 * k + 1], rl[4 * k + 2], rl[4 * k + 3]);
+                else l = *reinterpret_cast<const float4*>(lat + i);
+                *reinterpret_cast<float4*>(lat + i) = make_float4(value(i, ru[4 * k], rc[4 * k], l.x), value(i + 1, ru[4 * k + 1], rc[4 * k + 1], l.y),
+                                                                  value(i + 2, ru[4 * k + 2], rc[4 * k + 2], l.z), value(i + 3, ru[4 * k + 3], rc[4 * k + 3], l.w));
+            }
+        }
     } else {
-        for (int i = t; i < hot_n; i += 1024) update(i, u[i], c[i], lat[i]);
+        for (int i = t; i < hot_n; i += 1024) lat[i] = value(i, u[i], c[i], lat[i]);
     }
     if (p.advance_in_kernel && t == 0) {
         // every workgroup read *step_ptr at its start and takes its ticket here, at its end: the one that draws the last
@@ -123,6 +143,7 @@ extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!q || !q->eps || !q->latent || !q->coef) MSD_FAIL(MSD_E_ARG, "cfg_step: null pointer");
     if (q->batch <= 0 || q->n <= 0 || q->num_steps <= 0) MSD_FAIL(MSD_E_ARG, "cfg_step: bad dims");
+    const bool vec4 = (q->n % 4) == 0 && q->n >= 4 && msd_aligned16(q->eps) && msd_aligned16(q->latent);   // (the register forms use 16-byte accesses)
     if (q->advance && !q->step_ptr) MSD_FAIL(MSD_E_ARG, "cfg_step: advance needs step_ptr");
     if (q->advance < 0 || q->advance > 2) MSD_FAIL(MSD_E_ARG, "cfg_step: advance takes 0, 1 or 2");
     CfgArgs a;
@@ -133,8 +154,8 @@ extern "C" int msd_cfg_step(const MsdCfgStep* q, msd_stream_t stream_) {
     if (a.ip_mask && (!a.ip_init || !a.ip_noise)) MSD_FAIL(MSD_E_ARG, "cfg_step: inpaint_mask needs inpaint_init and inpaint_noise");
     a.step_noise = q->step_noise; a.noise_coef = q->noise_coef;
     if (a.step_noise && !a.noise_coef) MSD_FAIL(MSD_E_ARG, "cfg_step: step_noise needs noise_coef");
-    if (q->n <= 16 * 1024) hipLaunchKernelGGL(cfg_step_kernel<16>, dim3(q->batch), dim3(1024), 0, stream, a.eps, a.latent, a.coef, a.step_ptr, a.batch, a.n, a.num_steps, a.guidance, a);        // <= 64x64 latents
-    else if (q->n <= 36 * 1024) hipLaunchKernelGGL(cfg_step_kernel<36>, dim3(q->batch), dim3(1024), 0, stream, a.eps, a.latent, a.coef, a.step_ptr, a.batch, a.n, a.num_steps, a.guidance, a);   // 96x96
+    if (vec4 && q->n <= 16 * 1024) hipLaunchKernelGGL(cfg_step_kernel<16>, dim3(q->batch), dim3(1024), 0, stream, a.eps, a.latent, a.coef, a.step_ptr, a.batch, a.n, a.num_steps, a.guidance, a);        // <= 64x64 latents
+    else if (vec4 && q->n <= 36 * 1024) hipLaunchKernelGGL(cfg_step_kernel<36>, dim3(q->batch), dim3(1024), 0, stream, a.eps, a.latent, a.coef, a.step_ptr, a.batch, a.n, a.num_steps, a.guidance, a);   // 96x96
     else hipLaunchKernelGGL(cfg_step_kernel<0>, dim3(q->batch), dim3(1024), 0, stream, a.eps, a.latent, a.coef, a.step_ptr, a.batch, a.n, a.num_steps, a.guidance, a);
     MSD_CHECK_LAUNCH();
     if (q->advance == 1) {

@@ -984,7 +984,8 @@ def test_softmax_rows(gpu):
 
 @pytest.mark.parametrize("guidance,rescale", [(7.5, 0.7), (7.5, 0.0), (0.0, 0.0)])
 @pytest.mark.parametrize("advance", [2, 1])   # the step counter moved inside the launch (by the last workgroup), or by a second launch
-def test_cfg_step(gpu, guidance, rescale, advance):
+@pytest.mark.parametrize("hw", [8, 64, 96, 100])   # 8x8 latent (most threads idle), 64x64 / 96x96 (the register forms' full sizes), 100x100 (the re-reading loop)
+def test_cfg_step(gpu, guidance, rescale, advance, hw):
     """CFG + rescale + sampler step against the oracle restatement, for every step of a 5-step run (batch 3: three
     workgroups race for the last ticket of the in-kernel advance)."""
     from minsdtf_amd import ops
@@ -992,19 +993,19 @@ def test_cfg_step(gpu, guidance, rescale, advance):
     from oracle import sd_oracle as O
 
     rng = np.random.default_rng(9)
-    B, n, steps = 3, 8 * 8 * 4, 5
+    B, n, steps = 3, hw * hw * 4, 5
     sch = Scheduler()
     sch.set_timesteps(steps)
     coef = torch.from_numpy(sch.coefficient_table()).to(gpu)
     osch = O.OracleScheduler()
     osch.set_timesteps(steps)
-    lat = rng.standard_normal((B, 8, 8, 4)).astype(np.float32)
+    lat = rng.standard_normal((B, hw, hw, 4)).astype(np.float32)
     lat_d = torch.from_numpy(lat.reshape(B, n).copy()).to(gpu)
     step = torch.zeros(2, dtype=torch.int32, device=gpu)   # {step, ticket}
     ref = lat.astype(np.float64)
     for i, t in enumerate(osch.timesteps):
-        u = rng.standard_normal((B, 8, 8, 4)).astype(np.float32)
-        c = (u + 0.3 * rng.standard_normal((B, 8, 8, 4))).astype(np.float32)
+        u = rng.standard_normal((B, hw, hw, 4)).astype(np.float32)
+        c = (u + 0.3 * rng.standard_normal((B, hw, hw, 4))).astype(np.float32)
         if guidance > 0:
             e = u + guidance * (c - u)
             if rescale > 0:
@@ -1016,7 +1017,7 @@ def test_cfg_step(gpu, guidance, rescale, advance):
         ref = osch.step(e, int(t), ref)
         run_calls(ops.cfg_step(eps=eps_d, latent=lat_d, coef=coef, step_ptr=step, batch=B, n=n, num_steps=steps,
                                guidance=guidance, guidance_rescale=rescale, advance=advance))
-        got = lat_d.cpu().numpy().reshape(B, 8, 8, 4)
+        got = lat_d.cpu().numpy().reshape(B, hw, hw, 4)
         # fp32 device math vs the reference's float64 numpy path
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max(), err_msg=f"step {i}")
         assert step.tolist() == [i + 1, 0]
