@@ -161,5 +161,12 @@ def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int, ln_produce
 
 
 def key_is_ln_producer(key: str) -> bool:
-    """Shape keys of the GEGLU / q|k|v projections carry an 'n' (no split-K: shape_key(allow_split=False))."""
-    return re.search(r"u[01]n(\+x\d+)?$", key) is None
+    """Whether a launch of this shape may write LayerNorm-fold row moments (ln_out), i.e. whether its column tile is part of its
+    numerics class.  Only three layers of a transformer block do (engine.Emitter.attentions: proj_in and the two to_out): 1x1,
+    C -> C, no shortcut operand.  Not the GEGLU / q|k|v projections (keys ending in 'n': shape_key(allow_split=False)), not the
+    1x1 layers with cin != N (conv_shortcut, the folded ff.net.2 + proj_out with K = 5 C)."""
+    m = re.match(r"\d+x\d+x\d+x(\d+)->(\d+)k(\d)s\du[01](n?)(\+x\d+)?$", key)
+    if m is None:
+        return True
+    cin, n, ks, nos, cx = m.groups()
+    return ks == "1" and nos != "n" and cx is None and cin == n

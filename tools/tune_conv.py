@@ -201,7 +201,9 @@ def numerics_class(shape, bm, bn, sk, stg=0):
     """What of a configuration changes the order of the fp32 sums (see the module docstring)."""
     from minsdtf_amd import tuning
 
-    return tuning.numerics_class(shape[5], bm, bn, sk, ln_producer=bool(shape[8]), stages=stg)   # (shape[8] = allow_split: False for GEGLU / q|k|v)
+    # (a LayerNorm producer: 1x1, C -> C, splittable key, no shortcut operand - tuning.key_is_ln_producer)
+    ln_prod = bool(shape[8]) and shape[5] == 1 and shape[3] == shape[4] and not shape[9]
+    return tuning.numerics_class(shape[5], bm, bn, sk, ln_producer=ln_prod, stages=stg)
 
 
 def pin_classes(shapes, all_results):
