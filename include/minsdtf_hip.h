@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 8
+#define MSD_ABI_VERSION 9
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -280,6 +280,13 @@ typedef struct MsdAttention {
     int32_t q_prescaled; /* != 0: q already carries the factor scale * log2(e) (folded into the weights of the projection that
                             produced it, minsdtf_amd/models.py), so the kernel takes exp2 of q k^T directly; `scale` is then
                             not applied again.  0: softmax(scale * q k^T) as written above. */
+    /* ABI 9 - head_dim 512 only (the VAE's single-head AttentionBlock, layers.py:28-59): scratch for a 4-way split of the KEY walk,
+     * >= 4 * batch * heads * s * (512 + 2) floats, 16-byte aligned, caller-owned, or NULL.  With it (and t >= 2048, t % 128 == 0) every
+     * query tile is served by four workgroups that each walk a quarter of the keys and a merge launch adds their partial results in
+     * part order (the one head at 512x512 is otherwise 64 workgroups on a 256-CU chip).  Whether the split runs depends on t and on
+     * this pointer only, never on the batch; results with and without it differ in rounding. */
+    float* workspace;
+    int64_t workspace_floats;
 } MsdAttention;
 
 MSD_API int msd_attention(const MsdAttention* p, msd_stream_t stream);

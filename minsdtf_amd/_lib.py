@@ -15,7 +15,7 @@ import weakref
 LIB_NAME = "libminsdtf_hip.so"
 # $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
 LIB_PATH = os.environ.get("MSD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -77,6 +77,7 @@ class MsdAttention(C.Structure):
         ("batch", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32), ("s", C.c_int32), ("t", C.c_int32),
         ("q_ld", C.c_int32), ("k_ld", C.c_int32), ("vt_ld", C.c_int32), ("o_ld", C.c_int32), ("scale", C.c_float),
         ("causal", C.c_int32), ("q_prescaled", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),   # ABI 9: key-split scratch of the d = 512 kernel, or NULL
     ]
 
 

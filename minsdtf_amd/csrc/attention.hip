@@ -30,6 +30,7 @@ struct AArgs {
     int presc;  // q already carries scale * log2(e) (folded into the projection that produced it)
     uint32_t mg_qtiles, mg_heads;   // floor(2^32 / d) for the workgroup-id decomposition (udiv_magic)
     int q_begin, q_count;           // attention32_kernel: the launch covers queries [q_begin, q_begin + q_count) of every sample (mg_qtiles: of that range)
+    float* ws; int nsplit_shift;    // attention512_kernel: key walk split over 1 << nsplit_shift workgroups per query tile, partial (O, m, l) to ws
 };
 
 // Kernarg preload (conv_common.h CG_HOT_PARAMS): the 16 dwords the kernels' prologues need, as leading scalar arguments
@@ -1404,13 +1405,18 @@ __global__ __launch_bounds__(256) void attention512_kernel(const AArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int qtiles = (p.s + 63) / 64;
-    const int wi = xcd_remap(blockIdx.x, qtiles * p.heads * p.batch);
+    // key split (round 5): the VAE's one head at 512x512 is 64 query tiles - a quarter of the chip, each walking all 4096 keys.  With
+    // nsplit = 4 a workgroup walks a quarter of the keys and leaves its unnormalised O, reference maximum and row sum in `ws`;
+    // attn512_merge_kernel adds the parts in part order.  The split follows the KEY COUNT only (host), never the batch.
+    const int wi_all = xcd_remap(blockIdx.x, (qtiles * p.heads * p.batch) << p.nsplit_shift);
+    const int wi = wi_all >> p.nsplit_shift, part = wi_all - (wi << p.nsplit_shift);
     const int bh = udiv_magic(wi, qtiles, p.mg_qtiles);
     const int b = udiv_magic(bh, p.heads, p.mg_heads), h = bh - b * p.heads;
     const int q0 = (wi - bh * qtiles) * 64 + wave * 16;
-    const bf16_t* kbase = p.k + (size_t)b * p.t * p.k_ld + h * D;
-    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld;
-    const int ntiles = p.t / KT;   // (host: t % 32 == 0)
+    const int ntiles = (p.t / KT) >> p.nsplit_shift;   // (host: t % (32 << nsplit_shift) == 0)
+    const int key0 = part * ntiles * KT;
+    const bf16_t* kbase = p.k + ((size_t)b * p.t + key0) * p.k_ld + h * D;
+    const bf16_t* vbase = p.vt + ((size_t)b * p.heads + h) * D * p.vt_ld + key0;
 
     // this wave's share of a tile: key rows 8 wave .. 8 wave + 7 and channel rows 128 wave .. 128 wave + 127
     auto issue_tile = [&](int tile, int stage) {
@@ -1515,8 +1521,21 @@ __global__ __launch_bounds__(256) void attention512_kernel(const AArgs p) {
     float lt = lrun;
     lt += __shfl_xor(lt, 16);
     lt += __shfl_xor(lt, 32);
-    const float inv = 1.0f / lt;
     const int qrow = q0 + r;
+    if (p.nsplit_shift) {   // this part's unnormalised O (fp32), its reference maximum and its row sum
+        if (qrow < p.s) {
+            const size_t rows = (size_t)p.batch * p.heads * p.s, row = ((size_t)b * p.heads + h) * p.s + qrow;
+            float* op = p.ws + ((size_t)part * rows + row) * D;
+#pragma unroll
+            for (int df = 0; df < DF; ++df) *reinterpret_cast<f32x4*>(op + df * 16 + 4 * g) = oacc[df];
+            if (g == 0) {
+                float* st = p.ws + (rows << p.nsplit_shift) * D + ((size_t)part * rows + row) * 2;
+                st[0] = mref; st[1] = lt;
+            }
+        }
+        return;
+    }
+    const float inv = 1.0f / lt;
     if (qrow < p.s) {
         bf16_t* op = p.out + ((size_t)b * p.s + qrow) * p.o_ld + h * D;
 #pragma unroll
@@ -1529,6 +1548,32 @@ __global__ __launch_bounds__(256) void attention512_kernel(const AArgs p) {
     }
 }
 constexpr int ATTN512_LDS = 2 * (32 * 512 * 2 + 512 * 32 * 2);
+
+// out = (sum over the parts, in part order, of 2^((m_part - m) sl2) O_part) / (the same sum of l_part), m = max over the parts:
+// one thread per (row, 4 channels), 128 threads per row
+__global__ __launch_bounds__(256) void attn512_merge_kernel(const float* ws, bf16_t* out, int rows_total, int s, int heads, int o_ld, int nsplit, float sl2) {
+    constexpr int D = 512;
+    const int row = blockIdx.x * 2 + (threadIdx.x >> 7), c = (threadIdx.x & 127) * 4;
+    if (row >= rows_total) return;
+    const float* st = ws + (size_t)nsplit * rows_total * D;
+    float m = st[(size_t)row * 2];
+    for (int pt = 1; pt < nsplit; ++pt) m = fmaxf(m, st[((size_t)pt * rows_total + row) * 2]);
+    float l = 0.f;
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int pt = 0; pt < nsplit; ++pt) {
+        const float* sp = st + ((size_t)pt * rows_total + row) * 2;
+        const float w = __builtin_amdgcn_exp2f((sp[0] - m) * sl2);
+        l += w * sp[1];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + ((size_t)pt * rows_total + row) * D + c);
+        o[0] += w * v[0]; o[1] += w * v[1]; o[2] += w * v[2]; o[3] += w * v[3];
+    }
+    const float inv = 1.0f / l;
+    const int bh = row / s, q = row - bh * s, b = bh / heads, h = bh - b * heads;
+    uint2 r;
+    r.x = pack_bf2(o[0] * inv, o[1] * inv);
+    r.y = pack_bf2(o[2] * inv, o[3] * inv);
+    *reinterpret_cast<uint2*>(out + ((size_t)b * s + q) * o_ld + h * D + c) = r;
+}
 
 // ---- launch configuration ---------------------------------------------------------------------
 template <int D>
@@ -1695,6 +1740,7 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     a.sl2 = q->scale * 1.4426950408889634f;
     a.causal = q->causal ? 1 : 0;
     a.presc = q->q_prescaled ? 1 : 0;
+    a.ws = nullptr; a.nsplit_shift = 0;
     if (a.causal && q->s != q->t) MSD_FAIL(MSD_E_ARG, "attention: causal masking needs s == t");
     // Workgroup size in queries: 128, or 64 when the 128-query grid has fewer workgroups than ~1.5 x the CUs (S = 1024
     // and below at batch 2: 128 / 32 / 8 workgroups).  Measured on one box (us, 128 vs 64 queries per workgroup): S=4096
@@ -1744,7 +1790,21 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
         case 512: {
             if ((q->t % 32) || a.causal || a.presc) MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim 512 needs t %% 32 == 0, no causal mask, no prescaled q");
             a.mg_qtiles = udiv_magic_of((q->s + 63) / 64);
-            hipLaunchKernelGGL(attention512_kernel, dim3(((q->s + 63) / 64) * q->heads * q->batch), dim3(256), ATTN512_LDS, stream, a);
+            // key split: four parts when the caller lent a workspace and every part still walks >= 16 tiles; a function of the key
+            // count alone (the parts are summed in part order: a sample's bits must not follow its batch)
+            const int nsplit = (q->workspace && q->t >= 2048 && (q->t % 128) == 0) ? 4 : 1;
+            const long long rows = (long long)q->batch * q->heads * q->s;
+            if (nsplit > 1 && q->workspace_floats < (long long)nsplit * rows * (512 + 2))
+                MSD_FAIL(MSD_E_WORKSPACE, "attention: head_dim 512 workspace too small (%lld < %lld floats)", (long long)q->workspace_floats,
+                         (long long)nsplit * rows * (512 + 2));
+            if (nsplit > 1 && (((uintptr_t)q->workspace) & 15u)) MSD_FAIL(MSD_E_ALIGN, "attention: workspace must be 16-byte aligned");
+            a.ws = q->workspace; a.nsplit_shift = nsplit == 4 ? 2 : 0;
+            hipLaunchKernelGGL(attention512_kernel, dim3(((q->s + 63) / 64) * q->heads * q->batch * nsplit), dim3(256), ATTN512_LDS, stream, a);
+            if (nsplit > 1) {
+                MSD_CHECK_LAUNCH();
+                hipLaunchKernelGGL(attn512_merge_kernel, dim3((unsigned)((rows + 1) / 2)), dim3(256), 0, stream, (const float*)q->workspace, (bf16_t*)q->out,
+                                   (int)rows, q->s, q->heads, q->o_ld, nsplit, a.sl2);
+            }
             break;
         }
         default: MSD_FAIL(MSD_E_UNSUPPORTED, "attention: head_dim %d (supported: 40, 64, 80, 160, 512)", q->head_dim);

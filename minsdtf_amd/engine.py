@@ -769,6 +769,7 @@ def emit_hintnet(e: Emitter, image_f32, B: int, H: int, W: int, out: Act, copies
 
 # VAE attention: the fused d = 512 kernel (scores stay on chip), or the three-launch route that materialises them
 VAE_FUSED_ATTN = os.environ.get("MSD_VAE_FUSED_ATTN", "1") != "0"   # (env switch: same-box A/B runs)
+VAE_ATTN_SPLIT = os.environ.get("MSD_VAE_ATTN_SPLIT", "1") != "0"   # 4-way key split of the d = 512 attention (env switch: A/B runs)
 
 
 def emit_vae_attention(e: Emitter, x: Act, name: str) -> Act:
@@ -785,9 +786,14 @@ def emit_vae_attention(e: Emitter, x: Act, name: str) -> Act:
     p.free(g)
     o = p.act(B, H, Wd, C)
     if VAE_FUSED_ATTN and C == 512 and S % 32 == 0:
+        # scratch of the kernel's 4-way key split (msd_attention, ABI 9): one head at 512x512 is 64 query tiles on 256 CUs
+        wsf = 4 * B * S * (C + 2) if (VAE_ATTN_SPLIT and S >= 2048 and S % 128 == 0) else 0
+        ws = p.alloc(wsf * 4) if wsf else None
         p.rec(ops.attention, q=q.buf, k=k.buf, vt=vt, out=o.buf, batch=B, heads=1, head_dim=C, s=S, t=S, q_ld=C, k_ld=C, vt_ld=S,
-              o_ld=C, scale=1.0 / float(np.sqrt(C)), name=name + ".attention")
+              o_ld=C, scale=1.0 / float(np.sqrt(C)), workspace=ws, workspace_floats=wsf, name=name + ".attention")
         p.free(q, k, vt)
+        if ws is not None:
+            p.free(ws)
         out = e.conv(o, name + ".proj_attn", C, residual=x)
         p.free(o, x)
         return out

@@ -137,7 +137,7 @@ def layer_norm(*, x, gamma, beta, out, rows, c, eps=1e-5, name="layer_norm") -> 
 
 
 def attention(*, q, k, vt, out, batch, heads, head_dim, s, t, q_ld, k_ld, vt_ld, o_ld, scale, causal=False,
-              q_prescaled=False, name="attention") -> Call:
+              q_prescaled=False, workspace=None, workspace_floats=0, name="attention") -> Call:
     lib = _lib.load()
     a = _lib.MsdAttention()
     a.q, a.k, a.vt, a.out = _p(q), _p(k), _p(vt), _p(out)
@@ -145,6 +145,7 @@ def attention(*, q, k, vt, out, batch, heads, head_dim, s, t, q_ld, k_ld, vt_ld,
     a.q_ld, a.k_ld, a.vt_ld, a.o_ld, a.scale = q_ld, k_ld, vt_ld, o_ld, float(scale)
     a.causal = int(bool(causal))
     a.q_prescaled = int(bool(q_prescaled))
+    a.workspace, a.workspace_floats = _p(workspace), int(workspace_floats)   # (head_dim 512: scratch of the 4-way key split)
     return Call(lib.msd_attention, (C.byref(a),), name, keep=a)
 
 

@@ -767,9 +767,31 @@ def test_attention_d512(gpu, B, S, spike):
     ref = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) @ v
     vt = v.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(gpu)
     out = torch.full((B, S, d), float("nan"), dtype=torch.bfloat16, device=gpu)
-    run_calls(ops.attention(q=q.to(torch.bfloat16).to(gpu), k=k.to(torch.bfloat16).to(gpu), vt=vt, out=out, batch=B, heads=1, head_dim=d,
+    qd, kd = q.to(torch.bfloat16).to(gpu), k.to(torch.bfloat16).to(gpu)
+    run_calls(ops.attention(q=qd, k=kd, vt=vt, out=out, batch=B, heads=1, head_dim=d,
                             s=S, t=T, q_ld=d, k_ld=d, vt_ld=T, o_ld=d, scale=scale))
     close(out, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"d512 B={B} S={S}")
+    # with a workspace the key walk is split four ways (t >= 2048, t % 128 == 0) and merged in part order (ABI 9): the fp32 answer
+    # again, and the same bits for a sample whether it runs alone or in a batch (the split follows the key count only)
+    wsf = 4 * B * S * (d + 2)
+    ws = torch.full((wsf,), float("nan"), dtype=torch.float32, device=gpu)
+    out2 = torch.full((B, S, d), float("nan"), dtype=torch.bfloat16, device=gpu)
+    run_calls(ops.attention(q=qd, k=kd, vt=vt, out=out2, batch=B, heads=1, head_dim=d, s=S, t=T, q_ld=d, k_ld=d, vt_ld=T, o_ld=d, scale=scale,
+                            workspace=ws, workspace_floats=wsf))
+    close(out2, ref, rtol=2e-2, atol=1.5e-2 * max(1.0, float(ref.abs().max())), what=f"d512 split B={B} S={S}")
+    split_ran = T >= 2048 and T % 128 == 0
+    assert bool(torch.isnan(ws).all()) != split_ran, "the key split must run exactly when t >= 2048 and t % 128 == 0"
+    if not split_ran:
+        assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+    if split_ran and B == 1:
+        q3 = torch.cat([qd, torch.randn(2, S, d, device=gpu).to(torch.bfloat16)])
+        k3 = torch.cat([kd, torch.randn(2, T, d, device=gpu).to(torch.bfloat16)])
+        vt3 = torch.cat([vt, torch.randn(2, d, T, device=gpu).to(torch.bfloat16)])
+        ws3 = torch.empty(3 * wsf, dtype=torch.float32, device=gpu)
+        out3 = torch.full((3, S, d), float("nan"), dtype=torch.bfloat16, device=gpu)
+        run_calls(ops.attention(q=q3, k=k3, vt=vt3, out=out3, batch=3, heads=1, head_dim=d, s=S, t=T, q_ld=d, k_ld=d, vt_ld=T, o_ld=d, scale=scale,
+                                workspace=ws3, workspace_floats=3 * wsf))
+        assert torch.equal(out3[0].view(torch.int16), out2[0].view(torch.int16)), "the split result of a sample depends on its batch"
 
 
 @pytest.mark.parametrize("rows,c", [(256, 320), (100, 640), (64, 1280), (7, 2048)])
