@@ -136,8 +136,8 @@ def in_graph_trace(args):
                          f"`python bench.py` that roofline.achieved_in_graph is computed from")
                 trace_family.write_csv(per, keep + f"_bench_kernel_stats{tag}.csv")
                 trace_family.write_md(per, keep + f"_bench_kernel_stats{tag}.md", title, fam)
-            except OSError as e:
-                log(f"in-graph trace: could not keep the trace summary: {e}")
+            except Exception as e:   # (keeping the summary is a convenience of tools/measure_round.sh: never the bench's problem)
+                log(f"in-graph trace: could not keep the trace summary: {type(e).__name__}: {e}")
         return fam
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

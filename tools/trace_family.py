@@ -59,7 +59,7 @@ def write_md(per, path, title, fam=None):
         f.write(f"# rocprofv3 --kernel-trace — {title}\n\n")
         if fam:
             f.write("| family (C-ABI entry point) | dispatches | total ms |" + (" us per fused step |" if "_steps" in fam else "") + "\n|---|---|---|" + ("---|" if "_steps" in fam else "") + "\n")
-            for k, v in sorted(((k, v) for k, v in fam.items() if not k.startswith("_")), key=lambda kv: -kv[1]["total_us"]):
+            for k, v in sorted(((k, v) for k, v in fam.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["total_us"]):
                 f.write(f"| {k} | {v['dispatches']} | {v['total_us'] / 1e3:.3f} |" + (f" {v['us_per_step']:.2f} |" if "_steps" in fam else "") + "\n")
             f.write("\n")
         f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
