@@ -124,14 +124,16 @@ def in_graph_trace(args):
         except SystemExit as e:
             log(f"in-graph trace: {e}")
             return None
-        steps = (loops + 1) * args.denoise_steps
+        # fused steps in the trace = its sampler launches (one per step: loops + 1 replays of the loop, plus the one eager warm-up
+        # step the engine runs before it captures)
+        steps = sum(v[0] for name, v in per.items() if "cfg_step_kernel" in name) or (loops + 1) * args.denoise_steps
         fam = trace_family.summarise(per, steps)
         fam["seconds"] = round(time.time() - t0, 1)
         keep = os.environ.get("MSD_BENCH_KEEP_TRACE")   # tools/measure_round.sh: the same trace becomes profiles/rN_bench_kernel_stats<tag>.{csv,md}
         if keep:
             try:
                 tag = config_tag(args.batch_per_gpu, args.size, args.controlnet)
-                title = (f"kernels of the replayed whole-loop hipGraph, {steps} fused steps ({loops + 1} loops x {args.denoise_steps}), "
+                title = (f"kernels of the replayed whole-loop hipGraph, {steps} fused steps ({loops + 1} loops x {args.denoise_steps} + the eager warm-up step), "
                          f"{args.size}x{args.size}, batch {args.batch_per_gpu}/GPU{', ControlNet' if args.controlnet else ''}: the child pass of "
                          f"`python bench.py` that roofline.achieved_in_graph is computed from")
                 trace_family.write_csv(per, keep + f"_bench_kernel_stats{tag}.csv")
