@@ -137,6 +137,20 @@ __device__ __forceinline__ void dma16sm(const void* sbase, uint32_t voff, uint32
         : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(lanes)
         : "memory");
 }
+// per-lane 64-bit sources under an explicit lane mask (the wave must be fully active at the call)
+__device__ __forceinline__ void dma16m(const void* gsrc, uint32_t lds_dst, uint64_t lanes) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b64 exec, %3\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst), "s"(lanes)
+        : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

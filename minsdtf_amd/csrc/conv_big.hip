@@ -508,6 +508,285 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
 #endif
 }
 
+// ---- halo-image variant: 3x3 / stride 1 / pad 1 convs (optionally behind a nearest x2 upsampling) on 16 x 16-pixel tiles -------------
+// The tap-shifted tiles of the kernel above re-stage every input pixel nine times per 64-channel chunk (9 x 32 KB of A per chunk beside
+// 9 x 20 KB of weights at BN = 160); here a chunk's 18 x 18-pixel halo is staged ONCE (41.5 KB) and the nine taps read it at shifted rows,
+// as conv_halo.hip does - with this file's K loop around it: 256 x BN macro tile, two half-workgroups one barrier apart, two phases per
+// K step (= one tap of one chunk; the wave's image rows in two parts), counted waits.  Vector-memory operations per K step and thread:
+// the WR weight rounds of the step LEAD ahead plus ONE halo-stream operation (round `tap` of the NEXT chunk's halo for taps 0-5 - five
+// 64-row rounds and a 16-row one - and a 1 KB zero-page round into never-read rows otherwise: every step issues the same count, so the
+// waits are compile-time constants).  K order = chunk-major (conv_halo's: for every chunk its nine taps), fragments and epilogue are
+// conv_halo's: the same bits (tests).  Hazards, in the slot count of the header:
+//   W ring   W(kt + LEAD) goes into the buffer W(kt - 1) was read from in phase 0 of step kt - 1 (later half: slot 4 kt - 3); first issued in
+//            slot 4 kt: 3 slots.  RAW: the wait that ends step kt retires W(kt + 1) - issued LEAD steps earlier - and everything older;
+//   halo     chunk c + 1's rounds are issued in phase 1 of taps 0-5 of chunk c into the buffer chunk c - 1 was last read from in phase 1 of
+//            its tap 8 (later half: 3 slots before the earlier half's phase 1 of tap 0); they are older than W(first step of c + 1), which is
+//            issued at tap 9 - LEAD >= 6, so the wait in front of that step retires them.
+template <int BN, int WGM, int WGN, int NBW>
+__global__ __launch_bounds__(512) void conv_bighalo_kernel(CG_HOT_PARAMS, const CGArgs p) {
+    CG_HOT_UNPACK;
+    constexpr int BM = 256, HW_ = 18, HROWS = 18 * 18, HPAD = 336;     // staged halo rows: 5 rounds of 64 + one of 16 (324 real)
+    static_assert(WGM * WGN == 8 && BN % 32 == 0 && BN % (WGN * 16) == 0, "tile");
+    constexpr int WMT = BM / WGM, WNT = BN / WGN, MI = WMT / 16, NJ = WNT / 16, IHS = MI / 2;
+    static_assert(MI % 2 == 0 && MI * WGM == 16, "a wave owns MI image rows of the 16 x 16 tile, read in two parts");
+    constexpr int H_BYTES = HPAD * 128, W_BYTES = BN * 128;
+    constexpr int WRF = BN / 64, WRH = (BN % 64) / 32, WR = WRF + WRH, W0 = (WR + 1) / 2;   // weight rounds per step / those phase 0 issues
+    constexpr int LEAD = NBW - 1;
+    static_assert(LEAD >= 1 && LEAD <= 3, "weight steps in flight (the halo RAW rule needs <= 3)");
+    static_assert(2 * H_BYTES + NBW * W_BYTES <= 160 * 1024, "LDS");
+    constexpr int NWAIT = LEAD + WR * (LEAD - 1);                      // operations younger than the next step's last weight round
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int grp = wave >> 2;
+    const int r = lane & 15, g = lane >> 4;
+    MSD_STAMP(0);
+    const int ups = p.upsample ? 1 : 0;
+    const int Hl = p.h_in << ups, Wl = p.w_in << ups;                  // the image the 3x3 window slides over (= the output image)
+    const int tiles_x = Wl >> 4, tps = tiles_x * (Hl >> 4);
+    const int tile = xcd_remap(blockIdx.x, hot_tiles_m * hot_tiles_n);
+    const int tdiv = hot_m_fast ? hot_tiles_m : hot_tiles_n;
+    const int tq = udiv_magic(tile, tdiv, hot_mg_tdiv), tr = tile - tq * tdiv;
+    const int tile_n = hot_m_fast ? tq : tr;
+    const int tmi = hot_m_fast ? tr : tq;
+    const int b = udiv_magic(tmi, tps, p.mg_tps);
+    const int trem = tmi - b * tps;
+    const int tyi = udiv_magic(trem, tiles_x, p.mg_tx);
+    const int ty0 = tyi * 16, tx0 = (trem - tyi * tiles_x) * 16;
+    const int n0 = tile_n * BN;
+    const int c_begin = blockIdx.y * hot_nk_per;                       // split-K is over 64-channel chunks (host: nk_per in chunks)
+    const int nch = min(p.nkc, c_begin + hot_nk_per) - c_begin;
+    const int nkt = nch * 9;
+
+    // ---- loader coordinates -------------------------------------------------------------------------------------------------------
+    const int cpos = lane & 7, lr8 = lane >> 3;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page) + cpos * 16;
+    // halo round k < 5: halo row 64 k + 8 wave + lr8; round 5: 320 + 2 wave + lr8 on lanes < 16.  hpix = pixel index, -1 outside the image
+    int hpix[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int hrow = k < 5 ? 64 * k + 8 * wave + lr8 : 320 + 2 * wave + (lr8 & 1);
+        const int hy = (hrow * 3641) >> 16, hx = hrow - hy * HW_;      // / 18 for hrow < 336
+        const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;                // in the conv's input image: the x2 image for an upsampling conv
+        const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+        const int pix = (b * p.h_in + (min(max(iy, 0), Hl - 1) >> ups)) * p.w_in + (min(max(ix, 0), Wl - 1) >> ups);   // nearest x2: source pixel (y >> 1, x >> 1)
+        hpix[k] = ok ? pix : -1;
+    }
+    // swizzled source chunk (bytes): key (hrow >> 1) & 7 = (4 wave + (lane >> 4)) & 7 for rounds 0-4, wave & 7 for round 5
+    const uint32_t hsrc = (uint32_t)((cpos ^ ((4 * wave + (lane >> 4)) & 7)) * 16);
+    const uint32_t hsrc5 = (uint32_t)((cpos ^ (wave & 7)) * 16);
+    uint32_t woff[WR];
+#pragma unroll
+    for (int k = 0; k < WR; ++k) {
+        const int q = 64 * k + (k >= WRF ? 4 : 8) * wave + lr8;
+        woff[k] = (uint32_t)min(n0 + q, hot_N - 1) * hot_w_rs + (uint32_t)((cpos ^ ((q >> 1) & 7)) * 16);   // columns past N re-read the last weight row (never stored)
+    }
+    const uint32_t ldsH_wave = lds0 + (uint32_t)(wave * 8) * 128u;
+    const uint32_t ldsH5_wave = lds0 + (uint32_t)(320 + wave * 2) * 128u;
+    const uint32_t ldsW_wave = lds0 + 2u * H_BYTES + (uint32_t)(wave * 8) * 128u;
+    const uint32_t ldsWh_wave = lds0 + 2u * H_BYTES + (uint32_t)(wave * 4) * 128u;
+
+    // source of a chunk's halo: base + pixel * row bytes (wave-uniform per chunk; which tensor of the concat)
+    struct ChunkA { uint64_t sb; uint32_t csrc2; };
+    auto chunk_a = [&](int c) {
+        const int ch = c * 64;
+        const bool first = ch < hot_c0;
+        ChunkA t;
+        t.sb = (uint64_t)(first ? hot_a0 : hot_a1) + (uint64_t)(uint32_t)((first ? ch : ch - hot_c0) * 2);
+        t.csrc2 = (uint32_t)(first ? hot_c0 : hot_c1) * 2u;
+        return t;
+    };
+    auto halo_addr = [&](auto K_, const ChunkA& t, bool live) -> uint64_t {   // branch-free select of the zero page (see addr_a_round above)
+        constexpr int k = decltype(K_)::value;
+        const uint32_t off = __umul24((uint32_t)hpix[k], t.csrc2) + (k < 5 ? hsrc : hsrc5);   // (pixels, row bytes < 2^24: host)
+        const uint32_t m32 = (uint32_t)(~hpix[k] >> 31) & (live ? 0xFFFFFFFFu : 0u);
+        const uint64_t m64 = ((uint64_t)m32 << 32) | m32;
+        return ((t.sb + off) & m64) | ((uint64_t)zero & ~m64);
+    };
+    auto fire_halo = [&](auto K_, uint64_t a, int hb) {
+        constexpr int k = decltype(K_)::value;
+        const uint32_t boff = (uint32_t)hb * (uint32_t)H_BYTES;
+        if constexpr (k < 5) dma16(reinterpret_cast<const void*>(a), ldsH_wave + boff + (uint32_t)k * 8192u);
+        else if constexpr (k == 5) dma16m(reinterpret_cast<const void*>(a), ldsH5_wave + boff, 0xFFFFull);
+        else dma16(zero, lds0 + boff + 328u * 128u);                   // the filler: rows 328-335 are never read
+    };
+    auto issue_w = [&](auto LO_, auto HI_, uint32_t koff, int ib) {    // weight rounds [LO, HI) of one K step
+        constexpr int LO = decltype(LO_)::value, HI = decltype(HI_)::value;
+        const uint32_t boff = (uint32_t)ib * (uint32_t)W_BYTES;
+#pragma unroll
+        for (int k = LO; k < HI; ++k) {
+            // (the step's K offset goes into the scalar base: added to the lane offsets, hipcc hoists the 9 x WR sums out of the chunk loop and spills them)
+            const char* wb = reinterpret_cast<const char*>(hot_w) + koff;
+            if (k < WRF) dma16s(wb, woff[k], ldsW_wave + boff + (uint32_t)k * 8192u);
+            else dma16sm(wb, woff[k], ldsWh_wave + boff + (uint32_t)k * 8192u, 0xFFFFFFFFull);
+        }
+    };
+    auto w_koff = [&](int c, int tap) { return (uint32_t)(tap * p.nkc + c) * hot_w_ks; };   // the weight matrix keeps its (tap, channel) column order
+
+    constexpr int EC = 2, EH = MI / EC;
+    f32x4 acc[EH][NJ][EC];
+#pragma unroll
+    for (int h = 0; h < EH; ++h)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < EC; ++i) acc[h][j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: the first chunk's halo, then the first LEAD steps' weights, each followed by a filler so that every step - these too -
+    //      has put WR + 1 operations into the queue ------------------------------------------------------------------------------------
+    {
+        const ChunkA t = chunk_a(c_begin);
+        fire_halo(std::integral_constant<int, 0>{}, halo_addr(std::integral_constant<int, 0>{}, t, true), 0);
+        fire_halo(std::integral_constant<int, 1>{}, halo_addr(std::integral_constant<int, 1>{}, t, true), 0);
+        fire_halo(std::integral_constant<int, 2>{}, halo_addr(std::integral_constant<int, 2>{}, t, true), 0);
+        fire_halo(std::integral_constant<int, 3>{}, halo_addr(std::integral_constant<int, 3>{}, t, true), 0);
+        fire_halo(std::integral_constant<int, 4>{}, halo_addr(std::integral_constant<int, 4>{}, t, true), 0);
+        fire_halo(std::integral_constant<int, 5>{}, halo_addr(std::integral_constant<int, 5>{}, t, true), 0);
+#pragma unroll
+        for (int tt = 0; tt < LEAD; ++tt) {                            // (nkt >= 9 > LEAD: every one of these steps exists)
+            issue_w(std::integral_constant<int, 0>{}, std::integral_constant<int, WR>{}, w_koff(c_begin, tt), tt);
+            fire_halo(std::integral_constant<int, 6>{}, 0, 1);
+        }
+    }
+    MSD_STAMP(1);
+    wait_vmcnt<1 + (LEAD - 1) * (WR + 1)>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // the second half runs one slot behind the first
+
+    // ---- fragment addressing --------------------------------------------------------------------------------------------------------
+    const int rw = cg_wrow(r);
+    const int woffs = 2 * H_BYTES + (wn * WNT + rw) * 128;
+    const int cw0 = ((g ^ (rw >> 1)) << 4), cw1 = (((4 + g) ^ (rw >> 1)) << 4);
+    bf16x8 af[2][IHS], wf[2][NJ];
+    int fa[IHS];                                   // LDS byte offsets of the next phase's A fragments (ks = 0; ks = 1: ^ 64), prepared in the MFMA slot
+    auto prep_frag = [&](int part, int ky, int kx, int hb) {
+#pragma unroll
+        for (int ii = 0; ii < IHS; ++ii) {
+            const int hr = (wm * MI + part * IHS + ii + ky) * HW_ + kx + r;
+            fa[ii] = hb * H_BYTES + hr * 128 + ((g ^ ((hr >> 1) & 7)) << 4);
+        }
+    };
+    auto load_a = [&]() {
+#pragma unroll
+        for (int ii = 0; ii < IHS; ++ii) {
+            af[0][ii] = *reinterpret_cast<const bf16x8*>(smem + fa[ii]);
+            af[1][ii] = *reinterpret_cast<const bf16x8*>(smem + (fa[ii] ^ 64));
+        }
+    };
+    auto load_w = [&](int rb) {
+        const char* bw = smem + rb * W_BYTES + woffs;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            wf[0][jj] = *reinterpret_cast<const bf16x8*>(bw + jj * 2048 + cw0);
+            wf[1][jj] = *reinterpret_cast<const bf16x8*>(bw + jj * 2048 + cw1);
+        }
+    };
+    auto mfma_part = [&](auto IP_) {               // ks outermost: every accumulator sees the step's two K halves in ascending order
+        constexpr int ip = decltype(IP_)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int ii = 0; ii < IHS; ++ii) {
+                    const int i = ip * IHS + ii;
+                    acc[i / EC][jj][i % EC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][jj], af[ks][ii], acc[i / EC][jj][i % EC], 0, 0, 0);
+                }
+    };
+    auto mfma_slot_open = [&]() {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+    };
+    auto mfma_slot_close = [&]() {
+        // one MFMA, then up to two of the address-arithmetic VALU instructions that ride in the slot
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+        }
+#pragma unroll
+        for (int ii = 0; ii < IHS; ++ii) asm volatile("" : "+v"(fa[ii]));   // (pin: see conv_big_kernel)
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- K loop: chunks x 9 taps x 2 phases -------------------------------------------------------------------------------------------
+    int rb = 0, ib = LEAD % NBW;
+    prep_frag(0, 0, 0, 0);
+    uint64_t ph = 0;                               // source of this step's halo-stream operation, prepared in phase 0's MFMA slot
+    ChunkA nx = chunk_a(c_begin);
+    for (int c = 0; c < nch; ++c) {
+        const int hb = c & 1;
+        const bool has_next = c + 1 < nch;
+        if (has_next) nx = chunk_a(c_begin + c + 1);
+#ifdef MSD_STAMPS
+        if (c == 0) MSD_STAMP(2);
+        if (c == (nch >> 1)) MSD_STAMP(5);
+#endif
+        auto step = [&](auto TAP_) {
+            constexpr int TAP = decltype(TAP_)::value;
+            constexpr int ky = TAP / 3, kx = TAP - ky * 3;
+            constexpr int TAPW = (TAP + LEAD) % 9, CW = (TAP + LEAD) / 9;          // the step whose weights this one issues
+            constexpr int TAPN = (TAP + 1) % 9;
+            const int rem = nkt - 1 - (c * 9 + TAP);
+            const uint32_t koff = w_koff(c_begin + c + CW, TAPW);
+            // -- phase 0: LOAD (all weight fragments, image rows part 0; first weight rounds of step + LEAD), MFMA
+            load_w(rb);
+            load_a();
+            __builtin_amdgcn_sched_barrier(0);
+            if (rem >= LEAD) issue_w(std::integral_constant<int, 0>{}, std::integral_constant<int, W0>{}, koff, ib);
+            mfma_slot_open();
+            prep_frag(1, ky, kx, hb);
+            if constexpr (TAP < 6) ph = halo_addr(std::integral_constant<int, TAP>{}, nx, has_next);
+            mfma_part(std::integral_constant<int, 0>{});
+            if constexpr (TAP < 6) asm volatile("" : "+v"(ph));
+            mfma_slot_close();
+            // -- phase 1: LOAD (image rows part 1; the other weight rounds, the halo-stream operation, the wait for the next step), MFMA
+            load_a();
+            __builtin_amdgcn_sched_barrier(0);
+            if (rem >= LEAD) issue_w(std::integral_constant<int, W0>{}, std::integral_constant<int, WR>{}, koff, ib);
+            if constexpr (TAP < 6) fire_halo(std::integral_constant<int, TAP>{}, ph, hb ^ 1);
+            else fire_halo(std::integral_constant<int, 6>{}, 0, hb ^ 1);
+            if (rem >= LEAD) wait_vmcnt<NWAIT>();
+            else if (rem >= 1) big_wait(LEAD + WR * max(0, min(LEAD - 1, rem - 1)));
+            mfma_slot_open();
+            prep_frag(0, TAPN / 3, TAPN % 3, TAP == 8 ? hb ^ 1 : hb);
+            mfma_part(std::integral_constant<int, 1>{});
+            mfma_slot_close();
+            if (++rb == NBW) rb = 0;
+            if (++ib == NBW) ib = 0;
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // (the first half's extra barrier: both halves have passed the same number)
+    wait_vmcnt<0>();                              // the last fillers still write this workgroup's LDS
+    MSD_STAMP(3);
+
+    auto epilogue_chunk = [&](auto H_) {
+        constexpr int h = decltype(H_)::value;
+        int mrow[EC];
+#pragma unroll
+        for (int i = 0; i < EC; ++i) mrow[i] = (b * Hl + ty0 + wm * MI + h * EC + i) * Wl + tx0;
+        cg_epilogue<EC, NJ, true, false>(p, acc[h], mrow, n0 + wn * WNT, r, g);   // (a spatial tile lies inside one sample)
+    };
+    epilogue_chunk(std::integral_constant<int, 0>{});
+    if constexpr (EH > 1) epilogue_chunk(std::integral_constant<int, 1>{});
+    if constexpr (EH > 2) epilogue_chunk(std::integral_constant<int, 2>{});
+    if constexpr (EH > 3) epilogue_chunk(std::integral_constant<int, 3>{});
+    static_assert(EH <= 4, "epilogue chunks");
+#ifdef MSD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MSD_STAMP(4);
+#endif
+}
+
 // ---- configurations: (BM, BN, WGM, WGN, IH, JH, NB, code); selected by tile_m = 5000 + BM, tile_n = BN, stages = code --------------
 #ifndef MSD_BIG_CFGS
 #define MSD_BIG_CFGS(X)          \
@@ -522,6 +801,15 @@ __global__ __launch_bounds__(512) void conv_big_kernel(CG_HOT_PARAMS, const CGAr
 #endif
 
 constexpr int big_lds(int bm, int bn, int nb) { return nb * (bm + bn) * 128; }   // = BigGeo<...>::LDS
+
+// halo-image configurations: (BN, WGM, WGN, weight ring depth, code); selected by tile_m = 5256, tile_n = BN, stages = 20 + code
+#ifndef MSD_BIGHALO_CFGS
+#define MSD_BIGHALO_CFGS(X) \
+    X(160, 4, 2, 3, 0)      \
+    X(128, 4, 2, 3, 0)      \
+    X(128, 4, 2, 4, 1)
+#endif
+constexpr int bighalo_lds(int bn, int nbw) { return 2 * 336 * 128 + nbw * bn * 128; }
 
 static bool g_big_attr_done = false;
 static int msd_conv_big_init() {
@@ -538,6 +826,12 @@ static int msd_conv_big_init() {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_big_kernel<bm, bn, wgm, wgn, ih, jh, nb, 2>),             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, big_lds(bm, bn, nb));
     MSD_BIG_CFGS(X)
+#undef X
+#define X(bn, wgm, wgn, nbw, code)                                                                                            \
+    if (e == hipSuccess)                                                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bighalo_kernel<bn, wgm, wgn, nbw>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bighalo_lds(bn, nbw));
+    MSD_BIGHALO_CFGS(X)
 #undef X
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_big): %s", hipGetErrorString(e));
     g_big_attr_done = true;
@@ -573,4 +867,29 @@ int msd_conv_big_launch(const CGArgs& a, int bm, int bn, int code, int slices, b
     MSD_BIG_CFGS(X)
 #undef X
     MSD_FAIL(MSD_E_UNSUPPORTED, "conv_big: no %d x %d configuration with code %d", bm, bn, code);
+}
+
+// ---- halo-image variant: host side ------------------------------------------------------------------------------------------------
+int msd_conv_bighalo_nj(int bn, int code) {
+#define X(bn_, wgm, wgn, nbw, code_) if (bn == bn_ && code == code_) return bn_ / wgn / 16;
+    MSD_BIGHALO_CFGS(X)
+#undef X
+    return 0;
+}
+
+// Launch for an already validated argument block (3x3 / stride 1 / pad 1, h_in and w_in multiples of 16, no shortcut operand; tiles_m =
+// batch x 16x16-pixel tiles, mg_tps / mg_tx set, nk_per in 64-channel CHUNKS: msd_conv_gemm).
+int msd_conv_bighalo_launch(const CGArgs& a, int bn, int code, int slices, hipStream_t stream) {
+    int rc = msd_conv_big_init();
+    if (rc) return rc;
+    const dim3 grid(a.tiles_m * a.tiles_n, slices);
+#define X(bn_, wgm, wgn, nbw, code_)                                                                                          \
+    if (bn == bn_ && code == code_) {                                                                                         \
+        hipLaunchKernelGGL((conv_bighalo_kernel<bn_, wgm, wgn, nbw>), grid, dim3(512), bighalo_lds(bn_, nbw), stream,         \
+                           CG_HOT_ARGS(a), a);                                                                                \
+        return MSD_OK;                                                                                                        \
+    }
+    MSD_BIGHALO_CFGS(X)
+#undef X
+    MSD_FAIL(MSD_E_UNSUPPORTED, "conv_big: no halo-image configuration 256 x %d with code %d", bn, code);
 }

@@ -40,7 +40,7 @@ struct CGArgs {
     const int hot_tiles_m = (int)(hot_pk_tiles & 0x7FFFFFu), hot_tiles_n = (int)((hot_pk_tiles >> 23) & 0xFFu);                \
     const int hot_m_fast = (int)(hot_pk_tiles >> 31);                                                                          \
     const int hot_nk_per = (int)(hot_pk_nk & 0xFFFFu), hot_nk = (int)(hot_pk_nk >> 16);                                        \
-    (void)hot_c1; (void)hot_a1; (void)hot_w_rs; (void)hot_w_ks
+    (void)hot_c1; (void)hot_a1; (void)hot_w_rs; (void)hot_w_ks; (void)hot_nk
 static inline bool cg_hot_ok(const CGArgs& a) {
     return a.c0 >= 0 && a.c0 < 65536 && a.c1 >= 0 && a.c1 < 65536 && a.tiles_m > 0 && a.tiles_m < (1 << 23) && a.tiles_n > 0 && a.tiles_n < 256 &&
            a.nk_per > 0 && a.nk_per < 65536 && a.nk > 0 && a.nk < 65536;

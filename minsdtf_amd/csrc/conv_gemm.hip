@@ -346,6 +346,8 @@ int msd_conv_wreg_nj(int bm, int bn, int stages);   // 16-column blocks per wave
 int msd_conv_wreg_launch(const CGArgs& a, int bm, int bn, int stages, int slices, bool dense, hipStream_t stream);
 int msd_conv_big_nj(int bm, int bn, int code);      // conv_big.hip: 16-column blocks per wave of a built configuration, 0: not built
 int msd_conv_big_launch(const CGArgs& a, int bm, int bn, int code, int slices, bool dense, hipStream_t stream);
+int msd_conv_bighalo_nj(int bn, int code);              // conv_big.hip, halo-image variant (tile_m 5256, stages 20 + code)
+int msd_conv_bighalo_launch(const CGArgs& a, int bn, int code, int slices, hipStream_t stream);
 // tile_m ranges of the forms (one predicate each, mirrored by minsdtf_amd/tuning.py form_of): [1000, 3000) halo tiles, [3000, 4000)
 // row panels, [4000, 5000) wreg, [5000, 6000) big; anything from 6000 up is refused
 static inline bool cg_is_wreg(int tile_m) { return tile_m >= 4000 && tile_m < 5000; }
@@ -490,16 +492,27 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     if (q->tile_m >= 6000 || q->tile_m < 0) MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_m %d names no kernel form", q->tile_m);
     const bool wreg = cg_is_wreg(q->tile_m), big = cg_is_big(q->tile_m);
     // big form, stages code + 10: chunk-major K walk (the halo-tile kernel's order and numerics class)
-    const bool big_km = big && q->stages >= 10;
-    const int big_code = big_km ? q->stages - 10 : q->stages;
+    // stages code + 20: the same walk on a staged 18 x 18-pixel halo per chunk (3x3 / stride 1 / pad 1 on whole 16 x 16-pixel tiles)
+    const bool big_hi = big && q->stages >= 20;
+    const bool big_km = big && q->stages >= 10 && !big_hi;
+    const int big_code = big_hi ? q->stages - 20 : (big_km ? q->stages - 10 : q->stages);
     if (big) {
-        if (big_km && (q->ksize != 3 || q->a2)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the chunk-major walk of the big-tile form is for 3x3 convs without a shortcut operand");
-        if (!msd_conv_big_nj(q->tile_m - 5000, q->tile_n, big_code))
+        if ((big_km || big_hi) && (q->ksize != 3 || q->a2)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the chunk-major walk of the big-tile form is for 3x3 convs without a shortcut operand");
+        if (big_hi) {
+            if (q->tile_m != 5256 || !msd_conv_bighalo_nj(q->tile_n, big_code))
+                MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: no halo-image big-tile configuration %d x %d code %d", q->tile_m - 5000, q->tile_n, big_code);
+            const int up = q->upsample ? 2 : 1;
+            if (q->stride != 1 || q->pad != 1 || q->h_out != up * q->h_in || q->w_out != up * q->w_in || (q->h_out % 16) || (q->w_out % 16))
+                MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the halo-image big-tile form runs 3x3 / stride 1 / pad 1 convs on output images of whole 16 x 16-pixel tiles (%d x %d)", q->h_out, q->w_out);
+        } else if (!msd_conv_big_nj(q->tile_m - 5000, q->tile_n, big_code))
             MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: no big-tile configuration %d x %d code %d", q->tile_m - 5000, q->tile_n, big_code);
         if (q->ln_out) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the big-tile form has no LayerNorm-producer epilogue (ln_out)");
         // its general loader forms pixel * row bytes with a 24-bit multiply
         if ((long long)q->batch * q->h_in * q->w_in >= (1ll << 24) || (long long)(q->c0 > q->c1 ? q->c0 : q->c1) * 2 >= (1ll << 24))
             MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: big-tile form needs fewer than 2^24 input pixels");
+        // ... and keeps the product in 32 bits
+        if ((long long)q->batch * q->h_in * q->w_in * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 >= (1ll << 32) - 4096)
+            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: big-tile form needs input tensors under 4 GB");
     }
     if (wreg != (q->w_layout == 2))
         MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_m %d with w_layout %d (the fragment-major weight image, w_layout 2, is read by the wreg form, tile_m 4000 + rows, and by nothing else)",
@@ -539,14 +552,14 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         if (ok) halo_th = th;
     }
     a.kmajor = big_km ? 1 : 0;
-    if (halo_th || big_km) {  // split-K is over 64-channel chunks (each = 9 K steps)
+    if (halo_th || big_km || big_hi) {  // split-K is over 64-channel chunks (each = 9 K steps)
         if (splitk > a.nkc) splitk = a.nkc;
         a.nk_per = (a.nkc + splitk - 1) / splitk;
     } else {
         if (splitk > a.nk) splitk = a.nk;
         a.nk_per = (a.nk + splitk - 1) / splitk;
     }
-    const int slices = (halo_th || big_km) ? (a.nkc + a.nk_per - 1) / a.nk_per : (a.nk + a.nk_per - 1) / a.nk_per;
+    const int slices = (halo_th || big_km || big_hi) ? (a.nkc + a.nk_per - 1) / a.nk_per : (a.nk + a.nk_per - 1) / a.nk_per;
     a.nslices = slices;
     if (big_km) a.nk_per *= 9;   // (the big form counts K tiles, nine per chunk)
     if (slices > 1) {
@@ -597,6 +610,23 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
             MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the LayerNorm fold, GEGLU and the q|k|v^T split run on the 1x1 / Dense form only");
         if (!cg_hot_ok(a)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: tile / K-tile / channel counts beyond the packed launch arguments (K tiles, channels < 65536; row tiles < 2^23; column tiles < 256)");
         rc = msd_conv_wreg_launch(a, wbm, wbn, q->stages, slices, dense, stream);
+        if (rc) return rc;
+        MSD_CHECK_LAUNCH();
+        if (slices > 1) {
+            launch_finalize(a, slices, stream);
+            MSD_CHECK_LAUNCH();
+        }
+        return MSD_OK;
+    }
+    if (big_hi) {   // the big form on a staged halo: conv_big.hip (conv_bighalo_kernel); nk_per stays in chunks
+        a.tiles_m = a.batch * (a.h_out / 16) * (a.w_out / 16);
+        a.tiles_n = (a.N + q->tile_n - 1) / q->tile_n;
+        a.m_fast = (a.N > a.M) ? 1 : 0;
+        a.mg_tdiv = udiv_magic_of(a.m_fast ? a.tiles_m : a.tiles_n);
+        a.mg_tps = udiv_magic_of((a.h_out / 16) * (a.w_out / 16));
+        a.mg_tx = udiv_magic_of(a.w_out / 16);
+        if (!cg_hot_ok(a)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: tile / K-tile / channel counts beyond the packed launch arguments (K tiles, channels < 65536; row tiles < 2^23; column tiles < 256)");
+        rc = msd_conv_bighalo_launch(a, q->tile_n, big_code, slices, stream);
         if (rc) return rc;
         MSD_CHECK_LAUNCH();
         if (slices > 1) {

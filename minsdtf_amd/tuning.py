@@ -49,6 +49,8 @@ WREG_TILES = ((4128, 128, 3), (4128, 128, 4), (4128, 64, 3), (4128, 64, 4), (406
 BIG_TILES = ((5256, 256, 0), (5256, 160, 0), (5256, 160, 1), (5256, 160, 2), (5256, 128, 0), (5256, 128, 1), (5128, 256, 0), (5128, 256, 1))
 # ... code + 10: the chunk-major K walk = the halo-tile kernel's order of sums (3x3, stride 1, no upsampling, no shortcut operand): its numerics class
 BIG_TILES_CHUNK_MAJOR = ((5256, 256, 10), (5256, 160, 10), (5256, 160, 11), (5256, 128, 10), (5128, 256, 10))
+# ... code + 20: the same walk over a staged 18 x 18-pixel halo per chunk (also pad 1, h_in and w_in multiples of 16; csrc/conv_big.hip conv_bighalo_kernel)
+BIG_TILES_HALO_IMAGE = ((5256, 160, 20), (5256, 128, 20), (5256, 128, 21))
 BIG_MIN_ROWS = 4096   # rows (M) below which the tuner does not try the big form
 
 

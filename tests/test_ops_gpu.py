@@ -180,6 +180,17 @@ def conv_ref(x_nhwc, w_hwio, bias=None, stride=1, pad=1, upsample=False):
     dict(B=3, H=16, W=16, c0=320, N=320, ks=3, tile_m=5256, tile_n=160, stages=11, same_as=(1128, 80, 0)),              # 45 K steps
     dict(B=2, H=16, W=16, c0=256, N=256, ks=3, splitk=2, tile_m=5256, tile_n=256, stages=10, same_as=(1128, 64, 0)),    # split over chunks: 2 + 2
     dict(B=2, H=16, W=16, c0=320, N=160, ks=3, splitk=2, tile_m=5256, tile_n=160, stages=10, same_as=(1128, 80, 0)),    # 5 chunks in slices of 3 + 2
+    # big form on a staged halo (stages 20 + code): 16x16-pixel tiles, every chunk's 18x18 halo staged once - again conv_halo's bits
+    dict(B=2, H=16, W=16, c0=64, N=160, ks=3, tile_m=5256, tile_n=160, stages=20, same_as=(1128, 80, 0)),               # ONE chunk: nothing to prefetch but fillers; every border
+    dict(B=1, H=32, W=48, c0=192, N=128, ks=3, tile_m=5256, tile_n=128, stages=20, same_as=(1128, 64, 0)),              # 2 x 3 tiles: interior borders read neighbours, 3 chunks
+    dict(B=3, H=16, W=32, c0=320, N=320, ks=3, tile_m=5256, tile_n=160, stages=20, same_as=(1128, 80, 0)),              # 5 chunks (both halo buffers reused), 2 column tiles
+    dict(B=1, H=16, W=32, c0=64, c1=64, N=100, ks=3, tile_m=5256, tile_n=128, stages=21, same_as=(1128, 64, 0)),        # one chunk per tensor of the concat, ragged N, weight ring of 4
+    dict(B=2, H=32, W=16, c0=128, c1=192, N=272, ks=3, tile_m=5256, tile_n=160, stages=20, same_as=(1128, 80, 0)),      # concat boundary inside the walk, N = 17 blocks (ragged second column tile)
+    dict(B=2, H=16, W=16, c0=320, N=160, ks=3, splitk=2, tile_m=5256, tile_n=160, stages=20, same_as=(1128, 80, 0)),    # 5 chunks in slices of 3 + 2
+    dict(B=2, H=16, W=16, c0=256, N=256, ks=3, splitk=4, tile_m=5256, tile_n=128, stages=21, same_as=(1128, 64, 0)),    # one chunk per slice
+    dict(B=2, H=16, W=16, c0=128, N=128, ks=3, f32out=True, act="silu", tile_m=5256, tile_n=128, stages=20, same_as=(1128, 64, 0)),
+    dict(B=2, H=8, W=8, c0=128, c1=64, N=256, ks=3, upsample=True, tile_m=5256, tile_n=128, stages=20, same_as=(5256, 128, 10)),   # nearest x2 in the halo staging (one 16x16 tile per sample)
+    dict(B=1, H=16, W=24, c0=64, N=160, ks=3, upsample=True, tile_m=5256, tile_n=160, stages=20, same_as=(5256, 160, 11)),          # 2 x 3 tiles of the 32 x 48 image
     dict(B=2, H=16, W=16, c0=128, c1=192, N=256, ks=3, tile_m=5128, tile_n=256, stages=10, same_as=(1256, 128, 0)),     # concat boundary inside the walk
 ])
 def test_conv_gemm(gpu, case):

@@ -139,8 +139,10 @@ def tune_one(shape, iters=10, only=None, sks_only=None):
     # big form (256-row macro tiles): not for the LayerNorm-producer Dense layers (K = N, 1x1: it has no ln_out epilogue)
     if M >= tuning.BIG_MIN_ROWS and not (ks == 1 and allow_split and cin == N and not cx) and not os.environ.get("MSD_TUNE_NO_BIG"):
         cands += [t for t in tuning.BIG_TILES if not (t[1] == 160 and N % 160) and not (t[1] > 128 and N <= 128)]
-        if ks == 3 and stride == 1 and not ups and not cx:   # ... walking K chunk-major: the halo-tile kernel's class
+        if ks == 3 and stride == 1 and not cx:   # ... walking K chunk-major: the halo-tile kernel's class
             cands += [t for t in tuning.BIG_TILES_CHUNK_MAJOR if not (t[1] == 160 and N % 160) and not (t[1] > 128 and N <= 128)]
+            if hl % 16 == 0 and wl % 16 == 0:   # ... on a staged halo (whole 16 x 16-pixel output tiles)
+                cands += [t for t in tuning.BIG_TILES_HALO_IMAGE if not (t[1] == 160 and N % 160) and not (t[1] > 128 and N <= 128)]
     if only is not None:
         cands = [t for t in cands if only(t)]
     frag = None
