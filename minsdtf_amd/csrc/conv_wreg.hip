@@ -18,6 +18,7 @@
 // cdna_hip_programming.md §5 "Three .s-level traps" (b)); both queues are counted by hand: one group = AR LDS-DMAs + 2 NJ
 // register loads per K tile, `s_waitcnt vmcnt((S - 2) x group)` retires the oldest group, and an empty asm statement naming
 // the destination registers keeps every consumer below that wait (§5.7 form (ii)).
+#include <type_traits>
 #include "conv_common.h"
 
 typedef uint32_t wr_u32x4 __attribute__((ext_vector_type(4)));
@@ -248,13 +249,18 @@ __global__ __launch_bounds__(NW * 64) void conv_wreg_kernel(CG_HOT_PARAMS, const
     }
 
     MSD_STAMP(3);
-#pragma unroll
-    for (int h = 0; h < EH; ++h) {
+    auto epilogue_chunk = [&](auto H_) {   // (explicit instances: a loop that hipcc does not unroll sends acc[h] to scratch)
+        constexpr int h = decltype(H_)::value;
         int mrow[EC];
 #pragma unroll
         for (int i = 0; i < EC; ++i) mrow[i] = m0 + wm * WMT + (h * EC + i) * 16;
         cg_epilogue<EC, NJ, false, DENSE>(p, acc[h], mrow, n0 + wn * NJ * 16, r, g, reinterpret_cast<float*>(smem), wn, WGN, wm * WMT + h * EC * 16, BM, tile_n);
-    }
+    };
+    epilogue_chunk(std::integral_constant<int, 0>{});
+    if constexpr (EH > 1) epilogue_chunk(std::integral_constant<int, 1>{});
+    if constexpr (EH > 2) epilogue_chunk(std::integral_constant<int, 2>{});
+    if constexpr (EH > 3) epilogue_chunk(std::integral_constant<int, 3>{});
+    static_assert(EH <= 4, "epilogue chunks");
 #ifdef MSD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
     MSD_STAMP(4);

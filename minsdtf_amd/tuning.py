@@ -52,6 +52,7 @@ BIG_TILES_CHUNK_MAJOR = ((5256, 256, 10), (5256, 160, 10), (5256, 160, 11), (525
 # ... code + 20: the same walk over a staged 18 x 18-pixel halo per chunk (also pad 1, h_in and w_in multiples of 16; csrc/conv_big.hip conv_bighalo_kernel)
 BIG_TILES_HALO_IMAGE = ((5256, 160, 20), (5256, 128, 20), (5256, 128, 21))
 BIG_MIN_ROWS = 4096   # rows (M) below which the tuner does not try the big form
+HALO_IMAGE_MIN_ROWS = 512   # ... its halo-image variant (one 16 x 16-pixel tile per sample at the 16x16 level, split-K over chunks)
 
 
 def is_halo(tile_m: int) -> bool:
@@ -132,9 +133,11 @@ def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_spli
                 ent = [128] + list(ent[1:])
             if is_big(int(ent[0])) and M < BIG_MIN_ROWS:   # (a 256-row macro tile on a small launch: the same class on small tiles)
                 stg = int(ent[3]) if len(ent) > 4 else 0
-                if stg >= 10 and w_in % 16 == 0 and h_in % 8 == 0:
+                if stg >= 10 and not upsample and stride == 1 and w_in % 16 == 0 and h_in % 8 == 0:
                     ent = [1128, 80 if N % 80 == 0 else 64, int(ent[2]), 0, 0.0]
-                elif stg < 10:
+                elif stg >= 10:   # (an upsampling layer of the chunk-major class: the halo-tile kernel does not take it; the big form walks any M)
+                    ent = [5256, 128, int(ent[2]), 10, 0.0]
+                else:
                     ent = [128, 128 if N % 128 == 0 else 64, int(ent[2]), 0, 0.0]
     if ent is not None:
         bm, bn, sk = int(ent[0]), int(ent[1]), int(ent[2])

@@ -27,7 +27,7 @@ def main():
         pad = 1 if ks == 3 else 0
         hl, wl = (2 * h_in, 2 * w_in) if ups else (h_in, w_in)
         M = batch * ((hl + 2 * pad - ks) // stride + 1) * ((wl + 2 * pad - ks) // stride + 1)
-        if M < tuning.BIG_MIN_ROWS:
+        if M < int(os.environ.get("BIG_BENCH_MIN_ROWS", tuning.BIG_MIN_ROWS)):
             continue
         key = tuning.shape_key(*s)
         tag = "vae" if (cin in (128, 256, 512) and N in (128, 256, 512)) or h_in >= 128 else ("768" if h_in in (96, 48, 24, 12) and w_in == h_in else ("b4" if batch == 8 else ("b2" if batch == 4 else "b1")))

@@ -58,7 +58,7 @@ def main():
             if s[7] and s[5] == 3 and s[6] == 1 and not s[9] and (args.only is None or re.search(args.only, key)):
                 groups.setdefault(key.split("x", 1)[1], []).append(key)
         for rest, keys in sorted(groups.items()):
-            if any(rows_of(parse_key(k)) < tuning.BIG_MIN_ROWS for k in keys):
+            if any(rows_of(parse_key(k)) < tuning.HALO_IMAGE_MIN_ROWS for k in keys):
                 continue
             plan, ok_all, any_gain = {}, True, False
             for key in keys:
@@ -98,7 +98,7 @@ def main():
         pad = 1 if ks == 3 else 0
         hl, wl = (2 * h_in, 2 * w_in) if ups else (h_in, w_in)
         M = batch * ((hl + 2 * pad - ks) // stride + 1) * ((wl + 2 * pad - ks) // stride + 1)
-        if M < tuning.BIG_MIN_ROWS or N < 64:
+        if M < (tuning.HALO_IMAGE_MIN_ROWS if args.halo_image else tuning.BIG_MIN_ROWS) or N < 64:
             continue
         tm, tn, sk, stg = int(ent[0]), int(ent[1]), int(ent[2]), int(ent[3]) if len(ent) > 4 else 0
         if tuning.is_big(tm) and not (args.halo_image and stg < 20):
