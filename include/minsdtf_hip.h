@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 9
+#define MSD_ABI_VERSION 10
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -228,8 +228,12 @@ MSD_API int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
  *             asynchronous), so the CALLER must read sync[8] once per job, after the work has completed, and treat a
  *             non-zero word as a failed job (minsdtf_amd/engine.py: check_gn_sync raises HipExtensionError).  Never observed
  *             under in-order dispatch.  Without `sync`: statistics + apply launches, no exchange, no flag.
+ *             Samples of >= 9216 pixels (msd_set_option "gn_rows"; 4096 pays from batch 2 per GPU) whose parts fit in registers take the
+ *             ROW-MAJOR form of the same exchange: 4-64 workgroups per SAMPLE, each owning a contiguous pixel range with all its
+ *             channels (16-byte accesses), 64 granules per part; it shares the block (second region of every sample's share)
+ *             and the give-up word.  (ABI 10: the share grew from 6,144 to 16,384 words for it.)
  */
-#define MSD_GN_SYNC_WORDS_PER_SAMPLE (3 * 32 * 64)
+#define MSD_GN_SYNC_WORDS_PER_SAMPLE 16384
 #define MSD_GN_MAX_CHUNKS 1024
 typedef struct MsdGroupNorm {
     const void* x0;

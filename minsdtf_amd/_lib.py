@@ -15,7 +15,7 @@ import weakref
 LIB_NAME = "libminsdtf_hip.so"
 # $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
 LIB_PATH = os.environ.get("MSD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -175,6 +175,11 @@ def load() -> C.CDLL:
     if lib.msd_abi_version() != ABI_VERSION:
         raise HipExtensionError(f"ABI version mismatch: library {lib.msd_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
+    # serving choice: MSD_GN_ROWS=4096 puts the 64x64-level GroupNorms on the row-major cluster form - faster from two images per
+    # GPU, slower at one; a process-wide arithmetic choice (a sample's bits do not depend on its batch under either setting)
+    if os.environ.get("MSD_GN_ROWS"):
+        if lib.msd_set_option(b"gn_rows", int(os.environ["MSD_GN_ROWS"])) != 0:
+            raise HipExtensionError(f"MSD_GN_ROWS={os.environ['MSD_GN_ROWS']}: {lib.msd_last_error().decode(errors='replace')}")
     global _shutdown_registered
     if not _shutdown_registered:
         atexit.register(shutdown)

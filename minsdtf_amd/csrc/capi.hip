@@ -27,6 +27,7 @@ void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
 void msd_set_gn_cluster(int v);
+void msd_set_gn_rows(int v);
 void msd_set_gn_poll_limit(int v);
 void msd_set_attn_qf(int v);
 void msd_set_xattn_nw(int v);
@@ -60,6 +61,11 @@ extern "C" int msd_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "gn_wide") == 0) {   // 1 = 1024-thread GroupNorm workgroups for mid-sized tensors [default]
         msd_set_gn_wide(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "gn_rows") == 0) {   // row-major cluster GroupNorm for samples of at least this many pixels [default 9216; 4096 pays at batch >= 2 per GPU]; 0 = never
+        if (value < 0) MSD_FAIL(MSD_E_ARG, "set_option: gn_rows takes a pixel count >= 0, got %d", value);
+        msd_set_gn_rows(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "gn_cluster") == 0) {   // pixels per part of the cluster GroupNorm (P = pixels / this, a power of two <= 8) [default 256]; 0 = never

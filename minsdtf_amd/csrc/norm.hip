@@ -367,6 +367,12 @@ __global__ __launch_bounds__(1024) void gn_group_kernel(GN_HOT_PARAMS, const GNA
 // resident and every other resident group completes; should the dispatch ever be out of order the poll is BOUNDED (it gives
 // up, raises the block's error word and the launch finishes with wrong numbers instead of hanging the GPU).
 constexpr int GN_SYNC_WORDS_PER_SLOT = 64;   // [0] ticket, [8] error, [16..31] sum granules, [32..47] sum-of-squares granules
+// A sample's share of the sync block (MSD_GN_SYNC_WORDS_PER_SAMPLE): 3 x 32 slots of the per-(sample, group) cluster form, then the
+// region of the row-major form (gn_rows_kernel): one header slot (ticket at [0]) and up to 64 parts x 64 granules of 8 bytes
+constexpr int GN_SYNC_GROUP_WORDS = 3 * 32 * GN_SYNC_WORDS_PER_SLOT;
+constexpr int GN_ROWS_MAX_PARTS = 64;
+constexpr int GN_SYNC_SAMPLE_WORDS = 16384;
+static_assert(GN_SYNC_GROUP_WORDS + GN_SYNC_WORDS_PER_SLOT + GN_ROWS_MAX_PARTS * 64 * 2 <= GN_SYNC_SAMPLE_WORDS, "sync layout");
 constexpr int GN_POLL_LIMIT = 1 << 18;   // default bound of the exchange poll (set_option "gn_poll_limit": tests shorten it)
 
 template <int NPT, int V>
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int psh
     if (t < 64) {   // wave 0: publish this part's moments, collect all P parts (lane j polls part j), sum them in part order
         // (slot-major, one 64-word block per P: where a block lies does not depend on the batch of the launch, so launches
         //  of different batch sizes that share a sync block still keep one counter per (sample, group, P))
-        uint32_t* blk = sync_region + ((size_t)slot * 3 + (pshift - 1)) * GN_SYNC_WORDS_PER_SLOT;
+        uint32_t* blk = sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + ((size_t)g * 3 + (pshift - 1)) * GN_SYNC_WORDS_PER_SLOT;
         unsigned long long* ga = reinterpret_cast<unsigned long long*>(blk + 16);
         unsigned long long* gq = reinterpret_cast<unsigned long long*>(blk + 32);
         uint32_t epoch = 0;
@@ -487,6 +493,155 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int psh
     }
 }
 
+// ---- single-launch GroupNorm, ROW-MAJOR parts: a workgroup owns a pixel range of a sample with ALL its channels ---------------------
+// The per-(sample, group) forms above read a group's 2-20 channels of every pixel: 4-40 bytes out of every 128-byte line, and 32 workgroups
+// fetch each line once each (gn_cluster<4,1> at the 64x64 level, batch 4: 23.7 us for 42 MB).  Here a workgroup's part is ONE contiguous
+// block of memory, read with 16-byte accesses (thread = one 8-channel chunk of a pixel row, the same chunk for all its pixels); it
+// reduces per-channel moments through LDS, folds them into the 32 groups' moments, publishes 64 tagged granules and collects the other
+// parts' (the exchange of gn_cluster_kernel, 64 values per part instead of 2), then normalises from registers: one read, one write.
+// The parts are summed in part order and P depends on the sample's size only, so a sample's bits do not depend on its batch.
+template <int NPT>
+__global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, const bf16_t* hot_x1, int hot_C, int hot_hw, int hot_c0, int hot_c1,
+                                                       int cpr, int rows, uint32_t mg_cpr, int pshift, int ppart, const GNArgs p,
+                                                       uint32_t* sync_region, int poll_limit) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int t = threadIdx.x, T = cpr * rows;
+    float* red = reinterpret_cast<float*>(smem_raw);         // [T][16]: per thread 8 sums, 8 sums of squares
+    float* chan = red + (size_t)T * 16;                      // [2][C]
+    float* parts = chan + 2 * hot_C;                         // [P][64]
+    float* tot = parts + ((size_t)64 << pshift);             // [64]: 32 sums, 32 sums of squares of the whole sample
+    float* stat = tot + 64;                                  // [32][2] mean, rstd
+    uint32_t* s_epoch = reinterpret_cast<uint32_t*>(stat + 64);
+    const int P = 1 << pshift;
+    const int part = blockIdx.x & (P - 1), b = blockIdx.x >> pshift;
+    const int row = udiv_magic(t, cpr, mg_cpr), ch = t - row * cpr;
+    const bool active = t < T;
+    const int px0 = part * ppart, px1 = min(hot_hw, px0 + ppart);
+    const int c = ch * 8;
+    const size_t row0 = (size_t)b * hot_hw;
+    const bool first = c < hot_c0;
+    const int sstride = first ? hot_c0 : hot_c1;
+    const bf16_t* src = first ? hot_x0 + row0 * hot_c0 + c : hot_x1 + row0 * hot_c1 + (c - hot_c0);
+
+    union { uint4 v; uint32_t w[4]; } x[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int px = px0 + row + k * rows;
+        if (active && px < px1) x[k].v = *reinterpret_cast<const uint4*>(src + (size_t)px * sstride);
+        else x[k].v = make_uint4(0u, 0u, 0u, 0u);
+    }
+    float gm[8], bt[8];
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gm[e] = p.gamma[c + e]; bt[e] = p.beta[c + e]; }
+    }
+    uint32_t ticket = 0;
+    // (every launch adds exactly 64 to the sample's ticket - 64 / P per workgroup - whatever its P: ticket / 64 + 1 is the same number in the
+    //  P workgroups of a launch and larger than in every earlier launch, of any P, that wrote these granules)
+    if (t == 0) ticket = __hip_atomic_fetch_add(sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS, 64u >> pshift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (active) {
+        float sm[8], sq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = bf_lo(x[k].w[e]), hi = bf_hi(x[k].w[e]);
+                sm[2 * e] += lo; sm[2 * e + 1] += hi;
+                sq[2 * e] += lo * lo; sq[2 * e + 1] += hi * hi;
+            }
+        float4* rp = reinterpret_cast<float4*>(red + (size_t)t * 16);
+        rp[0] = make_float4(sm[0], sm[1], sm[2], sm[3]); rp[1] = make_float4(sm[4], sm[5], sm[6], sm[7]);
+        rp[2] = make_float4(sq[0], sq[1], sq[2], sq[3]); rp[3] = make_float4(sq[4], sq[5], sq[6], sq[7]);
+    }
+    if (t == 0) *s_epoch = (ticket >> 6) + 1u;
+    __syncthreads();
+    // per-channel moments of the part: channel cc, moment m <- sum over the pixel rows (fixed order)
+    for (int j = t; j < 2 * hot_C; j += 1024) {
+        const int m = j >= hot_C ? 1 : 0, cc = j - m * hot_C;
+        const float* q = red + (size_t)(cc >> 3) * 16 + (cc & 7) + 8 * m;
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a += q[(size_t)r * cpr * 16];
+        chan[j] = a;
+    }
+    __syncthreads();
+    const uint32_t epoch = *s_epoch;
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS + GN_SYNC_WORDS_PER_SLOT);
+    if (t < 64) {   // group moments of the part: published as {value, epoch} granules
+        const int cpg = hot_C >> 5, g = t & 31, m = t >> 5;
+        const float* q = chan + m * hot_C + g * cpg;
+        float a = 0.f;
+        for (int e = 0; e < cpg; ++e) a += q[e];
+        __hip_atomic_store(gran + (size_t)part * 64 + t, ((unsigned long long)epoch << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // collect the P x 64 granules of the sample (thread i: granules i, i + 1024, .. - at most 4, polled TOGETHER: a poll is a round trip
+    // to the memory side); bounded, as in gn_cluster_kernel
+    {
+        const int ng = 64 << pshift;
+        unsigned long long v[4] = {0, 0, 0, 0};
+        bool done[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) done[k] = t + 1024 * k >= ng;
+        for (int it = 0; it < poll_limit; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!done[k]) v[k] = __hip_atomic_load(gran + t + 1024 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!done[k]) done[k] = (uint32_t)(v[k] >> 32) == epoch;
+            if (done[0] && done[1] && done[2] && done[3]) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!(done[0] && done[1] && done[2] && done[3])) { sync_region[(size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS + 8] = 1u; sync_region[8] = 1u; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t + 1024 * k < ng) parts[t + 1024 * k] = __uint_as_float((uint32_t)v[k]);
+    }
+    __syncthreads();
+    if (t < 64) {   // the sample's moments: parts in part order, ((p0 + p1) + p2) + ...
+        float a = 0.f;
+        for (int j = 0; j < P; ++j) a += parts[j * 64 + t];
+        tot[t] = a;
+    }
+    __syncthreads();
+    if (t < 32) {
+        const float cnt = (float)p.hw * (float)(hot_C >> 5);
+        const float mean = tot[t] / cnt;
+        const float var = fmaxf(tot[32 + t] / cnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        stat[2 * t] = mean; stat[2 * t + 1] = rstd;
+        if (part == 0) {
+            p.stats[((size_t)b * 32 + t) * 2 + 0] = mean;
+            p.stats[((size_t)b * 32 + t) * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = udiv_magic(c + e, hot_C >> 5, p.mg_cpg);
+        const float mean = stat[2 * g], rstd = stat[2 * g + 1];
+        gm[e] *= rstd; bt[e] -= mean * gm[e];
+    }
+    bf16_t* dst = p.out + row0 * p.C + c;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int px = px0 + row + k * rows;
+        if (px < px1) {
+            union { uint4 v; uint32_t w[4]; } o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float lo = bf_lo(x[k].w[e]) * gm[2 * e] + bt[2 * e];
+                float hi = bf_hi(x[k].w[e]) * gm[2 * e + 1] + bt[2 * e + 1];
+                if (p.silu) { lo = silu_f(lo); hi = silu_f(hi); }
+                o.w[e] = pack_bf2(lo, hi);
+            }
+            *reinterpret_cast<uint4*>(dst + (size_t)px * p.C) = o.v;
+        }
+    }
+}
+
 static int g_gn_poll_limit = GN_POLL_LIMIT;
 void msd_set_gn_poll_limit(int v) { g_gn_poll_limit = v; }
 
@@ -517,6 +672,10 @@ static int g_gn_wide = 1;  // 1 = 1024-thread stats / apply workgroups for mid-s
 static int g_gn_cluster = 256;    // pixels per part the cluster kernel aims at: P = largest power of two <= pixels / this, at most 8
                                   // (P = 1: the one-workgroup kernel); 0 = never the cluster kernel (A/B runs)
 void msd_set_gn_cluster(int v) { g_gn_cluster = v; }
+static int g_gn_rows = 9216;      // row-major parts (gn_rows_kernel) for samples of at least this many PIXELS; 0 = never (A/B runs).
+                                  // 4096 adds the 64x64 level: same-box loop -1.7 % at batch 4, -0.7 % at batch 2, +0.6 % at batch 1 (2 samples
+                                  // x 32 parts = 64 workgroups pull 80 KB each: a quarter of the chip's requests in flight) - a serving choice
+void msd_set_gn_rows(int v) { g_gn_rows = v; }
 void msd_set_gn_impl(int v) { g_gn_impl = v; }
 void msd_set_gn_wide(int v) { g_gn_wide = v; }
 
@@ -543,6 +702,40 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
     a.mg_tpp = udiv_magic_of(a.tpp);
     a.mg_cpg = udiv_magic_of(C / 32);
     a.silu = q->silu ? 1 : 0; a.eps = q->eps;
+    // row-major parts: samples of >= g_gn_rows pixels (default: 96x96 at 768^2 and up) whose part fits in registers;
+    // smaller samples are latency chains, where this form's longer chain (LDS reductions, 64 granules per part) loses: tools/gn_bench.py
+    if (g_gn_rows > 0 && g_gn_cluster && q->sync && q->hw >= g_gn_rows && a.cv <= 512) {
+        const int cpr = a.cv, rows = 1024 / cpr;
+        int pshift = 2;
+        while (pshift <= 6 && (((q->hw + (1 << pshift) - 1) >> pshift) + rows - 1) / rows > 6) ++pshift;
+        if (pshift <= 6) {
+            const int P = 1 << pshift;
+            const int ppart = (q->hw + P - 1) / P;
+            const int npt = (ppart + rows - 1) / rows;
+            const long long need = (long long)q->batch * GN_SYNC_SAMPLE_WORDS;
+            if (q->sync_words < need)
+                MSD_FAIL(MSD_E_WORKSPACE, "group_norm: sync block too small (%lld < %lld words)", (long long)q->sync_words, need);
+            if (((uintptr_t)q->sync) & 7u) MSD_FAIL(MSD_E_ALIGN, "group_norm: sync must be 8-byte aligned");
+            const size_t lds = ((size_t)cpr * rows * 16 + 2 * (size_t)C + ((size_t)64 << pshift) + 64 + 64 + 4) * sizeof(float);
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_rows_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_rows_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(gn_rows): %s", hipGetErrorString(e));
+                attr_done = true;
+            }
+            const dim3 grid((unsigned)q->batch << pshift);
+            const uint32_t mgc = udiv_magic_of(cpr);
+#define GN_ROWS_LAUNCH(N_) hipLaunchKernelGGL((gn_rows_kernel<N_>), grid, dim3(1024), lds, stream, a.x0, a.x1, a.C, a.hw, a.c0, a.c1, cpr, rows, mgc, pshift, ppart, a, q->sync, g_gn_poll_limit)
+            if (npt <= 2) GN_ROWS_LAUNCH(2);
+            else if (npt <= 4) GN_ROWS_LAUNCH(4);
+            else GN_ROWS_LAUNCH(6);
+#undef GN_ROWS_LAUNCH
+            MSD_CHECK_LAUNCH();
+            return MSD_OK;
+        }
+    }
     {
         // single-launch path: V = words per thread-unit (widest that divides the group's run), at most
         // 24 units per thread (register budget of a 1024-thread workgroup: 128 VGPRs)
@@ -562,7 +755,7 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
                 const int P = 1 << pshift;
                 const int ppart = (q->hw + P - 1) / P;
                 const int nptc = (ppart + ppp - 1) / ppp;
-                const long long need = (long long)3 * q->batch * 32 * GN_SYNC_WORDS_PER_SLOT;
+                const long long need = (long long)q->batch * GN_SYNC_SAMPLE_WORDS;
                 if (nptc <= (V == 4 ? 8 : 16) && (long long)q->batch * 32 * P < (1ll << 30)) {
                     if (q->sync_words < need)
                         MSD_FAIL(MSD_E_WORKSPACE, "group_norm: sync block too small (%lld < %lld words)", (long long)q->sync_words, need);

@@ -113,7 +113,7 @@ def conv_direct(*, x, w, out, batch, h_in, w_in, c_in, c_out, ksize=3, stride=1,
 GN_MAX_CHUNKS = 1024
 
 
-GN_SYNC_WORDS_PER_SAMPLE = 3 * 32 * 64   # MSD_GN_SYNC_WORDS_PER_SAMPLE
+GN_SYNC_WORDS_PER_SAMPLE = 16384   # MSD_GN_SYNC_WORDS_PER_SAMPLE
 
 
 def group_norm(*, x0, gamma, beta, stats, partials, out, batch, hw, c0, x1=None, c1=0, silu=False, eps=1e-5,

@@ -640,9 +640,12 @@ def test_group_norm(gpu, case):
     dict(B=2, hw=1024, c0=640, silu=True, opt=256),      # the 32x32 level on 4 parts (gn_cluster = 256 pixels per part)
     dict(B=2, hw=256, c0=1280, silu=True, opt=128),      # ... and the 16x16 level on 2
 ])
-def test_group_norm_cluster(gpu, case):
+@pytest.mark.parametrize("form", ["groups", "rows"])
+def test_group_norm_cluster(gpu, case, form):
     """GroupNorm as ONE launch in which 2 / 4 / 8 workgroups share a (sample, group) slab and exchange partial moments through the
-    caller's sync block (norm.hip gn_cluster_kernel): against fp32 group_norm; the same bits on every repetition (each launch
+    caller's sync block (norm.hip gn_cluster_kernel), or - form "rows", gn_rows_kernel - 4-64 workgroups share a SAMPLE by pixel range,
+    all channels each (the threshold is lowered so that every case whose parts fit in registers takes it; the 128x128 x 512 case does
+    not and stays on the group form): against fp32 group_norm; the same bits on every repetition (each launch
     runs under a new epoch of the same counters), for a sample alone and inside a batch (with the SAME sync block, so the
     block's layout may not depend on the batch), and with launches of another part count in between; no workgroup ever gave
     up waiting (error words stay 0)."""
@@ -670,6 +673,7 @@ def test_group_norm_cluster(gpu, case):
 
     lib = _lib.load()
     lib.msd_set_option(b"gn_cluster", case.get("opt", 256))
+    lib.msd_set_option(b"gn_rows", 1 if form == "rows" else 0)
     try:
         outs = [torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=d) for _ in range(3)]
         run_calls([launch(o) for o in outs])                       # three epochs back to back on one stream
@@ -695,19 +699,28 @@ def test_group_norm_cluster(gpu, case):
         assert bool(torch.isfinite(half.float()).all())
         assert torch.equal(one[0].view(torch.int16), outs[0][last].view(torch.int16)), "a sample's bits depend on its batch"
         assert torch.equal(again.view(torch.int16), outs[0].view(torch.int16))
-        assert int(sync.view(-1, 64)[:, 8].max()) == 0, "a workgroup gave up waiting for its group's partial moments"
+        # (error words: word 8 of the 96 group slots and of the row-major form's header slot of every sample; behind them lie granules)
+        assert int(sync.view(B, -1, 64)[:, :97, 8].max()) == 0, "a workgroup gave up waiting for its group's partial moments"
+        rows_ran = int(sync.view(B, -1)[:, 3 * 32 * 64].max()) > 0     # the row-major form's ticket: first word behind the 96 group slots
+        rows_per_pass = 1024 // (C // 8)     # (eligible: some P in 4 .. 64 leaves a thread at most 6 pixels; the half-size launch counts too)
+        fits = any(-(-(-(-n // P)) // rows_per_pass) <= 6 for n in (hw, hw // 2) for P in (4, 8, 16, 32, 64))
+        assert rows_ran == (form == "rows" and fits), "which form ran"
     finally:
         lib.msd_set_option(b"gn_cluster", 256)
+        lib.msd_set_option(b"gn_rows", 9216)
 
 
-def test_group_norm_cluster_give_up_is_loud(gpu):
-    """The cluster GroupNorm's bounded poll (norm.hip gn_cluster_kernel) must never end in a silently wrong image: a ticket
+@pytest.mark.parametrize("form", ["groups", "rows"])
+def test_group_norm_cluster_give_up_is_loud(gpu, form):
+    """The cluster GroupNorm's bounded poll (norm.hip gn_cluster_kernel; form "rows": gn_rows_kernel, whose 32 workgroups per sample add 2
+    each to ONE ticket) must never end in a silently wrong image: a ticket
     counter knocked off its multiple-of-P phase makes one workgroup of a group wait for an epoch nobody publishes; it gives
     up (poll bound shortened through set_option so the test takes milliseconds), raises word [8] of the sync block, and the
     engine's once-per-job check (engine.check_gn_sync) turns that into HipExtensionError and clears the word."""
     from minsdtf_amd import _lib, engine, ops
 
     lib = _lib.load()
+    lib.msd_set_option(b"gn_rows", 4096 if form == "rows" else 0)
     B, H, W, C = 1, 64, 64, 320
     plan = engine.Plan(gpu)
     e = engine.Emitter(plan, {"n.g": torch.ones(C, device=gpu), "n.b": torch.zeros(C, device=gpu)})
@@ -722,10 +735,15 @@ def test_group_norm_cluster_give_up_is_loud(gpu):
     good = y.buf.tensor(torch.bfloat16, (B, H * W, C)).clone()
     words = plan._gn_sync_buf.tensor(torch.int32, (B * ops.GN_SYNC_WORDS_PER_SAMPLE,)).view(-1, 64)
     used = torch.nonzero(words[:, 0]).flatten()
-    assert used.numel() == 32, "the cluster form did not run (one ticket counter per group expected)"
-    P = int(words[used[5], 0])                           # one launch added exactly P to the counter
-    assert P in (2, 4, 8)
-    words[used[5], 0] += 1                               # group 5: the P tickets of the next launch straddle two epochs
+    if form == "rows":   # (behind slot 96 lie granules, not counters)
+        assert int(torch.count_nonzero(words[:96, 0])) == 0 and int(words[96, 0]) == 64, "the row-major form did not run (one ticket per sample, 64 per launch)"
+        used, P, knock = [96] * 6, 63, 2                 # 32 workgroups x 2: off by 2, the last ticket of the next launch lands in the next epoch
+    else:
+        assert used.numel() == 32, "the cluster form did not run (one ticket counter per group expected)"
+        P = int(words[used[5], 0])                           # one launch added exactly P to the counter
+        assert P in (2, 4, 8)
+        knock = 1
+    words[used[5], 0] += knock                           # group 5: the P tickets of the next launch straddle two epochs
     lib.msd_set_option(b"gn_poll_limit", 256)
     try:
         plan.run(st)
@@ -752,11 +770,13 @@ def test_group_norm_cluster_give_up_is_loud(gpu):
         close(y2.buf.tensor(torch.bfloat16, (B, H * W, C)).float().cpu(), good.float().cpu(), what="three-launch GroupNorm after the give-up")
         # the groups that were not disturbed still carry the right numbers
         got = y.buf.tensor(torch.bfloat16, (B, H * W, C))
-        assert torch.equal(got[..., :50].view(torch.int16), good[..., :50].view(torch.int16))
+        if form == "groups":
+            assert torch.equal(got[..., :50].view(torch.int16), good[..., :50].view(torch.int16))
     finally:
         lib.msd_set_option(b"gn_poll_limit", 1 << 18)
         lib.msd_set_option(b"gn_cluster", 256)           # (the default: the rest of the suite runs the cluster kernel again)
-        words[used[5], 0] += P - 1                       # back on a multiple of P (the plan dies with the test anyway)
+        lib.msd_set_option(b"gn_rows", 9216)
+        words[used[5], 0] += P - knock if form == "rows" else P - 1   # back on a multiple (the plan dies with the test anyway)
 
 
 @pytest.mark.parametrize("B,S,spike", [(1, 4096, False), (2, 320, True), (1, 9216, False), (1, 64, False), (3, 200, False)])
