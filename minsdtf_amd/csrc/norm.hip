@@ -395,6 +395,16 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int psh
     const int sstride = first ? hot_c0 : hot_c1;
     const bf16_t* src = first ? hot_x0 + row0 * hot_c0 + c : hot_x1 + row0 * hot_c1 + (c - hot_c0);
 
+    // (slot-major, one 64-word block per P: where a block lies does not depend on the batch of the launch, so launches
+    //  of different batch sizes that share a sync block still keep one counter per (sample, group, P))
+    uint32_t* blk = sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + ((size_t)g * 3 + (pshift - 1)) * GN_SYNC_WORDS_PER_SLOT;
+    // the ticket is drawn FIRST: its round trip to the memory side (~1.5 us) then runs beside the loads and the reduction instead of
+    // between the reduction and the publication
+    uint32_t ticket = 0;
+    const bool early = poll_limit > 0;   // (A/B switch: a negative poll bound = draw the ticket where it is needed, as before round 5)
+    if (!early) poll_limit = -poll_limit;
+    if (early && t == 0) ticket = __hip_atomic_fetch_add(blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
     union { vec_t v; uint32_t w[V]; } x[NPT];
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
@@ -423,9 +433,6 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int psh
     if ((t & 63) == 0) { red[t >> 6][0] = s; red[t >> 6][1] = ss; }
     __syncthreads();
     if (t < 64) {   // wave 0: publish this part's moments, collect all P parts (lane j polls part j), sum them in part order
-        // (slot-major, one 64-word block per P: where a block lies does not depend on the batch of the launch, so launches
-        //  of different batch sizes that share a sync block still keep one counter per (sample, group, P))
-        uint32_t* blk = sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + ((size_t)g * 3 + (pshift - 1)) * GN_SYNC_WORDS_PER_SLOT;
         unsigned long long* ga = reinterpret_cast<unsigned long long*>(blk + 16);
         unsigned long long* gq = reinterpret_cast<unsigned long long*>(blk + 32);
         uint32_t epoch = 0;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int psh
             float a = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < 16; ++w) { a += red[w][0]; q += red[w][1]; }
-            const uint32_t ticket = __hip_atomic_fetch_add(blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!early) ticket = __hip_atomic_fetch_add(blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             epoch = (ticket >> pshift) + 1u;
             __hip_atomic_store(ga + part, ((unsigned long long)epoch << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gq + part, ((unsigned long long)epoch << 32) | __float_as_uint(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -644,16 +651,18 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
 
 static int g_gn_poll_limit = GN_POLL_LIMIT;
 void msd_set_gn_poll_limit(int v) { g_gn_poll_limit = v; }
+static int g_gn_ticket_early = 1;   // 1 = the cluster form draws its ticket at kernel start [default], 0 = after the reduction (A/B)
+void msd_set_gn_ticket_early(int v) { g_gn_ticket_early = v; }
 
 template <int V>
 static void gn_cluster_launch(const GNArgs& a, int upp, int npt, dim3 grid, int pshift, int ppart, uint32_t* region, hipStream_t stream) {
     const dim3 block(1024);
     const int ppp = 1024 / upp;
     const uint32_t mg = udiv_magic_of(upp);
-    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
-    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
-    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
-    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
+    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_ticket_early ? g_gn_poll_limit : -g_gn_poll_limit);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_ticket_early ? g_gn_poll_limit : -g_gn_poll_limit);
+    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_ticket_early ? g_gn_poll_limit : -g_gn_poll_limit);
+    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_ticket_early ? g_gn_poll_limit : -g_gn_poll_limit);
 }
 
 template <int V>
