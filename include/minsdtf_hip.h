@@ -146,7 +146,10 @@ typedef struct MsdConvGemm {
                             big form (tile_m 5000 + rows): a configuration code, not a depth: 5256x256:0 (2 x 2 quadrant phases, 2 K-tile
                             buffers) 5256x160:0/1/2 (quadrants x 3 buffers / row halves x 3 / quadrants x 2) 5256x128:0/1 5128x256:0/1
                             (row halves / quadrants, 3 buffers); + 10 = the same configuration walking K chunk-major (3x3 convs without a
-                            shortcut operand only): the halo-tile kernel's order of sums, hence ITS bits instead of the tile kernel's */
+                            shortcut operand only): the halo-tile kernel's order of sums, hence ITS bits instead of the tile kernel's;
+                            20 + code with tile_m 5256 = that chunk-major walk over a STAGED 18 x 18-pixel halo per 64-channel chunk
+                            (3x3 / stride 1 / pad 1, with or without `upsample`, h_out and w_out multiples of 16; otherwise
+                            MSD_E_UNSUPPORTED): 5256x160:20 5256x128:20/21 (weight ring of 3 / 4) */
     const float* ln_in;      /* float2 [M][ln_in_slots] row-moment partials of the input rows, or NULL */
     const float* ln_colsum;  /* [N]: sum_k W[n][k] of the gamma-folded bf16 weights (with ln_in) */
     float* ln_out;           /* float2 [M][ln_out_slots] row-moment partials of the stored output, or NULL */
