@@ -28,7 +28,6 @@ void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
 void msd_set_gn_cluster(int v);
 void msd_set_gn_rows(int v);
-void msd_set_gn_ticket_early(int v);
 void msd_set_gn_poll_limit(int v);
 void msd_set_attn_qf(int v);
 void msd_set_xattn_nw(int v);
@@ -62,10 +61,6 @@ extern "C" int msd_set_option(const char* key, int value) {
     }
     if (key && strcmp(key, "gn_wide") == 0) {   // 1 = 1024-thread GroupNorm workgroups for mid-sized tensors [default]
         msd_set_gn_wide(value);
-        return MSD_OK;
-    }
-    if (key && strcmp(key, "gn_ticket_early") == 0) {   // cluster GroupNorm: 1 = ticket drawn at kernel start [default], 0 = after the reduction (same bits)
-        msd_set_gn_ticket_early(value ? 1 : 0);
         return MSD_OK;
     }
     if (key && strcmp(key, "gn_rows") == 0) {   // row-major cluster GroupNorm for samples of at least this many pixels [default 9216; 4096 pays at batch >= 2 per GPU]; 0 = never

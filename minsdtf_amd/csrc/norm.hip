@@ -398,12 +398,14 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int psh
     // (slot-major, one 64-word block per P: where a block lies does not depend on the batch of the launch, so launches
     //  of different batch sizes that share a sync block still keep one counter per (sample, group, P))
     uint32_t* blk = sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + ((size_t)g * 3 + (pshift - 1)) * GN_SYNC_WORDS_PER_SLOT;
-    // the ticket is drawn FIRST: its round trip to the memory side (~1.5 us) then runs beside the loads and the reduction instead of
-    // between the reduction and the publication
+    // The ticket's round trip to the memory side (~1.5-2 us) sat between the reduction and the publication.  With 8- and 16-byte units (the
+    // slabs whose loads take at least as long) it is drawn FIRST and runs beside the loads: 64x64 x 640 10.1 -> 8.2 us, the VAE's 64x64 x 512
+    // 9.2 -> 7.4.  Not with 4-byte units: vector-memory results return in order, so wave 0 then stands at its first use of the loaded data
+    // until the ticket is back (64x64 x 320: 7.2 -> 7.6 us); drawn behind the loads it gained nothing either.
     uint32_t ticket = 0;
-    const bool early = poll_limit > 0;   // (A/B switch: a negative poll bound = draw the ticket where it is needed, as before round 5)
-    if (!early) poll_limit = -poll_limit;
+    constexpr bool early = V >= 2;   // (compile-time: behind a test of a kernel ARGUMENT the atomic waits for the argument load and the head start is gone)
     if (early && t == 0) ticket = __hip_atomic_fetch_add(blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory");   // (the loads below stay below: hipcc is free to move them across a relaxed atomic, and did)
 
     union { vec_t v; uint32_t w[V]; } x[NPT];
 #pragma unroll
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int psh
             float a = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < 16; ++w) { a += red[w][0]; q += red[w][1]; }
-            if (!early) ticket = __hip_atomic_fetch_add(blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (!early) ticket = __hip_atomic_fetch_add(blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             epoch = (ticket >> pshift) + 1u;
             __hip_atomic_store(ga + part, ((unsigned long long)epoch << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(gq + part, ((unsigned long long)epoch << 32) | __float_as_uint(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -651,18 +653,16 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
 
 static int g_gn_poll_limit = GN_POLL_LIMIT;
 void msd_set_gn_poll_limit(int v) { g_gn_poll_limit = v; }
-static int g_gn_ticket_early = 1;   // 1 = the cluster form draws its ticket at kernel start [default], 0 = after the reduction (A/B)
-void msd_set_gn_ticket_early(int v) { g_gn_ticket_early = v; }
 
 template <int V>
 static void gn_cluster_launch(const GNArgs& a, int upp, int npt, dim3 grid, int pshift, int ppart, uint32_t* region, hipStream_t stream) {
     const dim3 block(1024);
     const int ppp = 1024 / upp;
     const uint32_t mg = udiv_magic_of(upp);
-    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_ticket_early ? g_gn_poll_limit : -g_gn_poll_limit);
-    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_ticket_early ? g_gn_poll_limit : -g_gn_poll_limit);
-    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_ticket_early ? g_gn_poll_limit : -g_gn_poll_limit);
-    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_ticket_early ? g_gn_poll_limit : -g_gn_poll_limit);
+    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
+    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
+    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
 }
 
 template <int V>
