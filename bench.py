@@ -788,7 +788,7 @@ def kernel_roofline(sd, b, nsteps, control=False, size=512):
             break
         except (OSError, ValueError):
             continue
-    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> / dense_rowpanel_kernel<*> / conv_wreg_kernel<*> / conv_big_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
+    roof = {"bound": "mfma", "kernel": "conv_gemm_dma_kernel<*> / conv3x3_halo_kernel<*> / dense_rowpanel_kernel<*> / conv_wreg_kernel<*> / conv_big_kernel<*> / conv_bighalo_kernel<*> + splitk_finalize (implicit-GEMM conv3x3/1x1/dense, bf16 MFMA 16x16x32)",
             "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
             "achieved_is": "back to back: the step's conv / dense calls alone under one HIP-event pair (no norm / attention launches between them)",
             "traffic": traffic, "traffic_source": traffic_src, "traffic_read_write": traffic_rw, "launches_per_unet_step": int(round(n)), "avg_launch_us": round(avg_ms * 1e3, 2),

@@ -1105,3 +1105,16 @@ def test_argument_errors(gpu):
     o = torch.zeros(64, 64, dtype=torch.bfloat16, device=gpu)
     with pytest.raises(_lib.HipExtensionError):
         run_calls(ops.conv_gemm(a0=x, w=w, out=o, batch=1, h_in=8, w_in=8, c0=48, N=64))
+    # the big form on a staged halo works on whole 16 x 16-pixel output tiles of a 3x3 / stride-1 conv and takes no shortcut operand: anything else
+    # is refused, never run on another kernel (its numerics class is part of the request)
+    x64 = torch.zeros(1, 24, 16, 64, dtype=torch.bfloat16, device=gpu)
+    w9 = torch.zeros(128, 9 * 64, dtype=torch.bfloat16, device=gpu)
+    o24 = torch.zeros(24 * 16, 128, dtype=torch.bfloat16, device=gpu)
+    for kw, what in [(dict(h_in=24, w_in=16), "halo-image"),                       # 24 rows: one and a half tiles
+                     (dict(h_in=16, w_in=16, stride=2), "halo-image"),
+                     (dict(h_in=16, w_in=16, stages=29), "halo-image"),            # no such configuration
+                     (dict(h_in=16, w_in=16, tile_m=5128), "halo-image")]:
+        args = dict(a0=x64, w=w9, out=o24, batch=1, c0=64, N=128, ksize=3, tile_m=5256, tile_n=128, stages=20)
+        args.update(kw)
+        with pytest.raises(_lib.HipExtensionError, match=what):
+            run_calls(ops.conv_gemm(**args))
