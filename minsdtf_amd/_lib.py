@@ -177,9 +177,10 @@ def load() -> C.CDLL:
     _lib = lib
     # serving choice: MSD_GN_ROWS=4096 puts the 64x64-level GroupNorms on the row-major cluster form - faster from two images per
     # GPU, slower at one; a process-wide arithmetic choice (a sample's bits do not depend on its batch under either setting)
-    if os.environ.get("MSD_GN_ROWS"):
-        if lib.msd_set_option(b"gn_rows", int(os.environ["MSD_GN_ROWS"])) != 0:
-            raise HipExtensionError(f"MSD_GN_ROWS={os.environ['MSD_GN_ROWS']}: {lib.msd_last_error().decode(errors='replace')}")
+    gn_rows = os.environ.get("MSD_GN_ROWS") or ("4096" if os.environ.get("MSD_PROFILE") == "throughput" else "")
+    if gn_rows:
+        if lib.msd_set_option(b"gn_rows", int(gn_rows)) != 0:
+            raise HipExtensionError(f"MSD_GN_ROWS={gn_rows}: {lib.msd_last_error().decode(errors='replace')}")
     global _shutdown_registered
     if not _shutdown_registered:
         atexit.register(shutdown)

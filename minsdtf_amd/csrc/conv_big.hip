@@ -767,6 +767,54 @@ __global__ __launch_bounds__(512) void conv_bighalo_kernel(CG_HOT_PARAMS, const 
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // (the first half's extra barrier: both halves have passed the same number)
     wait_vmcnt<0>();                              // the last fillers still write this workgroup's LDS
+
+    // ---- shortcut operand (ResBlock: conv2(h) + conv_shortcut(x) as one contraction): after the slice's main chunks, its share of the
+    //      64-channel chunks of a2 | a3, read at the OUTPUT pixel - one K step each on a plain 256-row tile (16 x 16 pixels x 128 B, staged in
+    //      the halo buffers; weights in two slots of the ring).  Both halves in lock step, one step of lead: these steps are <= a quarter of
+    //      the walk.  The slice's extras come AFTER its main chunks and the extras are dealt over the slices in order: part of the numerics
+    //      class (the only kernel that walks a shortcut-folded conv chunk-major).
+    const int nxc = p.nk - p.nk_main;
+    if (nxc > 0) {
+        const int eps = (nxc + p.nslices - 1) / p.nslices;
+        const int e0 = min(nxc, (int)blockIdx.y * eps), e1 = min(nxc, e0 + eps);
+        const int cx3 = p.K - p.nk_main * 64 - p.c2;   // channels of a3
+        auto issue_extra = [&](int e, int slot) {
+            const int ce = e * 64;
+            const bool first = ce < p.c2;
+            const uint64_t sb = (uint64_t)(first ? p.a2 : p.a3) + (uint64_t)(uint32_t)((first ? ce : ce - p.c2) * 2);
+            const uint32_t cs2 = (uint32_t)(first ? p.c2 : cx3) * 2u;
+            const uint32_t base = __builtin_amdgcn_readfirstlane(ldsH_wave + (uint32_t)slot * (uint32_t)H_BYTES);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // row q = 64 k + 8 wave + lr8 of the tile = pixel (q >> 4, q & 15); same swizzle key as the halo rounds
+                const int q = 64 * k + 8 * wave + lr8;
+                const int pix = (b * Hl + ty0 + (q >> 4)) * Wl + tx0 + (q & 15);
+                dma16(reinterpret_cast<const void*>(sb + (__umul24((uint32_t)pix, cs2) + hsrc)), base + (uint32_t)k * 8192u);
+            }
+            issue_w(std::integral_constant<int, 0>{}, std::integral_constant<int, WR>{}, (uint32_t)(p.nk_main + e) * hot_w_ks, slot);
+        };
+        auto prep_xfrag = [&](int part, int slot) {
+#pragma unroll
+            for (int ii = 0; ii < IHS; ++ii) {
+                const int q = (wm * MI + part * IHS + ii) * 16 + r;
+                fa[ii] = slot * H_BYTES + q * 128 + ((g ^ ((q >> 1) & 7)) << 4);
+            }
+        };
+        int slot = 0;
+        if (e0 < e1) issue_extra(e0, 0);
+        for (int e = e0; e < e1; ++e) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // this step's operands have landed for every wave; the other slot's readers are past their MFMAs
+            if (e + 1 < e1) issue_extra(e + 1, slot ^ 1);
+            load_w(slot);
+            prep_xfrag(0, slot);
+            load_a();
+            mfma_part(std::integral_constant<int, 0>{});
+            prep_xfrag(1, slot);
+            load_a();
+            mfma_part(std::integral_constant<int, 1>{});
+            slot ^= 1;
+        }
+    }
     MSD_STAMP(3);
 
     auto epilogue_chunk = [&](auto H_) {

@@ -497,7 +497,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     const bool big_km = big && q->stages >= 10 && !big_hi;
     const int big_code = big_hi ? q->stages - 20 : (big_km ? q->stages - 10 : q->stages);
     if (big) {
-        if ((big_km || big_hi) && (q->ksize != 3 || q->a2)) MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the chunk-major walk of the big-tile form is for 3x3 convs without a shortcut operand");
+        if ((big_km || big_hi) && (q->ksize != 3 || (q->a2 && !big_hi)))
+            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: the chunk-major walk of the big-tile form is for 3x3 convs (with a shortcut operand: on the staged-halo variant only)");
         if (big_hi) {
             if (q->tile_m != 5256 || !msd_conv_bighalo_nj(q->tile_n, big_code))
                 MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: no halo-image big-tile configuration %d x %d code %d", q->tile_m - 5000, q->tile_n, big_code);

@@ -15,6 +15,7 @@ import re
 from typing import Dict, Optional, Tuple
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning.json")
+_PROFILE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning_throughput.json")
 _table: Optional[Dict[str, list]] = None
 _families: Optional[Dict[str, Dict[int, list]]] = None   # batch-agnostic key -> {batch: entry}
 
@@ -52,7 +53,7 @@ BIG_TILES_CHUNK_MAJOR = ((5256, 256, 10), (5256, 160, 10), (5256, 160, 11), (525
 # ... code + 20: the same walk over a staged 18 x 18-pixel halo per chunk (also pad 1, h_in and w_in multiples of 16; csrc/conv_big.hip conv_bighalo_kernel)
 BIG_TILES_HALO_IMAGE = ((5256, 160, 20), (5256, 128, 20), (5256, 128, 21))
 BIG_MIN_ROWS = 4096   # rows (M) below which the tuner does not try the big form
-HALO_IMAGE_MIN_ROWS = 512   # ... its halo-image variant (one 16 x 16-pixel tile per sample at the 16x16 level, split-K over chunks)
+HALO_IMAGE_MIN_ROWS = 256   # ... its halo-image variant (one 16 x 16-pixel tile per sample at the 16x16 level, split-K over chunks)
 
 
 def is_halo(tile_m: int) -> bool:
@@ -84,6 +85,14 @@ def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=Tr
             f"{'+x' + str(cx) if cx else ''}")
 
 
+def profile() -> str:
+    """"latency" (default: every choice made for one image per GPU, the headline) or "throughput" ($MSD_PROFILE)."""
+    p = os.environ.get("MSD_PROFILE", "latency") or "latency"
+    if p not in ("latency", "throughput"):
+        raise ValueError(f"MSD_PROFILE={p!r}: latency or throughput")
+    return p
+
+
 def _load() -> Dict[str, list]:
     global _table, _families
     if _table is None:
@@ -92,6 +101,16 @@ def _load() -> Dict[str, list]:
                 _table = json.load(f)
         except (OSError, ValueError):
             _table = {}
+        # Serving profile: MSD_PROFILE=throughput lays conv_tuning_throughput.json over the table - whole LAYERS (every measured batch of a
+        # layer shape, so the one-class-per-layer rule holds inside the profile) moved to the configuration that pays from two images per GPU
+        # and costs at one: the shortcut-folded 3x3 convs on the staged-halo big form.  A process-wide arithmetic choice, like
+        # MSD_GN_ROWS (which this profile also sets to 4096 unless given: minsdtf_amd/_lib.py).
+        if profile() == "throughput":
+            try:
+                with open(_PROFILE_PATH) as f:
+                    _table.update(json.load(f))
+            except (OSError, ValueError) as e:
+                raise RuntimeError(f"MSD_PROFILE=throughput: cannot read {_PROFILE_PATH}: {e}") from e
         # A/B runs: $MSD_TUNE_OVERRIDE = JSON {shape key: [tile_m, tile_n, splitk, stages]} (or @file) laid over the table
         ov = os.environ.get("MSD_TUNE_OVERRIDE")
         if ov:
@@ -133,7 +152,9 @@ def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_spli
                 ent = [128] + list(ent[1:])
             if is_big(int(ent[0])) and M < BIG_MIN_ROWS:   # (a 256-row macro tile on a small launch: the same class on small tiles)
                 stg = int(ent[3]) if len(ent) > 4 else 0
-                if stg >= 10 and not upsample and stride == 1 and w_in % 16 == 0 and h_in % 8 == 0:
+                if stg >= 20 and cx:   # (shortcut-folded conv on the staged halo: no other kernel walks it chunk-major; it takes any whole number of tiles)
+                    pass
+                elif stg >= 10 and not upsample and stride == 1 and w_in % 16 == 0 and h_in % 8 == 0:
                     ent = [1128, 80 if N % 80 == 0 else 64, int(ent[2]), 0, 0.0]
                 elif stg >= 10:   # (an upsampling layer of the chunk-major class: the halo-tile kernel does not take it; the big form walks any M)
                     ent = [5256, 128, int(ent[2]), 10, 0.0]

@@ -360,13 +360,20 @@ def test_tuning_table_pins_one_numerics_class_per_layer():
     from minsdtf_amd import tuning
 
     table = json.load(open(os.path.join(ROOT, "minsdtf_amd", "conv_tuning.json")))
-    fams = {}
-    for key, ent in table.items():
-        b, rest = key.split("x", 1)
-        ks = int(re.search(r"k(\d)s", rest).group(1))
-        fams.setdefault(rest, set()).add(tuning.numerics_class(ks, int(ent[0]), int(ent[1]), int(ent[2]), tuning.key_is_ln_producer(key), stages=int(ent[3]) if len(ent) > 4 else 0))
-    bad = {k: v for k, v in fams.items() if len(v) != 1}
-    assert not bad, bad
+    overlay = json.load(open(os.path.join(ROOT, "minsdtf_amd", "conv_tuning_throughput.json")))   # MSD_PROFILE=throughput lays this over the table
+    assert overlay and set(overlay) <= set(table), "the throughput overlay moves measured entries only"
+    for tab in (table, {**table, **overlay}):   # ... inside either profile
+        fams = {}
+        for key, ent in tab.items():
+            b, rest = key.split("x", 1)
+            ks = int(re.search(r"k(\d)s", rest).group(1))
+            fams.setdefault(rest, set()).add(tuning.numerics_class(ks, int(ent[0]), int(ent[1]), int(ent[2]), tuning.key_is_ln_producer(key), stages=int(ent[3]) if len(ent) > 4 else 0))
+        bad = {k: v for k, v in fams.items() if len(v) != 1}
+        assert not bad, bad
+    # the overlay moves WHOLE layers (every measured batch of a layer shape), and only shortcut-folded 3x3 convs onto the staged-halo big form
+    moved = {k.split("x", 1)[1] for k in overlay}
+    assert all((k in overlay) for k in table if k.split("x", 1)[1] in moved)
+    assert all("+x" in k and int(e[0]) == 5256 and int(e[3]) >= 20 for k, e in overlay.items())
     # an unmeasured batch lands in the same class as the measured ones; an unknown layer falls back per SAMPLE
     a = tuning.lookup(2, 8, 8, 1280, 1280, 3, 1, False, 128, 180, True)
     b = tuning.lookup(6, 8, 8, 1280, 1280, 3, 1, False, 384, 180, True)

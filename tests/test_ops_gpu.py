@@ -275,6 +275,12 @@ def test_conv_gemm(gpu, case):
     dict(B=3, H=12, W=20, c=128, cx0=64, cx1=0, N=320, ks=3, tile_m=5256, tile_n=160, stages=0),              # big form, ragged M
     dict(B=2, H=16, W=16, c=192, cx0=128, cx1=64, N=256, ks=3, splitk=3, tile_m=5256, tile_n=256, stages=0),  # ... shortcut over a concat, split-K across both parts
     dict(B=2, H=16, W=16, c=64, cx0=128, cx1=0, N=256, ks=1, tile_m=5128, tile_n=256, stages=0),              # ... 1x1 main part
+    # big form on a staged halo: the slice's shortcut chunks follow its main chunks (chunk-major: its own numerics class - compared
+    # with another configuration of the same form)
+    dict(B=2, H=16, W=32, c=128, cx0=64, cx1=0, N=160, ks=3, tile_m=5256, tile_n=160, stages=20, other=(5256, 128, 20)),              # ONE shortcut chunk (nothing to prefetch)
+    dict(B=1, H=32, W=16, c=192, cx0=128, cx1=64, N=272, ks=3, tile_m=5256, tile_n=128, stages=20, other=(5256, 160, 20)),            # shortcut over a concat: 3 chunks, ragged N
+    dict(B=2, H=16, W=16, c=320, cx0=640, cx1=0, N=320, ks=3, splitk=3, tile_m=5256, tile_n=128, stages=21, other=(5256, 160, 20)),   # 5 + 10 chunks over 3 slices (2, 2, 1 main; 4, 4, 2 extra)
+    dict(B=1, H=16, W=16, c=128, cx0=64, cx1=0, N=128, ks=3, splitk=2, tile_m=5256, tile_n=128, stages=20, other=(5256, 128, 21)),    # the second slice has no shortcut chunk
 ])
 def test_conv_gemm_shortcut_operand(gpu, case):
     """conv(h) + conv1x1(x) as one contraction (diffusion_model.py:34-38,50): K = taps of h, then the channels of x."""
@@ -311,6 +317,8 @@ def test_conv_gemm_shortcut_operand(gpu, case):
     # chunk-major weights on the same tile (wreg: on the tile kernel): storage order / kernel form only, the same bits
     big = case.get("tile_m", 0) >= 5000
     other = dict(tile_m=64, tile_n=128) if (wreg or big) else dict(tile_m=case.get("tile_m", 0), tile_n=case.get("tile_n", 0), stages=case.get("stages", 0))
+    if case.get("other"):
+        other = dict(tile_m=case["other"][0], tile_n=case["other"][1], stages=case["other"][2])
     out2 = torch.full_like(out, float("nan"))
     run_calls(ops.conv_gemm(a0=keep[0], w=packing.chunk_major(wcat), w_layout=1, out=out2, batch=B, h_in=H, w_in=W, c0=c, N=N, ksize=ks,
                             bias=keep[3], a2=keep[1], c2=cx0, a3=keep[2], c3=cx1, workspace=keep[4], workspace_floats=keep[4].numel(),

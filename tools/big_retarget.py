@@ -35,6 +35,10 @@ def main():
     ap.add_argument("--reclass-upsample", action="store_true",
                     help="upsampling 3x3 layers whose every measured batch has M >= BIG_MIN_ROWS: move the LAYER (all its batches) from the "
                          "tile class to the chunk-major class when the chunk-major candidates are faster for every batch")
+    ap.add_argument("--reclass-shortcut", action="store_true",
+                    help="the THROUGHPUT profile's overlay (minsdtf_amd/conv_tuning_throughput.json, --out): shortcut-folded 3x3 layers (+x keys) whose "
+                         "every measured batch is whole 16 x 16-pixel tiles move - all their batches - to the staged-halo big form when the batches of "
+                         "two or more images per GPU (fused batch >= 4) gain; the one-image batch pays (that is the profile's trade)")
     ap.add_argument("--only", default=None, help="regular expression on the key")
     args = ap.parse_args()
     import tune_conv
@@ -51,6 +55,47 @@ def main():
         hl, wl = (2 * h_in, 2 * w_in) if ups else (h_in, w_in)
         return batch * ((hl + 2 * pad - ks) // stride + 1) * ((wl + 2 * pad - ks) // stride + 1)
 
+    if args.reclass_shortcut:
+        groups, overlay = {}, {}
+        for key in sorted(table):
+            s = parse_key(key)
+            if s[9] and s[5] == 3 and s[6] == 1 and not s[7] and s[1] % 16 == 0 and s[2] % 16 == 0 and (args.only is None or re.search(args.only, key)):
+                groups.setdefault(key.split("x", 1)[1], []).append(key)
+        for rest, keys in sorted(groups.items()):
+            if any(rows_of(parse_key(k)) < tuning.HALO_IMAGE_MIN_ROWS for k in keys):
+                print(f"  layer {rest}: a measured batch below {tuning.HALO_IMAGE_MIN_ROWS} rows: left alone")
+                continue
+            plan, t_old, t_new = {}, 0.0, 0.0
+            for key in keys:
+                s = parse_key(key)
+                ent = table[key]
+                tm, tn, sk, stg = int(ent[0]), int(ent[1]), int(ent[2]), int(ent[3]) if len(ent) > 4 else 0
+                best_t, _, flop = tune_conv.tune_one(s, iters=args.iters, only=lambda t: t == (tm, tn, stg), sks_only=[sk])
+                best_b, _, _ = tune_conv.tune_one(s, iters=args.iters, only=lambda t: t[0] >= 5000 and t[2] >= 20, sks_only=[sk])
+                if best_t is None or best_b is None:
+                    plan = None
+                    break
+                print(f"{key:44s} {tm}x{tn}s{stg}k{sk} {best_t[0]:8.1f} us ({flop / best_t[0] / 1e6:5.0f} TF) | {best_b[1]}x{best_b[2]}s{best_b[4]} {best_b[0]:8.1f} us "
+                      f"({flop / best_b[0] / 1e6:5.0f} TF) ({1.0 - best_b[0] / best_t[0]:+.1%})", flush=True)
+                if s[0] >= 4:
+                    t_old += best_t[0]
+                    t_new += best_b[0]
+                plan[key] = ([tm, tn, sk, stg, round(best_t[0], 1)], [best_b[1], best_b[2], best_b[3], best_b[4], round(best_b[0], 1)])
+            if plan and t_old > 0 and t_new < (1.0 - args.min_gain) * t_old:
+                for key, (old_e, new_e) in plan.items():
+                    overlay[key] = new_e
+                    log[key] = dict(table=old_e, big=new_e, replaced=True, profile="throughput")
+                    n_rep += 1
+                print(f"  layer {rest}: into the throughput overlay ({len(plan)} entries; fused batches >= 4: {t_old:.0f} -> {t_new:.0f} us)")
+            else:
+                print(f"  layer {rest}: left alone")
+        with open(args.out, "w") as f:
+            json.dump(overlay, f, indent=0, sort_keys=True)
+        if args.log:
+            with open(args.log, "w") as f:
+                json.dump(log, f, indent=1, sort_keys=True)
+        print(f"{n_rep} entries in the overlay; wrote {args.out}")
+        return
     if args.reclass_upsample:
         groups = {}
         for key in sorted(table):

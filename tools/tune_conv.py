@@ -141,7 +141,7 @@ def tune_one(shape, iters=10, only=None, sks_only=None):
         cands += [t for t in tuning.BIG_TILES if not (t[1] == 160 and N % 160) and not (t[1] > 128 and N <= 128)]
         if ks == 3 and stride == 1 and not cx:   # ... walking K chunk-major: the halo-tile kernel's class
             cands += [t for t in tuning.BIG_TILES_CHUNK_MAJOR if not (t[1] == 160 and N % 160) and not (t[1] > 128 and N <= 128)]
-    if M >= tuning.HALO_IMAGE_MIN_ROWS and ks == 3 and stride == 1 and not cx and hl % 16 == 0 and wl % 16 == 0 and not os.environ.get("MSD_TUNE_NO_BIG"):
+    if M >= tuning.HALO_IMAGE_MIN_ROWS and ks == 3 and stride == 1 and not (cx and ups) and hl % 16 == 0 and wl % 16 == 0 and not os.environ.get("MSD_TUNE_NO_BIG"):
         # ... on a staged halo (whole 16 x 16-pixel output tiles)
         cands += [t for t in tuning.BIG_TILES_HALO_IMAGE if not (t[1] == 160 and N % 160) and not (t[1] > 128 and N <= 128)]
     if only is not None:
