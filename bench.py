@@ -470,7 +470,9 @@ def main(argv=None):
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"SD1.5 {size}x{size} {nsteps}-step txt2img, CFG 7.5 + rescale 0.7, batch {b}/GPU, "
                                f"UNet+VAE{'+ControlNet' if args.controlnet else ''} HIP path, random-init weights", "global_batch": gb,
-                   "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph},
+                   "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph,
+                   # process-wide arithmetic choices read from the environment (minsdtf_amd/tuning.py, _lib.py): "latency" = the default
+                   "profile": os.environ.get("MSD_PROFILE", "latency") or "latency", "gn_rows": os.environ.get("MSD_GN_ROWS")},
         "n_ranks_seen": n_ranks_seen, "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
         "launcher": os.environ.get("MSD_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "external" if world > 1 else "none"),
         "rank_devices": rank_devices(dev, world),

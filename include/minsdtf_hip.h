@@ -149,7 +149,8 @@ typedef struct MsdConvGemm {
                             shortcut operand only): the halo-tile kernel's order of sums, hence ITS bits instead of the tile kernel's;
                             20 + code with tile_m 5256 = that chunk-major walk over a STAGED 18 x 18-pixel halo per 64-channel chunk
                             (3x3 / stride 1 / pad 1, with or without `upsample`, h_out and w_out multiples of 16; otherwise
-                            MSD_E_UNSUPPORTED): 5256x160:20 5256x128:20/21 (weight ring of 3 / 4) */
+                            MSD_E_UNSUPPORTED): 5256x160:20 5256x128:20/21 (weight ring of 3 / 4).  With a shortcut operand (a2) a
+                            slice's shortcut chunks follow its main chunks: an order of sums no other form has */
     const float* ln_in;      /* float2 [M][ln_in_slots] row-moment partials of the input rows, or NULL */
     const float* ln_colsum;  /* [N]: sum_k W[n][k] of the gamma-folded bf16 weights (with ln_in) */
     float* ln_out;           /* float2 [M][ln_out_slots] row-moment partials of the stored output, or NULL */
