@@ -306,7 +306,8 @@ MSD_API int msd_attention(const MsdAttention* p, msd_stream_t stream);
  *   out = softmax(q k^T) v with the softmax as exp2 of the raw product: wq MUST carry scale * log2(e) (q_prescaled form).
  * x: bf16 [batch*s][c] (the block's raw rows), ln_in: float2 [batch*s][ln_in_slots] (the producer's ln_out partials),
  * wq: bf16 gamma-folded weights [c][c] in `w_layout`, ln_colsum / bias: [c]; k: bf16 [batch][t][k_ld], vt: bf16
- * [batch][heads][head_dim][vt_ld] (key contiguous), out: bf16 [batch*s][o_ld].  heads = 8, head_dim 40 or 80, t <= 96. */
+ * [batch][heads][head_dim][vt_ld] (key contiguous), out: bf16 [batch*s][o_ld].  heads = 8, head_dim 40, 80 or 160, t <= 96
+ * (160: the head's 400 KB of weights are streamed through a four-stage LDS ring instead of waiting in LDS). */
 typedef struct MsdCrossAttnQ {
     const void* x;
     const float* ln_in;

@@ -1384,6 +1384,253 @@ static constexpr int xattn_lds() {
 }
 static_assert(xattn_lds<40>() <= 160 * 1024 && xattn_lds<80>() <= 160 * 1024, "LDS budget");
 
+// ---- the same at C = 1280 (d = 160: the 16x16 and 8x8 levels) -------------------------------------------------------
+// A head's slice of to_q is 160 rows x 1280 channels = 400 KB: it cannot wait in LDS like the 25 / 100 KB slices above, and
+// a wave's 16 raw rows are 160 registers.  So the projection is a K loop over the twenty 64-channel chunks: the chunk's
+// 160 x 64 weight block (20 KB) arrives by LDS-DMA in a four-stage ring, three chunks in flight; the wave's two x fragments
+// of a chunk travel global -> VGPR beside it (inline asm: both queues are counted by hand, see conv_wreg.hip) — ten
+// accumulators per wave, 20 MFMAs per chunk.  What follows the loop is the kernel above with D = 160: q^T packed to bf16 IS
+// the B operand of S^T = K q^T (five 32-channel steps per key block), single-pass softmax over T <= 96 keys, O^T = V^T P^T.
+// The K / V^T images need no zero fill here (160 = 10 x 16 = 5 x 32: no pad rows or columns are ever read; key rows / key
+// chunks >= t are stored as zeros by their owners).  A workgroup is bound by the 400 KB + 16 NW x 2.5 KB it streams through
+// one CU (~6-8 us at the ~70 GB/s a CU takes in); head h runs on XCD h (workgroup id & 7), so an XCD's L2 holds one head's
+// weights and the matrix leaves HBM once per launch.
+typedef uint32_t xq_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void xq_load(xq_u32x4& lo, xq_u32x4& hi, const void* ptr) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64" : "=&v"(lo), "=&v"(hi) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void xr_load(xq_u32x4& dst, const void* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(ptr) : "memory");
+}
+
+template <int NW, int MODE = 0>   // MODE (experiments): 1 = no MFMAs in the projection loop, 2 = no ring traffic, 3 = neither
+__global__ __launch_bounds__(64 * NW) void xattn_q160_kernel(XATTN_HOT_PARAMS, const XArgs p) {
+    constexpr int D = 160, C = 8 * D, KC = C / 64, DB = D / 16, DCK = DB / 2;
+    constexpr int NT = 64 * NW, QT = 16 * NW;
+    constexpr int NS = 4, PF = 3;                 // ring stages; chunks in flight
+    constexpr int DMAW = (D / 8) / NW;            // weight DMAs per wave and chunk (8 rows x 128 B each)
+    constexpr int OPS = DMAW + 2;                 // vector-memory operations per wave and chunk (+ the two x fragments)
+    constexpr int W_STAGE = D * 128;
+    constexpr int TB = 6, TPAD = TB * 16;
+    constexpr int KROW = DCK * 64 + 16, VROW = TPAD * 2 + 16;
+    constexpr int K_BYTES = TPAD * KROW;
+    constexpr int DCH = D / 8;
+    static_assert((D / 8) % NW == 0 && PF == NS - 1 && (PF - 1) * OPS <= 63 && KC % NS == 0, "ring configuration");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;
+    char* sK = smem + NS * W_STAGE;
+    char* sV = sK + K_BYTES;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int qtiles = (hot_s + QT - 1) / QT;
+    const int h = blockIdx.x & 7, qt_b = blockIdx.x >> 3;       // head = XCD under round-robin placement (speed only)
+    const int b = udiv_magic(qt_b, qtiles, hot_mg_qtiles);
+    const int q0 = (qt_b - b * qtiles) * QT + wave * 16;
+    const int qrow = min(q0 + r, hot_s - 1);
+
+    // ---- 1. the small operands (oldest in the queue), then the ring.  K / V^T pass through registers into their LDS images
+    // before the loop; their loads are inline asm like the x fragments (hipcc would wait for them one by one with counts
+    // that know nothing of the DMAs behind them, i.e. for most of the ring's first three chunks).
+    constexpr int KCH = (TPAD * DCH + NT - 1) / NT, VCH = (D * (TPAD / 8) + NT - 1) / NT;
+    xq_u32x4 rk[KCH], rv[VCH];
+    constexpr int LNS = 5;   // (LN_MAX_SLOTS / 4 of conv_common.h)
+    float2 lnp[LNS];
+    {
+        const float2* src = reinterpret_cast<const float2*>(p.ln_in) + ((size_t)b * hot_s + qrow) * hot_ln_slots;
+#pragma unroll
+        for (int k = 0; k < LNS; ++k) lnp[k] = src[min(g + 4 * k, hot_ln_slots - 1)];
+    }
+    float4 csv[DB], bsv[DB];   // column sums / folded bias of this lane's 4 head channels per block
+#pragma unroll
+    for (int bb = 0; bb < DB; ++bb) {
+        const int d = bb * 16 + 4 * g;
+        csv[bb] = *reinterpret_cast<const float4*>(p.colsum + h * D + d);
+        bsv[bb] = p.bias ? *reinterpret_cast<const float4*>(p.bias + h * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bf16_t* kbase = hot_k + (size_t)b * hot_t * hot_k_ld + h * D;
+    const bf16_t* vbase = p.vt + ((size_t)b * hot_heads + h) * D * p.vt_ld;
+    // (clamped addresses, no branches: what lies beyond key t - 1 is replaced by zeros when the images are stored)
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int idx = tid + NT * i, key = idx / DCH, ch = idx - key * DCH;
+        xr_load(rk[i], kbase + (size_t)min(key, hot_t - 1) * hot_k_ld + ch * 8);
+    }
+    const int vch_last = (hot_t - 1) >> 3;   // (vt_ld >= t rounded up to 8: this chunk lies inside every row)
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int idx = tid + NT * i, d = idx / (TPAD / 8), ch = idx - d * (TPAD / 8);
+        xr_load(rv[i], vbase + (size_t)min(d, D - 1) * p.vt_ld + min(ch, vch_last) * 8);
+    }
+    // ring: wave w moves weight rows [8 DMAW w, 8 DMAW (w + 1)) of every chunk and loads its own 16 x 64 block of x
+    uint32_t woff[DMAW];
+    {
+        const int cpos = lane & 7, lrow = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < DMAW; ++i) {
+            const int row = (wave * DMAW + i) * 8 + lrow;
+            woff[i] = (uint32_t)(h * D + row) * hot_w_rs + (uint32_t)((cpos ^ ((row >> 1) & 7)) * 16);
+        }
+    }
+    const uint32_t lds_wave = lds0 + (uint32_t)(wave * DMAW) * 1024u;
+    const char* xptr = reinterpret_cast<const char*>(hot_x + ((size_t)b * hot_s + qrow) * C + g * 8);
+    xq_u32x4 xq[NS][2];
+    auto issue = [&](int kc, int slot) {
+        const uint32_t ko = (uint32_t)kc * hot_w_ks;
+#pragma unroll
+        for (int i = 0; i < DMAW; ++i) dma16s(hot_wq, (MODE & 2) ? woff[i] : woff[i] + ko, __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)(slot * W_STAGE + i * 1024)));
+        xq_load(xq[slot][0], xq[slot][1], xptr + ((MODE & 2) ? 0 : kc * 128));
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) issue(s, s);
+    // the K / V^T images (every 16-byte piece of them is written: no zero fill)
+    wait_vmcnt<PF * OPS>();
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) asm volatile("" : "+v"(rk[i]));   // consumers stay below the wait
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) asm volatile("" : "+v"(rv[i]));
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int idx = tid + NT * i, key = idx / DCH, ch = idx - key * DCH;
+        if (key < TPAD) *reinterpret_cast<xq_u32x4*>(sK + key * KROW + ch * 16) = key < hot_t ? rk[i] : (xq_u32x4){0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int idx = tid + NT * i, d = idx / (TPAD / 8), ch = idx - d * (TPAD / 8);
+        if (d >= D) continue;
+        xq_u32x4 v = rv[i];
+        const int valid = hot_t - ch * 8;   // keys >= t are padding of unspecified content: force to 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (2 * j >= valid) v[j] = 0;
+            else if (2 * j + 1 >= valid) v[j] &= 0xFFFFu;
+        }
+        *reinterpret_cast<xq_u32x4*>(sV + d * VROW + ch * 16) = v;
+    }
+
+    // ---- 2. q^T = W_h x^T over the chunks: block bb holds head channels 16 bb + 4 g + e of query r
+    f32x4 qacc[DB];
+#pragma unroll
+    for (int bb = 0; bb < DB; ++bb) qacc[bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int sw = (r >> 1) & 7;
+#pragma unroll 1
+    for (int kc0 = 0; kc0 < KC; kc0 += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int kc = kc0 + u;
+            wait_vmcnt_tiles<OPS, PF - 1>(KC - 1 - kc);   // chunk kc has landed (this wave's share of it)
+            __syncthreads();                               // ... every wave's; and stage (kc - 1) & 3 has been read by all
+            if (kc + PF < KC) issue(kc + PF, (u + PF) % NS);
+            asm volatile("" : "+v"(xq[u][0]));             // consumers stay below the wait
+            asm volatile("" : "+v"(xq[u][1]));
+            const char* ws = sW + u * W_STAGE + r * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, xq[u][ks]);
+#pragma unroll
+                for (int bb = 0; bb < DB; ++bb) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(ws + bb * 2048 + (((ks * 4 + g) ^ sw) << 4));
+                    if ((MODE & 1) && kc > 0) continue;
+                    qacc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, qacc[bb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // LayerNorm row moments, summed as cg_epilogue does (lane group g: slots g, g + 4, ...; then (g0 + g1) + (g2 + g3))
+    float mean, rstd;
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNS; ++k)
+            if (g + 4 * k < hot_ln_slots) { s1 += lnp[k].x; s2 += lnp[k].y; }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        mean = s1 * p.ln_inv_k;
+        rstd = rsqrtf(fmaxf(s2 * p.ln_inv_k - mean * mean, 0.f) + p.ln_eps);
+    }
+    // LayerNorm fold + bias (the Dense epilogue's expressions); two blocks -> one operand
+    uint32_t qpk[DB][2];
+#pragma unroll
+    for (int bb = 0; bb < DB; ++bb) {
+        qpk[bb][0] = pack_bf2(rstd * (qacc[bb][0] - mean * csv[bb].x) + bsv[bb].x, rstd * (qacc[bb][1] - mean * csv[bb].y) + bsv[bb].y);
+        qpk[bb][1] = pack_bf2(rstd * (qacc[bb][2] - mean * csv[bb].z) + bsv[bb].z, rstd * (qacc[bb][3] - mean * csv[bb].w) + bsv[bb].w);
+    }
+    __syncthreads();   // the K / V^T images of the other waves (the loop's barriers have long ordered them; kept for the reader)
+    // ---- 3. S^T = K q^T (q carries scale * log2 e): lane holds keys 16 kb + 4 g + e of query r
+    f32x4 sacc[TB];
+#pragma unroll
+    for (int kb = 0; kb < TB; ++kb) {
+        sacc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) {
+            union { bf16x8 v; uint32_t u[4]; } qo;
+            qo.u[0] = qpk[2 * c][0]; qo.u[1] = qpk[2 * c][1]; qo.u[2] = qpk[2 * c + 1][0]; qo.u[3] = qpk[2 * c + 1][1];
+            union { bf16x8 v; uint2 h2[2]; } kf;
+            const char* kp = sK + (kb * 16 + r) * KROW + c * 64 + g * 8;
+            kf.h2[0] = *reinterpret_cast<const uint2*>(kp);
+            kf.h2[1] = *reinterpret_cast<const uint2*>(kp + 32);
+            sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf.v, qo.v, sacc[kb], 0, 0, 0);
+        }
+    }
+    // single-pass softmax over the T keys of the lane's query
+    float m = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < TB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (kb * 16 + 4 * g + e >= hot_t) sacc[kb][e] = -1e30f;
+            m = fmaxf(m, sacc[kb][e]);
+        }
+    m = rows_max4(m);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < TB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float pv = __builtin_amdgcn_exp2f(sacc[kb][e] - m);
+            sacc[kb][e] = pv;
+            lsum += pv;
+        }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    // ---- 4. O^T = V^T P^T over 32-key chunks (P packed to bf16 = the B operand, key order {4g+e, 16+4g+e} of the chunk)
+    f32x4 oacc[DB];
+#pragma unroll
+    for (int bb = 0; bb < DB; ++bb) oacc[bb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < TB / 2; ++c) {
+        union { bf16x8 v; uint32_t u[4]; } pk;
+        pk.u[0] = pack_bf2(sacc[2 * c][0], sacc[2 * c][1]);
+        pk.u[1] = pack_bf2(sacc[2 * c][2], sacc[2 * c][3]);
+        pk.u[2] = pack_bf2(sacc[2 * c + 1][0], sacc[2 * c + 1][1]);
+        pk.u[3] = pack_bf2(sacc[2 * c + 1][2], sacc[2 * c + 1][3]);
+#pragma unroll
+        for (int bb = 0; bb < DB; ++bb) {
+            union { bf16x8 v; uint2 h2[2]; } vf;
+            const char* vp = sV + (bb * 16 + r) * VROW + c * 64 + g * 8;
+            vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
+            vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 32);
+            oacc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, oacc[bb], 0, 0, 0);
+        }
+    }
+    if (q0 + r < hot_s) {
+        const float inv = 1.0f / lsum;
+        bf16_t* op = p.out + ((size_t)b * hot_s + q0 + r) * p.o_ld + h * D;
+#pragma unroll
+        for (int bb = 0; bb < DB; ++bb) {
+            uint2 o;
+            o.x = pack_bf2(oacc[bb][0] * inv, oacc[bb][1] * inv);
+            o.y = pack_bf2(oacc[bb][2] * inv, oacc[bb][3] * inv);
+            *reinterpret_cast<uint2*>(op + bb * 16 + 4 * g) = o;
+        }
+    }
+}
+template <int NW>
+static constexpr int xattn160_lds() { return 4 * 160 * 128 + 96 * (5 * 64 + 16) + 160 * (96 * 2 + 16); }
+static_assert(xattn160_lds<4>() <= 160 * 1024, "LDS budget");
+
 // ---- d = 512: the VAE's single-head AttentionBlock (layers.py:28-59) ----------------------------------------------
 // The head does not fit the kernel above (O^T of 32 queries x 512 channels alone is 256 registers per lane), and the
 // reference's route — materialise softmax(q k^T / sqrt(C)) — is 64 MB of fp32 scores + 32 MB of probabilities per image
@@ -1608,6 +1855,8 @@ static int g_attn_d160_pipe = 1;   // d = 160, 64-query workgroups: 1 = K/V tile
                                    // [default], 0 = load -> store -> compute (NBUF 1: the only form the 128-query workgroups have registers for).  Staging only:
                                    // the same bits.  The S <= 256 launches of the 16x16 / 8x8 levels put one wave on a SIMD of a quarter of the CUs: a serial chain
 void msd_set_attn_d160_pipe(int v) { g_attn_d160_pipe = v; }
+static int g_xattn160_mode = 0;   // (experiments: see xattn_q160_kernel's MODE)
+void msd_set_xattn160_mode(int v) { g_xattn160_mode = v; }
 static int g_xattn_nw = 0;    // 0 = automatic, 4 / 8 = waves (x 16 queries) per workgroup of the fused cross-attention (A/B runs)
 void msd_set_xattn_nw(int v) { g_xattn_nw = v; }
 
@@ -1658,6 +1907,10 @@ int msd_attention_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<40, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<40>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<80, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<80>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q_kernel<80, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn_lds<80>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
     {
         int dev = 0;
@@ -1821,8 +2074,8 @@ extern "C" int msd_cross_attention_q(const MsdCrossAttnQ* q, msd_stream_t stream
     hipStream_t stream = (hipStream_t)stream_;
     if (!q || !q->x || !q->ln_in || !q->wq || !q->ln_colsum || !q->k || !q->vt || !q->out) MSD_FAIL(MSD_E_ARG, "cross_attention_q: null pointer");
     if (q->batch <= 0 || q->s <= 0 || q->t <= 0) MSD_FAIL(MSD_E_ARG, "cross_attention_q: bad dims");
-    if (q->heads != 8 || (q->head_dim != 40 && q->head_dim != 80) || q->t > 96)
-        MSD_FAIL(MSD_E_UNSUPPORTED, "cross_attention_q: 8 heads of 40 or 80 channels and at most 96 keys (heads=%d head_dim=%d t=%d)", q->heads,
+    if (q->heads != 8 || (q->head_dim != 40 && q->head_dim != 80 && q->head_dim != 160) || q->t > 96)
+        MSD_FAIL(MSD_E_UNSUPPORTED, "cross_attention_q: 8 heads of 40, 80 or 160 channels and at most 96 keys (heads=%d head_dim=%d t=%d)", q->heads,
                  q->head_dim, q->t);
     const int C = q->heads * q->head_dim;
     if (q->ln_in_slots < 1 || q->ln_in_slots > 20 || !(q->ln_eps > 0.f)) MSD_FAIL(MSD_E_ARG, "cross_attention_q: 1 <= ln_in_slots <= 20, ln_eps > 0");
@@ -1841,6 +2094,20 @@ extern "C" int msd_cross_attention_q(const MsdCrossAttnQ* q, msd_stream_t stream
     a.ln_slots = q->ln_in_slots; a.ln_inv_k = 1.0f / (float)C; a.ln_eps = q->ln_eps;
     a.w_rs = q->w_layout ? 128u : (uint32_t)C * 2u;
     a.w_ks = q->w_layout ? (uint32_t)C * 128u : 128u;
+    if (q->head_dim == 160) {   // streamed projection (xattn_q160_kernel): 64 queries x one head per workgroup, head = workgroup id & 7
+        if ((long long)q->batch * q->s * C * 2 >= (1ll << 32)) MSD_FAIL(MSD_E_UNSUPPORTED, "cross_attention_q: batch * s too large");
+        const int qtiles = (q->s + 63) / 64;
+        a.mg_heads = udiv_magic_of(q->heads); a.mg_qtiles = udiv_magic_of(qtiles);
+        const dim3 grid160((unsigned)qtiles * q->batch * 8u);
+        switch (g_xattn160_mode) {
+            case 1: hipLaunchKernelGGL((xattn_q160_kernel<4, 1>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
+            case 2: hipLaunchKernelGGL((xattn_q160_kernel<4, 2>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
+            case 3: hipLaunchKernelGGL((xattn_q160_kernel<4, 3>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
+            default: hipLaunchKernelGGL((xattn_q160_kernel<4>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a);
+        }
+        MSD_CHECK_LAUNCH();
+        return MSD_OK;
+    }
     // 128 queries per workgroup where the 64-query grid would need more than ~1.5 workgroups per CU (a query's result does
     // not depend on which queries share its workgroup)
     const long long wgs64 = (long long)((q->s + 63) / 64) * q->heads * q->batch;

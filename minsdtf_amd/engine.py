@@ -349,6 +349,10 @@ W_CHUNK_MAJOR = os.environ.get("MSD_W_CHUNK_MAJOR", "1") != "0"
 MFMA_TEMB_PROJ = os.environ.get("MSD_MFMA_TEMB_PROJ", "1") != "0"
 # attn2.to_q + the attention over the text context as one launch at the 64x64 / 32x32 levels (msd_cross_attention_q)
 XATTN_FUSED = os.environ.get("MSD_XATTN_FUSED", "1") != "0"
+# ... and at the 16x16 / 8x8 levels (C = 1280, d = 160: the streamed-projection form, round 5).  Off: in the replayed loop the
+# one launch takes 19.9 us where the two take 8.6 + 9.9 (25-step loop 97.30 vs 97.06 ms); the kernel stays for
+# tools/xattn_bench.py and its parity tests.
+XATTN_FUSED_D160 = os.environ.get("MSD_XATTN_FUSED_D160", "0") != "0"
 
 
 # ----------------------------------------------------------------------------- layer emitters
@@ -512,7 +516,7 @@ class Emitter:
         # cross-attention over the text context (k, v^T precomputed once per prompt)
         kc, vtc, tp = ctx_kv[tb + ".attn2"]
         a2 = p.act(B, H, Wd, C)
-        if fold and XATTN_FUSED and heads == 8 and d in (40, 80) and ctx_len <= 96:
+        if fold and XATTN_FUSED and heads == 8 and (d in (40, 80) or (d == 160 and XATTN_FUSED_D160)) and ctx_len <= 96:
             # norm2 -> to_q -> attention over the 77 context tokens as ONE launch (msd_cross_attention_q)
             wn = tb + ".attn2.to_q"
             p.rec(ops.cross_attention_q, x=t1.buf, ln_in=t1.ln[0], ln_in_slots=t1.ln[1], wq=self.W[wn + ".lnw"],

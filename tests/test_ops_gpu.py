@@ -974,6 +974,10 @@ def test_attention(gpu, case, qf, presc, form):
     dict(B=2, S=128, d=80, T=77, slots=10),     # 32x32 level (C = 640)
     dict(B=1, S=64, d=80, T=96, slots=5),       # the largest context the kernel takes
     dict(B=1, S=64, d=40, T=13, slots=3, spike=True),   # short context, one dominant key
+    dict(B=2, S=256, d=160, T=77, slots=10),    # 16x16 level (C = 1280): the streamed-projection form (xattn_q160_kernel)
+    dict(B=2, S=64, d=160, T=77, slots=20),     # the 8x8 mid block, the most partial slots a producer leaves
+    dict(B=1, S=100, d=160, T=96, slots=5),     # ragged query tile, the largest context
+    dict(B=3, S=64, d=160, T=13, slots=3, spike=True),
 ])
 @pytest.mark.parametrize("layout,nw", [(1, 4), (0, 4), (1, 8)])   # weight layout; 64 / 128 queries per workgroup (picked by grid size: both forced)
 def test_cross_attention_q(gpu, case, layout, nw):

@@ -3,6 +3,7 @@
     python tools/ab_loop.py --variant base --variant gn_impl=0 [--rounds 4] [--batch 1]
 
 Each variant is a comma-separated list of msd_set_option KEY=INT pairs ("base" = no switch).  The UNet is loaded once;
+`py:NAME=INT` sets the module switch minsdtf_amd.engine.NAME instead (e.g. py:XATTN_FUSED_D160=0);
 for every round every variant gets a fresh DenoiseEngine (switches are read when a launch is recorded, so the loop graph
 is re-captured), and the rounds are interleaved (cdna_hip_programming.md rule 24).  Prints ms per 25-step loop: median,
 min, and every round.
@@ -42,7 +43,10 @@ def main():
     noise = np.random.default_rng(0).standard_normal((B, h, h, 4)).astype(np.float32)
     sd.scheduler.set_timesteps(args.steps)
     variants = args.variant or ["base"]
-    keys = sorted({kv.split("=")[0] for v in variants if v != "base" for kv in v.split(",") if not kv.startswith("tune:")})
+    keys = sorted({kv.split("=")[0] for v in variants if v != "base" for kv in v.split(",") if not kv.startswith(("tune:", "py:"))})
+    from minsdtf_amd import engine as _engine
+
+    py_defaults = {}   # py:NAME=INT sets minsdtf_amd.engine.NAME (the emitters' module switches) for that variant
     from minsdtf_amd import tuning
 
     tuning._load()
@@ -54,11 +58,18 @@ def main():
             for k in keys:
                 lib.msd_set_option(k.encode(), defaults.get(k, DEFAULTS.get(k, 0)))
             tuning._table = dict(pristine)
+            for k, val in py_defaults.items():
+                setattr(_engine, k, val)
             if v != "base":
                 for kv in v.split(","):
                     if kv.startswith("tune:"):   # tune:FILE = JSON {shape key: [tile_m, tile_n, splitk, stages]} laid over the tuning table
                         with open(kv[5:]) as f:
                             tuning._table.update({k: list(e) + [0.0] for k, e in json.load(f).items()})
+                        continue
+                    if kv.startswith("py:"):
+                        k, val = kv[3:].split("=")
+                        py_defaults.setdefault(k, getattr(_engine, k))
+                        setattr(_engine, k, type(py_defaults[k])(int(val)))
                         continue
                     k, val = kv.split("=")
                     _lib.check(lib.msd_set_option(k.encode(), int(val)), kv)
