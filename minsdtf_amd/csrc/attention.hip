@@ -1403,7 +1403,7 @@ __device__ __forceinline__ void xr_load(xq_u32x4& dst, const void* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(ptr) : "memory");
 }
 
-template <int NW, int MODE = 0>   // MODE (experiments): 1 = no MFMAs in the projection loop, 2 = no ring traffic, 3 = neither
+template <int NW, int MODE = 0>   // MODE bits (experiments): 1 = no MFMAs in the projection loop, 2 = every chunk's loads aimed at chunk 0, 4 = no ring loads after chunk 0, 8 = no attention after the projection
 __global__ __launch_bounds__(64 * NW) void xattn_q160_kernel(XATTN_HOT_PARAMS, const XArgs p) {
     constexpr int D = 160, C = 8 * D, KC = C / 64, DB = D / 16, DCK = DB / 2;
     constexpr int NT = 64 * NW, QT = 16 * NW;
@@ -1480,8 +1480,11 @@ __global__ __launch_bounds__(64 * NW) void xattn_q160_kernel(XATTN_HOT_PARAMS, c
     auto issue = [&](int kc, int slot) {
         const uint32_t ko = (uint32_t)kc * hot_w_ks;
 #pragma unroll
-        for (int i = 0; i < DMAW; ++i) dma16s(hot_wq, (MODE & 2) ? woff[i] : woff[i] + ko, __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)(slot * W_STAGE + i * 1024)));
-        xq_load(xq[slot][0], xq[slot][1], xptr + ((MODE & 2) ? 0 : kc * 128));
+        for (int i = 0; i < DMAW; ++i) {
+            if ((MODE & 4) && kc > 0) continue;   // (the waits then count operations that were never issued: they pass at once)
+            dma16s(hot_wq, (MODE & 2) ? woff[i] : woff[i] + ko, __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)(slot * W_STAGE + i * 1024)));
+        }
+        if (!((MODE & 4) && kc > 0)) xq_load(xq[slot][0], xq[slot][1], xptr + ((MODE & 2) ? 0 : kc * 128));
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) issue(s, s);
@@ -1558,6 +1561,14 @@ __global__ __launch_bounds__(64 * NW) void xattn_q160_kernel(XATTN_HOT_PARAMS, c
         qpk[bb][1] = pack_bf2(rstd * (qacc[bb][2] - mean * csv[bb].z) + bsv[bb].z, rstd * (qacc[bb][3] - mean * csv[bb].w) + bsv[bb].w);
     }
     __syncthreads();   // the K / V^T images of the other waves (the loop's barriers have long ordered them; kept for the reader)
+    if (MODE & 8) {   // (no attention: the packed q of the head as the result, so that nothing above is dead code)
+        if (q0 + r < hot_s) {
+            bf16_t* op = p.out + ((size_t)b * hot_s + q0 + r) * p.o_ld + h * D;
+#pragma unroll
+            for (int bb = 0; bb < DB; ++bb) *reinterpret_cast<uint2*>(op + bb * 16 + 4 * g) = make_uint2(qpk[bb][0], qpk[bb][1]);
+        }
+        return;
+    }
     // ---- 3. S^T = K q^T (q carries scale * log2 e): lane holds keys 16 kb + 4 g + e of query r
     f32x4 sacc[TB];
 #pragma unroll
@@ -1911,6 +1922,9 @@ int msd_attention_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_q160_kernel<4, 15>), hipFuncAttributeMaxDynamicSharedMemorySize, xattn160_lds<4>());
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(attention): %s", hipGetErrorString(e));
     {
         int dev = 0;
@@ -2103,6 +2117,9 @@ extern "C" int msd_cross_attention_q(const MsdCrossAttnQ* q, msd_stream_t stream
             case 1: hipLaunchKernelGGL((xattn_q160_kernel<4, 1>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
             case 2: hipLaunchKernelGGL((xattn_q160_kernel<4, 2>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
             case 3: hipLaunchKernelGGL((xattn_q160_kernel<4, 3>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
+            case 7: hipLaunchKernelGGL((xattn_q160_kernel<4, 7>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
+            case 8: hipLaunchKernelGGL((xattn_q160_kernel<4, 8>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
+            case 15: hipLaunchKernelGGL((xattn_q160_kernel<4, 15>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
             default: hipLaunchKernelGGL((xattn_q160_kernel<4>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a);
         }
         MSD_CHECK_LAUNCH();
