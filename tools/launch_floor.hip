@@ -1,0 +1,22 @@
+// Micro-probe (not part of the product): what one kernel boundary costs inside a replayed hipGraph on this box.
+//   k_empty: nothing.   k_chain: every thread loads 16 B of what the PREVIOUS launch stored (ping-pong buffers), adds, stores 16 B.
+// tools/launch_floor.py captures N launches into a graph and reports the per-launch time for grids of 1 / 256 / 1024 workgroups
+// and chain footprints of 64 KB / 1 MB / 8 MB: launch + drain + the cross-XCD round trip of a dependent chain's first load.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+extern "C" __global__ __launch_bounds__(256) void k_empty() {}
+extern "C" __global__ __launch_bounds__(256) void k_chain(const uint4* in, uint4* out, int n16) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) {
+        uint4 v = in[i];
+        v.x += 1; v.y += v.x; v.z ^= v.y; v.w += 3;
+        out[i] = v;
+    }
+}
+extern "C" int launch_empty(int grid, void* stream) {
+    hipLaunchKernelGGL(k_empty, dim3(grid), dim3(256), 0, (hipStream_t)stream);
+    return (int)hipGetLastError();
+}
+extern "C" int launch_chain(const void* in, void* out, int n16, int grid, void* stream) {
+    hipLaunchKernelGGL(k_chain, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (uint4*)out, n16);
+    return (int)hipGetLastError();
+}
