@@ -54,11 +54,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--calls", type=int, default=48)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="msd_set_option switch, e.g. --opt splitk_xcd=0")
     args = ap.parse_args()
     from minsdtf_amd import _lib, ops, packing, tuning
 
     lib = _lib.load()
     lib.msd_init()
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.check(lib.msd_set_option(k.encode(), int(v)), kv)
     dev = torch.device("cuda:0")
     for idx, (name, B, H, W, c0, c1, N, ks) in enumerate(SHAPES):
         if args.only >= 0 and idx != args.only:

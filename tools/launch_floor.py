@@ -12,7 +12,7 @@ if not os.path.exists(so):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(here, "launch_floor.hip"), "-o", so])
 lib = C.CDLL(so)
 lib.launch_empty.argtypes = [C.c_int, C.c_void_p]
-lib.launch_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+lib.launch_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 N = 400
 
 
@@ -39,12 +39,13 @@ def graph_us(fn):
 torch.zeros(1, device="cuda")
 for grid in (1, 256, 1024):
     print(f"empty kernel, {grid:5d} workgroups: {graph_us(lambda i, s: lib.launch_empty(grid, s)):6.2f} us per launch", flush=True)
-for kb in (64, 1024, 8192):
+for kb in (64, 1024, 4096, 8192):
     n16 = kb * 1024 // 16
     a = torch.zeros(n16 * 4, dtype=torch.int32, device="cuda")
     b = torch.zeros_like(a)
     for grid in (256, 1024):
         if grid * 256 > n16 * 4:
             continue
-        us = graph_us(lambda i, s: lib.launch_chain((a if i % 2 == 0 else b).data_ptr(), (b if i % 2 == 0 else a).data_ptr(), n16, grid, s))
-        print(f"dependent chain, {kb:5d} KB read + written per launch, {grid:5d} workgroups: {us:6.2f} us per launch ({2 * kb * 1024 / us / 1e6:6.2f} TB/s)", flush=True)
+        for shift in (0, 1, 8):
+            us = graph_us(lambda i, s: lib.launch_chain((a if i % 2 == 0 else b).data_ptr(), (b if i % 2 == 0 else a).data_ptr(), n16, grid, shift, s))
+            print(f"dependent chain, {kb:5d} KB read + written per launch, {grid:5d} workgroups, reads workgroup + {shift}'s stores: {us:6.2f} us per launch ({2 * kb * 1024 / us / 1e6:6.2f} TB/s)", flush=True)
