@@ -28,6 +28,7 @@ void msd_set_conv_dense(int v);
 void msd_set_gn_wide(int v);
 void msd_set_gn_cluster(int v);
 void msd_set_gn_rows(int v);
+void msd_set_gn_xmap(int v);
 void msd_set_gn_poll_limit(int v);
 void msd_set_attn_qf(int v);
 void msd_set_xattn_nw(int v);
@@ -65,6 +66,7 @@ extern "C" int msd_set_option(const char* key, int value) {
         msd_set_gn_wide(value);
         return MSD_OK;
     }
+    if (key && strcmp(key, "gn_xmap") == 0) { msd_set_gn_xmap(value); return MSD_OK; }   // A/B runs: 0 = the cluster GroupNorm's parts of a group on consecutive workgroup ids
     if (key && strcmp(key, "gn_rows") == 0) {   // row-major cluster GroupNorm for samples of at least this many pixels [default 9216; 4096 pays at batch >= 2 per GPU]; 0 = never
         if (value < 0) MSD_FAIL(MSD_E_ARG, "set_option: gn_rows takes a pixel count >= 0, got %d", value);
         msd_set_gn_rows(value);

@@ -376,14 +376,29 @@ static_assert(GN_SYNC_GROUP_WORDS + GN_SYNC_WORDS_PER_SLOT + GN_ROWS_MAX_PARTS *
 constexpr int GN_POLL_LIMIT = 1 << 18;   // default bound of the exchange poll (set_option "gn_poll_limit": tests shorten it)
 
 template <int NPT, int V>
-__global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int pshift, int ppart, const GNArgs p,
+__global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int pshift, int ppart, int xsh, const GNArgs p,
                                                           uint32_t* sync_region, int poll_limit) {
     typedef typename gn_vec<V>::type vec_t;
     __shared__ float red[16][2];
     __shared__ float s_stat[2];
     const int t = threadIdx.x;
     const int P = 1 << pshift;
-    const int part = blockIdx.x & (P - 1), slot = blockIdx.x >> pshift;   // slot = b * 32 + g
+    // xsh = 0: the parts of a (sample, group) are consecutive workgroup ids.  xsh = 1 + log2(batch P / 8) (power of two): XCD x (=
+    // blockIdx.x & 7 under round-robin placement) takes the pixel ranges [x batch P / 8, (x + 1) batch P / 8) of the batch's row space for
+    // every group — the rows the conv / dense launches in front of and behind this one give that XCD (xcd_remap, n fastest), so what they
+    // stored and what they will read stays in its L2 (tools/launch_floor.py: another XCD's fresh stores arrive at half the rate).  The parts
+    // of a group, for all samples, then lie within batch P consecutive ids (host: <= 128): the progress argument below holds with that
+    // window.  Placement only: the same parts summed in the same order, the same bits.
+    int part, slot;   // slot = b * 32 + g
+    if (xsh) {
+        const int sh = xsh - 1, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int gp = (xcd << sh) + (j & ((1 << sh) - 1));   // global part index b P + part
+        part = gp & (P - 1);
+        slot = (gp >> pshift) * 32 + (j >> sh);
+    } else {
+        part = blockIdx.x & (P - 1);
+        slot = blockIdx.x >> pshift;
+    }
     const int b = slot >> 5, g = slot & 31;
     const int cpg = hot_C / 32;
     const int pl = udiv_magic(t, upp, mg_upp), u = t - pl * upp;   // my pixel lane, my unit inside the group's run
@@ -654,15 +669,27 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
 static int g_gn_poll_limit = GN_POLL_LIMIT;
 void msd_set_gn_poll_limit(int v) { g_gn_poll_limit = v; }
 
+static int g_gn_xmap = 1;   // cluster GroupNorm: 1 = XCD x takes the pixel ranges the convs around it give that XCD [default], 0 = a group's parts on consecutive ids (A/B runs; same bits)
+void msd_set_gn_xmap(int v) { g_gn_xmap = v ? 1 : 0; }
+
 template <int V>
 static void gn_cluster_launch(const GNArgs& a, int upp, int npt, dim3 grid, int pshift, int ppart, uint32_t* region, hipStream_t stream) {
     const dim3 block(1024);
     const int ppp = 1024 / upp;
     const uint32_t mg = udiv_magic_of(upp);
-    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
-    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
-    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
-    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, a, region, g_gn_poll_limit);
+    int xsh = 0;
+    {
+        const int bp = (int)(grid.x >> 5);   // batch x P (grid = batch x 32 groups x P parts)
+        if (g_gn_xmap && bp >= 8 && bp <= 128 && (bp & (bp - 1)) == 0 && (int)grid.x == bp * 32) {
+            int l = 0;
+            while ((8 << l) < bp) ++l;
+            xsh = l + 1;
+        }
+    }
+    if (npt <= 2) hipLaunchKernelGGL((gn_cluster_kernel<2, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, xsh, a, region, g_gn_poll_limit);
+    else if (npt <= 4) hipLaunchKernelGGL((gn_cluster_kernel<4, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, xsh, a, region, g_gn_poll_limit);
+    else if (npt <= 8) hipLaunchKernelGGL((gn_cluster_kernel<8, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, xsh, a, region, g_gn_poll_limit);
+    else if constexpr (V < 4) hipLaunchKernelGGL((gn_cluster_kernel<16, V>), grid, block, 0, stream, GN_HOT_ARGS(a), pshift, ppart, xsh, a, region, g_gn_poll_limit);
 }
 
 template <int V>
