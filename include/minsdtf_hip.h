@@ -236,6 +236,8 @@ MSD_API int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
  *             ROW-MAJOR form of the same exchange: 4-64 workgroups per SAMPLE, each owning a contiguous pixel range with all its
  *             channels (16-byte accesses), 64 granules per part; it shares the block (second region of every sample's share)
  *             and the give-up word.  (ABI 10: the share grew from 6,144 to 16,384 words for it.)
+ *             The per-(sample, group) form deals its workgroups by XCD (an XCD takes the pixel ranges whose rows the conv launches
+ *             around it give it; msd_set_option "gn_xmap" 0 = a group's parts on consecutive ids): placement only, the same bits.
  */
 #define MSD_GN_SYNC_WORDS_PER_SAMPLE 16384
 #define MSD_GN_MAX_CHUNKS 1024
