@@ -707,6 +707,12 @@ def test_group_norm_cluster(gpu, case, form):
         assert bool(torch.isfinite(half.float()).all())
         assert torch.equal(one[0].view(torch.int16), outs[0][last].view(torch.int16)), "a sample's bits depend on its batch"
         assert torch.equal(again.view(torch.int16), outs[0].view(torch.int16))
+        # the cluster form's workgroups dealt by XCD (norm.hip gn_cluster_kernel xsh, the default) against a group's parts on consecutive
+        # workgroup ids: which workgroup works on which (sample, group, part) is placement only
+        lib.msd_set_option(b"gn_xmap", 0)
+        plain = torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=d)
+        run_calls([launch(plain)])
+        assert torch.equal(plain.view(torch.int16), outs[0].view(torch.int16)), "the XCD dealing of the cluster form changed bits"
         # (error words: word 8 of the 96 group slots and of the row-major form's header slot of every sample; behind them lie granules)
         assert int(sync.view(B, -1, 64)[:, :97, 8].max()) == 0, "a workgroup gave up waiting for its group's partial moments"
         rows_ran = int(sync.view(B, -1)[:, 3 * 32 * 64].max()) > 0     # the row-major form's ticket: first word behind the 96 group slots
@@ -716,6 +722,7 @@ def test_group_norm_cluster(gpu, case, form):
     finally:
         lib.msd_set_option(b"gn_cluster", 256)
         lib.msd_set_option(b"gn_rows", 9216)
+        lib.msd_set_option(b"gn_xmap", 1)
 
 
 @pytest.mark.parametrize("form", ["groups", "rows"])
