@@ -150,6 +150,28 @@ def shutdown() -> None:
         torch.cuda.synchronize()
 
 
+def _apply_env_options(lib) -> None:
+    """Process-wide arithmetic choices made through the environment, validated before the library handle is cached.
+    MSD_GN_ROWS=<pixels>: the row-major cluster GroupNorm from that sample size on - 4096 pays from two images
+    per GPU and costs at one; MSD_PROFILE=throughput (parsed in ONE place, tuning.profile()) implies 4096 unless given.  Under
+    either setting a sample's bits do not depend on its batch."""
+    from . import tuning
+
+    try:
+        prof = tuning.profile()
+    except ValueError as e:
+        raise HipExtensionError(str(e)) from e
+    gn_rows = os.environ.get("MSD_GN_ROWS") or ("4096" if prof == "throughput" else "")
+    if not gn_rows:
+        return
+    try:
+        rows = int(gn_rows)
+    except ValueError as e:
+        raise HipExtensionError(f"MSD_GN_ROWS={gn_rows!r}: a pixel count (integer >= 0)") from e
+    if lib.msd_set_option(b"gn_rows", rows) != 0:
+        raise HipExtensionError(f"MSD_GN_ROWS={gn_rows}: {lib.msd_last_error().decode(errors='replace')}")
+
+
 def load() -> C.CDLL:
     """Load (once) and type the shared library.  Raises HipExtensionError when it is unusable."""
     global _lib
@@ -174,13 +196,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.msd_abi_version() != ABI_VERSION:
         raise HipExtensionError(f"ABI version mismatch: library {lib.msd_abi_version()} != binding {ABI_VERSION}")
+    _apply_env_options(lib)   # (raises: the library is NOT cached then, so the next load() fails the same way instead of running on defaults)
     _lib = lib
-    # serving choice: MSD_GN_ROWS=4096 puts the 64x64-level GroupNorms on the row-major cluster form - faster from two images per
-    # GPU, slower at one; a process-wide arithmetic choice (a sample's bits do not depend on its batch under either setting)
-    gn_rows = os.environ.get("MSD_GN_ROWS") or ("4096" if os.environ.get("MSD_PROFILE") == "throughput" else "")
-    if gn_rows:
-        if lib.msd_set_option(b"gn_rows", int(gn_rows)) != 0:
-            raise HipExtensionError(f"MSD_GN_ROWS={gn_rows}: {lib.msd_last_error().decode(errors='replace')}")
     global _shutdown_registered
     if not _shutdown_registered:
         atexit.register(shutdown)

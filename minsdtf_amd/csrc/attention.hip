@@ -1866,8 +1866,12 @@ static int g_attn_d160_pipe = 1;   // d = 160, 64-query workgroups: 1 = K/V tile
                                    // [default], 0 = load -> store -> compute (NBUF 1: the only form the 128-query workgroups have registers for).  Staging only:
                                    // the same bits.  The S <= 256 launches of the 16x16 / 8x8 levels put one wave on a SIMD of a quarter of the CUs: a serial chain
 void msd_set_attn_d160_pipe(int v) { g_attn_d160_pipe = v; }
-static int g_xattn160_mode = 0;   // (experiments: see xattn_q160_kernel's MODE)
-void msd_set_xattn160_mode(int v) { g_xattn160_mode = v; }
+#ifdef MSD_STAMPS
+static int g_xattn160_mode = 0;   // (experiments: see xattn_q160_kernel's MODE; the instrumented build only)
+int msd_set_xattn160_mode(int v) { g_xattn160_mode = v; return 1; }
+#else
+int msd_set_xattn160_mode(int v) { return v == 0; }   // the release library has the product instantiation only: any other mode is refused
+#endif
 static int g_xattn_nw = 0;    // 0 = automatic, 4 / 8 = waves (x 16 queries) per workgroup of the fused cross-attention (A/B runs)
 void msd_set_xattn_nw(int v) { g_xattn_nw = v; }
 
@@ -2113,6 +2117,7 @@ extern "C" int msd_cross_attention_q(const MsdCrossAttnQ* q, msd_stream_t stream
         const int qtiles = (q->s + 63) / 64;
         a.mg_heads = udiv_magic_of(q->heads); a.mg_qtiles = udiv_magic_of(qtiles);
         const dim3 grid160((unsigned)qtiles * q->batch * 8u);
+#ifdef MSD_STAMPS   // the kernel's experiment instantiations (deliberately wrong results) exist in the instrumented build only
         switch (g_xattn160_mode) {
             case 1: hipLaunchKernelGGL((xattn_q160_kernel<4, 1>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
             case 2: hipLaunchKernelGGL((xattn_q160_kernel<4, 2>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
@@ -2122,6 +2127,9 @@ extern "C" int msd_cross_attention_q(const MsdCrossAttnQ* q, msd_stream_t stream
             case 15: hipLaunchKernelGGL((xattn_q160_kernel<4, 15>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a); break;
             default: hipLaunchKernelGGL((xattn_q160_kernel<4>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a);
         }
+#else
+        hipLaunchKernelGGL((xattn_q160_kernel<4>), grid160, dim3(256), xattn160_lds<4>(), stream, XATTN_HOT_ARGS(a), a);
+#endif
         MSD_CHECK_LAUNCH();
         return MSD_OK;
     }

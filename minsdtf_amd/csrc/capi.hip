@@ -32,7 +32,7 @@ void msd_set_gn_xmap(int v);
 void msd_set_gn_poll_limit(int v);
 void msd_set_attn_qf(int v);
 void msd_set_xattn_nw(int v);
-void msd_set_xattn160_mode(int v);
+int msd_set_xattn160_mode(int v);
 void msd_set_attn_form(int v);
 void msd_set_attn_d160_pipe(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "gn_impl" (1 = single-launch per-group
@@ -56,7 +56,10 @@ extern "C" int msd_set_option(const char* key, int value) {
         msd_set_attn_d160_pipe(value ? 1 : 0);
         return MSD_OK;
     }
-    if (key && strcmp(key, "xattn160_mode") == 0) { msd_set_xattn160_mode(value); return MSD_OK; }
+    if (key && strcmp(key, "xattn160_mode") == 0) {   // experiment modes of xattn_q160_kernel (wrong results by design): `make stamps` build only
+        if (!msd_set_xattn160_mode(value)) MSD_FAIL(MSD_E_ARG, "set_option: xattn160_mode %d exists in the instrumented build (make stamps) only", value);
+        return MSD_OK;
+    }
     if (key && strcmp(key, "xattn_nw") == 0) {    // 0 = automatic [default], 4 / 8 = 64 / 128 queries per fused cross-attention workgroup
         if (value != 0 && value != 4 && value != 8) MSD_FAIL(MSD_E_ARG, "set_option: xattn_nw takes 0, 4 or 8");   // grid and kernel must agree on the tile
         msd_set_xattn_nw(value);

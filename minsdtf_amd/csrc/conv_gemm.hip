@@ -514,6 +514,10 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
         // ... and keeps the product in 32 bits
         if ((long long)q->batch * q->h_in * q->w_in * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 >= (1ll << 32) - 4096)
             MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: big-tile form needs input tensors under 4 GB");
+        // the shortcut operand (staged-halo variant) is addressed the same way, by OUTPUT pixel x c2 / c3 row bytes (the checks above
+        // hold a same-size output and no upsampling for it; the 4 GB bound on M x max(c2, c3) too)
+        if (q->a2 && ((long long)q->batch * q->h_out * q->w_out >= (1ll << 24) || (long long)(q->c2 > q->c3 ? q->c2 : q->c3) * 2 >= (1ll << 24)))
+            MSD_FAIL(MSD_E_UNSUPPORTED, "conv_gemm: big-tile form needs fewer than 2^24 output pixels / shortcut row bytes");
     }
     if (wreg != (q->w_layout == 2))
         MSD_FAIL(MSD_E_ARG, "conv_gemm: tile_m %d with w_layout %d (the fragment-major weight image, w_layout 2, is read by the wreg form, tile_m 4000 + rows, and by nothing else)",

@@ -245,6 +245,24 @@ GN_GIVE_UP_WORD = 8
 GN_EPOCH = 0
 
 
+def retire_stale(cache: dict) -> int:
+    """Drop the entries of a plan cache whose key ends in another GN_EPOCH than the current one (every such cache appends
+    the epoch to its keys), BEFORE the replacement is built: a retired engine / bound plan owns a device arena, a captured
+    hipGraph and a sync block, and the retry after a give-up must not have to fit next to them (768x768 or batch 4 would
+    run out of memory on the very call the mechanism exists for).  Returns the number of entries dropped."""
+    stale = [k for k in cache if k[-1] != GN_EPOCH]
+    for k in stale:
+        owner = cache.pop(k)
+        rel = getattr(owner, "release_graphs", None)
+        if rel is not None:
+            rel()
+    if stale:
+        import gc
+
+        gc.collect()   # (plans and their recorded closures reference one another: free the arenas now, not at some later collection)
+    return len(stale)
+
+
 def gn_sync_flags(device=None) -> Optional[torch.Tensor]:
     """Device int32 tensor with the give-up word of every live plan on `device` that owns a cluster-GroupNorm sync block
     (None when there is none).  Stream-ordered: queue it behind the job, copy it with the job's D2H, hand it to

@@ -254,6 +254,7 @@ class HipModel:
     # ---- plan cache
     def _bound(self, key, builder) -> "_BoundPlan":
         key = (key, engine.GN_EPOCH)   # (a reported cluster-GroupNorm give-up retires every recorded plan: engine.check_gn_sync)
+        engine.retire_stale(self._plans)   # ... and frees their arenas / graphs before the replacement is built
         bp = self._plans.get(key)
         if bp is None:
             self._require_weights()

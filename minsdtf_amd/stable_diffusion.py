@@ -734,14 +734,16 @@ class StableDiffusionBase:
                 return torch.from_numpy(finish(self.image_decoder.predict_on_batch(eng.latent), *host)).to(eng.latent.device)
             return self.image_decoder.decode_to_uint8(eng.latent)
 
+        # (a one-rank group with FORCE_COLLECTIVES still takes the real exchanges: tests/test_rccl_gpu.py)
+        sharded = world > 1 or (getattr(self, "shard_batch", False) and mdist.collectives_on())
         out = mdist.generate_sharded(local, context, unconditional_context, start_latent, dev,
-                                     per_sample=list(per_sample.values()), shared=list(shared.values()),
-                                     # (a one-rank group with FORCE_COLLECTIVES still takes the real exchanges: tests/test_rccl_gpu.py)
-                                     shard=world > 1 or (getattr(self, "shard_batch", False) and mdist.collectives_on()))
-        flags = engine.gn_sync_flags(dev) if out.device.type == "cuda" else None   # queued behind the job, read with its D2H
+                                     per_sample=list(per_sample.values()), shared=list(shared.values()), shard=sharded)
+        flags = engine.gn_sync_flags(dev)   # (None without a cluster-GroupNorm plan on `dev`) queued behind the job, read with its D2H
         host = out.cpu().numpy()
         if flags is not None:   # a cluster GroupNorm that gave up - on ANY rank of a sharded job: raise, never return that image
-            engine.check_gn_sync(flags.cpu(), device=dev, group_wide=world > 1 or mdist.collectives_on())
+            # group-wide ONLY for a job the group ran together: an independent replica (shard_batch False under a process
+            # group that exists for other reasons) must not issue a collective its peers never match
+            engine.check_gn_sync(flags.cpu(), device=dev, group_wide=sharded)
         return host
 
     def _engine(self, B, tc, tu, steps, g, phi, control, inpaint=False) -> DenoiseEngine:
@@ -752,6 +754,16 @@ class StableDiffusionBase:
         key = (B, tc, tu, steps, g, phi, control, self.denoise_streams, inpaint, self.active_tcd, wver, engine.GN_EPOCH)
         eng = self._engines.get(key)
         if eng is None:
+            # one resident engine (its arenas are the big allocations): the old one goes BEFORE the new one is built, so that a
+            # re-recording (another shape, new weights, a cluster-GroupNorm give-up: GN_EPOCH) never needs room for both
+            if self._engines:
+                import gc
+
+                for old in self._engines.values():
+                    old.release_graphs()
+                old = None
+                self._engines = {}
+                gc.collect()
             eng = DenoiseEngine(self.diffusion_model, B, tc, tu, steps, g, phi,
                                 control_net=self.control_net if control else None,
                                 hint_net=self.hint_net if control else None, use_graph=self.jit_compile,

@@ -315,6 +315,48 @@ def test_public_api_shards_the_batch_world2(tmp_path):
             np.testing.assert_array_equal(a, b)
 
 
+def _replica_worker(rank, world, port, out_dir):
+    """shard_batch False under a live process group: ONLY rank 0 generates (what sampling inside a DDP training job looks
+    like).  Any collective issued by that call would hang (rank 1 never matches it) or pair with an unrelated one."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from minsdtf_amd import dist as mdist
+    from minsdtf_amd import engine
+
+    mdist.init("gloo")
+    assert mdist.collectives_on()
+    if rank == 0:
+        def boom(*a, **k):
+            raise AssertionError("an independent replica touched the process group")
+
+        saved = (dist.all_reduce, dist.broadcast, dist.all_gather_into_tensor)
+        dist.all_reduce = dist.broadcast = dist.all_gather_into_tensor = boom
+        seen = []
+        real_check = engine.check_gn_sync
+        # the stub pipeline runs on the CPU, where no plan owns a sync block: hand the job a (clean) give-up word so that the
+        # check the GPU path makes after every job is made here too
+        engine.gn_sync_flags = lambda device=None: torch.zeros(1, dtype=torch.int32)
+        engine.check_gn_sync = lambda flags=None, device=None, group_wide=False: (seen.append(group_wide), real_check(flags, device, group_wide))[1]
+        try:
+            p = _stub_pipeline()
+            assert p.shard_batch is False
+            got = p.generate_image(**_api_cases(0)["txt2img"])
+            assert got.shape[0] == 4 and p.engine_batches[-1] == 4
+            assert seen == [False]
+        finally:
+            dist.all_reduce, dist.broadcast, dist.all_gather_into_tensor = saved
+        np.save(os.path.join(out_dir, "replica_ok.npy"), np.asarray([1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_independent_replica_issues_no_collective_world2(tmp_path):
+    """generate_image's give-up check was group-wide whenever a process group with more than one rank
+    existed - also for an independent replica (shard_batch False).  The check follows the same predicate as the sharding."""
+    mp.spawn(_replica_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "replica_ok.npy"))
+
+
 def test_public_api_rejects_indivisible_batch():
     from minsdtf_amd.dist import shard_bounds
 

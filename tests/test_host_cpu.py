@@ -454,3 +454,99 @@ def test_product_path_does_not_import_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+# ------------------------------------------------------------------ round-6 hygiene
+def test_plan_caches_retire_stale_epochs(monkeypatch):
+    """A reported cluster-GroupNorm give-up bumps engine.GN_EPOCH; every cache keyed on it must DROP the old-epoch entries
+    (arena + hipGraph + sync block each) before the replacement is built, not keep them beside it."""
+    from minsdtf_amd import engine, models
+
+    released = []
+
+    class Owner:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def release_graphs(self):
+            released.append(self.tag)
+
+    monkeypatch.setattr(engine, "GN_EPOCH", 3)
+    cache = {(("a",), 2): Owner("old-a"), (("b",), 3): Owner("cur-b"), (("c",), 1): Owner("old-c")}
+    assert engine.retire_stale(cache) == 2
+    assert list(cache) == [(("b",), 3)] and sorted(released) == ["old-a", "old-c"]
+    assert engine.retire_stale(cache) == 0
+    # HipModel._bound purges before it builds
+    m = models.HipModel.__new__(models.HipModel)
+    m._plans = {(("x",), 2): Owner("old-x")}
+    m._W = object()
+    m.name = "stub"
+    built = m._bound(("x",), lambda: Owner("new-x"))
+    assert built.tag == "new-x" and list(m._plans) == [(("x",), 3)] and "old-x" in released
+
+
+def test_engine_cache_holds_one_engine(monkeypatch):
+    """StableDiffusion._engine: the resident engine is released BEFORE its replacement is constructed."""
+    import minsdtf_amd.stable_diffusion as sdm
+    from minsdtf_amd import engine
+
+    events = []
+
+    class FakeEngine:
+        def __init__(self, *a, **kw):
+            events.append("build")
+
+        def release_graphs(self):
+            events.append("release")
+
+    class FakeModel:
+        weights_version = 1
+
+    monkeypatch.setattr(sdm, "DenoiseEngine", FakeEngine)
+    sd = sdm.StableDiffusion.__new__(sdm.StableDiffusion)
+    sd._engines, sd.denoise_streams, sd.active_tcd, sd.jit_compile = {}, 1, False, True
+    sd._diffusion_model = FakeModel()
+    sd._control_net = sd._hint_net = None
+    e1 = sd._engine(1, 77, 77, 25, 7.5, 0.7, False)
+    assert sd._engine(1, 77, 77, 25, 7.5, 0.7, False) is e1 and events == ["build"]
+    monkeypatch.setattr(engine, "GN_EPOCH", engine.GN_EPOCH + 1)
+    e2 = sd._engine(1, 77, 77, 25, 7.5, 0.7, False)
+    assert e2 is not e1 and events == ["build", "release", "build"] and list(sd._engines.values()) == [e2]
+
+
+def test_env_options_are_validated_before_the_library_is_cached(monkeypatch):
+    """_lib.load(): a bad MSD_GN_ROWS / MSD_PROFILE raises HipExtensionError and leaves NO cached handle behind (the next
+    load() must fail the same way, never run silently on the defaults)."""
+    from minsdtf_amd import _lib
+
+    _lib.load()   # (make sure the file exists / is loadable at all)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("MSD_GN_ROWS", "lots")
+    for _ in range(2):
+        with pytest.raises(_lib.HipExtensionError, match="MSD_GN_ROWS"):
+            _lib.load()
+        assert _lib._lib is None
+    monkeypatch.setenv("MSD_GN_ROWS", "-5")
+    with pytest.raises(_lib.HipExtensionError, match="MSD_GN_ROWS"):
+        _lib.load()
+    monkeypatch.delenv("MSD_GN_ROWS")
+    monkeypatch.setenv("MSD_PROFILE", "Throughput")
+    with pytest.raises(_lib.HipExtensionError, match="MSD_PROFILE"):
+        _lib.load()
+    assert _lib._lib is None
+    monkeypatch.delenv("MSD_PROFILE")
+    lib = _lib.load()
+    assert _lib._lib is lib
+    assert lib.msd_set_option(b"gn_rows", 9216) == 0   # (back to the default for whatever test runs next in this process)
+
+
+def test_release_library_refuses_experiment_modes():
+    """msd_set_option("xattn160_mode", != 0) selects kernel instantiations that compute wrong results on purpose: they exist
+    in the instrumented build (make stamps) only, the release library says so instead of switching."""
+    from minsdtf_amd import _lib
+
+    lib = _lib.load()
+    assert lib.msd_set_option(b"xattn160_mode", 0) == 0
+    for mode in (1, 2, 8, 15):
+        assert lib.msd_set_option(b"xattn160_mode", mode) == -1
+        assert b"instrumented build" in lib.msd_last_error()

@@ -88,7 +88,8 @@ def main():
                                      scale=d ** -0.5, q_prescaled=True))
         tfs = []
         for m in [int(v) for v in args.modes.split(",")]:
-            lib.msd_set_option(b"xattn160_mode", m)
+            # (modes other than 0 exist in the instrumented build only: make -C minsdtf_amd/csrc stamps, MSD_HIP_LIB=tools/_build/libminsdtf_hip_stamps.so)
+            _lib.check(lib.msd_set_option(b"xattn160_mode", m), "xattn160_mode")
             tfs.append(f"{graph_time(fused):7.2f}")
         lib.msd_set_option(b"xattn160_mode", 0)
         tt = graph_time(two) * 2
