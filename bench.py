@@ -33,6 +33,7 @@ import time
 
 import numpy as np
 
+T_PROCESS_START = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -215,9 +216,14 @@ def launch_ranks(n: int, argv) -> int:
 
     port = _free_port()
     procs = []
+    import shutil
+    import tempfile
+
+    # rank 0 hands its packed weights to the other ranks through this RAM-backed directory (load_synthetic_shared); ours to remove
+    shm = tempfile.mkdtemp(prefix="msd_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSD_BENCH_LAUNCHER="self")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSD_BENCH_LAUNCHER="self", MSD_BENCH_SHARE_DIR=shm)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only mode this host driver supports for RCCL
         env.setdefault("NCCL_DEBUG", "WARN")                # RCCL's own reason for a failed init / collective reaches the log verbatim
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
@@ -282,6 +288,7 @@ def launch_ranks(n: int, argv) -> int:
         rc = 128 + int(e.args[0])
     finally:
         stop_all()   # (no-op when every rank has exited)
+        shutil.rmtree(shm, ignore_errors=True)
         for sg, h in old.items():
             signal.signal(sg, h)
     th.join(timeout=10)
@@ -298,6 +305,45 @@ def launch_ranks(n: int, argv) -> int:
     return rc if 0 <= rc < 256 else 1
 
 
+def share_dir(world: int):
+    """Directory (RAM-backed) through which rank 0 hands its PACKED weights to the other ranks of the node, or None (one
+    rank, or MSD_BENCH_SHARE_WEIGHTS=0).  The launcher names it ($MSD_BENCH_SHARE_DIR) and removes it at the end; under
+    torchrun it is derived from the rendezvous port, and rank 0 removes it after the closing barrier."""
+    if world <= 1 or os.environ.get("MSD_BENCH_SHARE_WEIGHTS", "1") == "0":
+        return None
+    d = os.environ.get("MSD_BENCH_SHARE_DIR")
+    if not d:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else os.environ.get("TMPDIR", "/tmp")
+        d = os.path.join(base, f"msd_bench_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def load_synthetic_shared(model, rank: int, sdir, seed=0, bias_scale=0.0, wait_s=600.0):
+    """model.load_synthetic(seed, bias_scale) on rank 0 - which then writes the packed result into `sdir` - and a map + upload
+    of that file on the other ranks (8 ranks generating and packing the same 3.4 GB of fp32 draws is 8x the host work for
+    nothing).  Same tensors bit for bit: what the ranks launch on IS rank 0's packing.  Returns the Keras-layout arrays on
+    rank 0 (the CPU baseline wants them), None elsewhere.  A rank whose file does not appear within `wait_s` seconds says so
+    and generates its own copy (rank 0 died: the launcher is about to end this rank anyway)."""
+    if sdir is None:
+        return model.load_synthetic(seed=seed, bias_scale=bias_scale)
+    path = os.path.join(sdir, f"{model.name}.packed.pt")
+    meta = dict(seed=seed, bias_scale=bias_scale)
+    if rank == 0:
+        arrays = model.load_synthetic(seed=seed, bias_scale=bias_scale)
+        model.save_packed(path, **meta)
+        return arrays
+    t_end = time.time() + wait_s
+    while not os.path.exists(path):
+        if time.time() > t_end:
+            log(f"[rank {rank}] {path} did not appear in {wait_s:.0f} s: generating {model.name}'s weights here")
+            model.load_synthetic(seed=seed, bias_scale=bias_scale)
+            return None
+        time.sleep(0.05)
+    model.load_packed(path, **meta)
+    return None
+
+
 def stub_generate(ctx, unc, z, *rest):
     """--stub-local: a per-sample function of the sliced inputs (no cross-sample coupling, like the real pipeline), so the
     gathered batch proves broadcast, slicing and gather order.  uint8 [b, 4, 4, 3]."""
@@ -309,6 +355,20 @@ def stub_generate(ctx, unc, z, *rest):
         e = torch.as_tensor(np.asarray(e.cpu()) if isinstance(e, torch.Tensor) else e).float()
         v = v + e.reshape(e.shape[0], -1).mean(dim=1, keepdim=True) * 50
     return torch.clamp(v + 128, 0, 255).to(torch.uint8).reshape(z.shape[0], 4, 4, 3)
+
+
+def gather_scalars(x, dev, world):
+    """One float per rank, rank order (None where a rank has none)."""
+    import torch
+    import torch.distributed as dist
+
+    v = float("nan") if x is None else float(x)
+    if world == 1:
+        return [None if v != v else v]
+    mine = torch.tensor([v], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    return [None if float(t.item()) != float(t.item()) else round(float(t.item()), 2) for t in every]
 
 
 def rank_devices(dev, world):
@@ -413,14 +473,15 @@ def main(argv=None):
         t0 = time.time()
         sd = StableDiffusion(size, size, jit_compile=not args.no_graph, device=dev)
         sd.denoise_streams = args.streams or None
-        unet_arrays = sd.diffusion_model.load_synthetic(seed=0)
-        vae_arrays = sd.image_decoder.load_synthetic(seed=0)
+        sdir = share_dir(world)   # N > 1: rank 0 generates + packs, the others map its packed file (None at N = 1)
+        unet_arrays = load_synthetic_shared(sd.diffusion_model, rank, sdir)
+        vae_arrays = load_synthetic_shared(sd.image_decoder, rank, sdir)
         if args.controlnet:  # zero-convs are NOT zero (bias_scale > 0 also draws non-trivial biases), else the path is vacuous
-            sd.control_net.load_synthetic(seed=0, bias_scale=0.05)
-            sd.hint_net.load_synthetic(seed=0, bias_scale=0.05)
+            load_synthetic_shared(sd.control_net, rank, sdir, bias_scale=0.05)
+            load_synthetic_shared(sd.hint_net, rank, sdir, bias_scale=0.05)
         if rank != 0 or args.no_cpu_baseline:
             unet_arrays = vae_arrays = None
-        log(f"[rank {rank}] weights generated + packed in {time.time() - t0:.1f}s")
+        log(f"[rank {rank}] weights {'generated + packed' if rank == 0 or sdir is None else 'mapped from rank 0 (' + sdir + ')'} in {time.time() - t0:.1f}s")
         out_shape = (gb, size, size, 3)
 
         def local(c, u, z, *hint):
@@ -444,13 +505,19 @@ def main(argv=None):
         sd.scheduler.set_timesteps(nsteps)
 
     first = [True]
+    first_job_s = [None]   # this rank's wall time from interpreter start to the end of its first (warm-up) job
 
     def one_job():
         if not first[0]:
             return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases, per_sample=hints)
         first[0] = False
         try:   # the first broadcast / all-gather: where an IPC or topology problem of RCCL shows
-            return sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases, per_sample=hints)
+            res = sharded_job(local, ctx, unc, noise, dev, sync_phases=args.sync_phases, per_sample=hints)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            first_job_s[0] = round(time.time() - T_PROCESS_START, 2)
+            log(f"[rank {rank}] process start -> first job done: {first_job_s[0]:.1f} s")
+            return res
         except Exception as e:
             log(f"[rank {rank}] first job FAILED: {type(e).__name__}: {e} (HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})")
             raise
@@ -471,6 +538,9 @@ def main(argv=None):
         "config": {"workload": f"SD1.5 {size}x{size} {nsteps}-step txt2img, CFG 7.5 + rescale 0.7, batch {b}/GPU, "
                                f"UNet+VAE{'+ControlNet' if args.controlnet else ''} HIP path, random-init weights", "global_batch": gb,
                    "parallelism": f"batch-shard x{world}", "hipgraph": not args.no_graph,
+                   # what a job does NOT redo: uploaded / computed when the schedule changes (DenoiseEngine.prepare), i.e. once for the run;
+                   # everything else of the hot path (context K/V, the loop, decode, D2H) runs inside every timed job
+                   "cached_across_jobs": ["sampler coefficient table", "time-embedding table (25 x timestep MLP + the 22 ResBlock projections)"],
                    # process-wide arithmetic choices read from the environment (minsdtf_amd/tuning.py, _lib.py): "latency" = the default
                    "profile": os.environ.get("MSD_PROFILE", "latency") or "latency", "gn_rows": os.environ.get("MSD_GN_ROWS")},
         "n_ranks_seen": n_ranks_seen, "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
@@ -478,6 +548,7 @@ def main(argv=None):
         "rank_devices": rank_devices(dev, world),
         "per_rank_ms": per_rank_ms,   # each rank's own elapsed over the timed jobs (its last job drained), rank order
         "ipc_mode": {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "NCCL_DEBUG": os.environ.get("NCCL_DEBUG")},
+        "start_to_first_job_s": gather_scalars(first_job_s[0], dev, world),   # per rank: interpreter start -> first job finished (weights, plans, capture)
     }
     if args.force_collectives:
         out["collectives_forced"] = True   # broadcast + all-gather ran through the process group at every job, also at world 1
@@ -499,6 +570,12 @@ def main(argv=None):
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not stub and "MSD_BENCH_SHARE_DIR" not in os.environ and world > 1:   # (torchrun: nobody else will)
+        import shutil
+
+        d = share_dir(world)
+        if d:
+            shutil.rmtree(d, ignore_errors=True)
 
 
 def rank0_extras(out, args, sd, world, b, nsteps, size, ctx, unc, noise, hints, unet_arrays, vae_arrays):
@@ -523,6 +600,15 @@ def rank0_extras(out, args, sd, world, b, nsteps, size, ctx, unc, noise, hints, 
     out["launches_per_step"] = len(eng.calls)   # C-ABI calls of one sampler step (split-K reductions / second GroupNorm launches come on top)
     if not args.no_roofline:
         out["roofline"], out["roofline_by_kernel"], extra = kernel_roofline(sd, b, nsteps, args.controlnet, size)
+        ig = out["roofline"].get("in_graph")
+        if ig is not None:
+            # the trace's durations come from the PROFILED child pass, which runs a few per cent slower than the timed region: the
+            # wall clock of a fused step of THIS process stands beside the trace's sum, so the two can be reconciled from the line
+            ig["wall_us_per_fused_step"] = round(1e3 * out["ms_denoise_loop"] / nsteps, 1)
+            tot = sum(ig["all_families_us_per_fused_step"].values())
+            ig["trace_sum_over_wall"] = round(tot / ig["wall_us_per_fused_step"], 4)
+            ig["note"] = ("all_families_us_per_fused_step sums kernel durations of the rocprofv3 child pass (profiler skew included, no launch "
+                          "gaps); wall_us_per_fused_step = ms_denoise_loop / denoise steps of this process, unprofiled: not a budget of one another")
         out["eager_ms_per_unet_step_by_entry_point"] = extra  # event-per-launch pass (includes ~1-2 us of event gap per call)
     if world == 1 and not args.controlnet:
         out["psnr_db_vs_oracle_golden"] = golden_psnr(sd, size, nsteps)

@@ -132,6 +132,18 @@ class HipModel:
         self.set_weights(arrays)
         return arrays
 
+    def save_packed(self, path: str, **meta) -> None:
+        """The packed device weights of this model -> `path` (packing.save_packed; `meta`: whatever identifies the
+        checkpoint, compared by load_packed)."""
+        self._require_weights()
+        packing.save_packed(self._W, path, dict(meta, kind=self.kind, table_kw=self._table_kw()))
+
+    def load_packed(self, path: str, **meta) -> None:
+        """Adopt weights another process packed (save_packed): no generation, no packing pass, one upload."""
+        self._W = packing.load_packed(path, self.device, dict(meta, kind=self.kind, table_kw=self._table_kw()))
+        self.weights_version += 1
+        self._plans.clear()
+
     def _maybe_load(self, ckpt_path, lora_dict=None):
         """Reference constructors load a local checkpoint if given one; no network download here."""
         if ckpt_path is not None and os.path.exists(ckpt_path):

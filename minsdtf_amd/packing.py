@@ -133,3 +133,29 @@ def fold_layer_norm(w_oi: torch.Tensor, bias, gamma: np.ndarray, beta: np.ndarra
 
 def dev_f32(a: np.ndarray, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+# ---- packed weights on disk (one rank packs, the others map) ----------------------------------------------------------------
+def save_packed(W: PackedWeights, path: str, meta: dict = None) -> None:
+    """Write a PackedWeights (the device tensors the launch plans read: bf16 matrices in their stored layout, fp32 vectors)
+    to `path`, atomically (temp file + rename: a reader never sees a partial file).  Meant for a RAM-backed directory
+    (/dev/shm): the ranks of one node then map what rank 0 packed instead of each generating and packing its own copy
+    (bench.py, N > 1).  Fragment-major copies are not saved: every plan makes the ones its table asks for."""
+    import os
+
+    blob = {"meta": dict(meta or {}), "chunk_major": sorted(W.chunk_major_keys),
+            "tensors": {k: (t.detach().cpu() if isinstance(t, torch.Tensor) else t) for k, t in W.items()}}
+    tmp = f"{path}.tmp.{os.getpid()}"
+    torch.save(blob, tmp)
+    os.replace(tmp, path)
+
+
+def load_packed(path: str, device, meta: dict = None) -> PackedWeights:
+    """The inverse of save_packed, onto `device`; `meta` (if given) must equal what the writer recorded (network kind,
+    table arguments, seed): a file of another model raises instead of being launched on."""
+    blob = torch.load(path, map_location="cpu", mmap=True, weights_only=True)
+    if meta is not None and blob["meta"] != dict(meta):
+        raise ValueError(f"{path}: packed for {blob['meta']}, wanted {dict(meta)}")
+    W = PackedWeights({k: (t.to(device) if isinstance(t, torch.Tensor) else t) for k, t in blob["tensors"].items()})
+    W.chunk_major_keys = set(blob["chunk_major"])
+    return W

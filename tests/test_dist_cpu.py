@@ -392,6 +392,7 @@ def test_bench_launches_its_own_ranks():
     # what a first real SCALE run needs to be diagnosable: every rank's own time, and the IPC mode the ranks ran with
     assert len(out["per_rank_ms"]) == 2 and all(0 < ms <= out["ms_per_step"] * out["steps"] + 1e-3 for ms in out["per_rank_ms"])
     assert out["ipc_mode"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and out["ipc_mode"]["NCCL_DEBUG"]
+    assert len(out["start_to_first_job_s"]) == 2 and all(t is not None and t > 0 for t in out["start_to_first_job_s"])
     one = _run_bench("--gpus", "1", "--batch-per-gpu", "2", "--backend", "gloo", "--stub-local", "--steps", "1", "--controlnet", "--size", "64")
     assert one.returncode == 0, one.stderr[-2000:]
     ref = json.loads(one.stdout.strip().splitlines()[-1])
@@ -438,3 +439,48 @@ def test_forced_collectives_world1_gloo():
                        stderr=subprocess.PIPE, text=True, timeout=110)
     assert p.returncode == 0, p.stderr[-3000:]
     assert any(ln.startswith("OK ") for ln in p.stdout.splitlines())
+
+
+def test_ranks_map_rank0s_packed_weights(tmp_path):
+    """bench.load_synthetic_shared: rank 0 generates + packs and writes the packed tensors; every other rank maps that file
+    (no generation, no packing) and ends up with the same tensors and layouts; a file of another checkpoint is refused."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from minsdtf_amd import packing
+
+    class Model:
+        name, kind, device = "toy", "toy_kind", torch.device("cpu")
+
+        def __init__(self):
+            self._W, self.generated, self.weights_version, self._plans = None, 0, 0, {}
+
+        def _table_kw(self):
+            return {}
+
+        def _require_weights(self):
+            assert self._W is not None
+
+        def load_synthetic(self, seed=0, bias_scale=0.0):
+            self.generated += 1
+            g = torch.Generator().manual_seed(seed)
+            W = packing.PackedWeights({"l.w": torch.randn(64, 128, generator=g).to(torch.bfloat16), "l.b": torch.randn(64, generator=g) * bias_scale})
+            W.to_chunk_major("l.w")
+            self._W = W
+            return ["keras arrays"]
+
+    from minsdtf_amd.models import HipModel
+
+    Model.save_packed, Model.load_packed = HipModel.save_packed, HipModel.load_packed
+    r0, r1 = Model(), Model()
+    assert bench.load_synthetic_shared(r0, 0, str(tmp_path), seed=3, bias_scale=0.5) == ["keras arrays"]
+    assert bench.load_synthetic_shared(r1, 1, str(tmp_path), seed=3, bias_scale=0.5) is None
+    assert r1.generated == 0 and r1._W.layout("l.w") == 1 and r1.weights_version == 1
+    for k in r0._W:
+        assert torch.equal(r0._W[k], r1._W[k])
+    with pytest.raises(ValueError):
+        bench.load_synthetic_shared(Model(), 1, str(tmp_path), seed=4, bias_scale=0.5)
+    late = Model()   # the file never appears (rank 0 gone): the rank says so and makes its own copy
+    assert bench.load_synthetic_shared(late, 1, str(tmp_path / "empty"), seed=3, wait_s=0.2) is None and late.generated == 1
+    assert bench.share_dir(1) is None

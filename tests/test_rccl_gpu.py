@@ -27,3 +27,34 @@ def test_rccl_world1_collectives_and_pipeline(gpu):
     info = json.loads(ok[-1][3:])
     print("RCCL world-1:", info)
     assert info["backend"] == "nccl" and info["world"] == 1 and info["device"] == "cuda:0" and info["pipeline"] == "bit-identical"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_through_rccl_with_shared_weights(gpu, tmp_path):
+    """First-contact rehearsal of the driver's SCALE command.  On a box with >= 2 GPUs: `python bench.py --gpus 2` - the
+    launcher starts two fresh ranks before anything touches a GPU, rank 1 maps the weights rank 0 packed (/dev/shm), both run
+    the real pipeline over RCCL, the line carries two devices, two first-job times and rank 0's image hash.  On a one-GPU box
+    (this pool): the same bench through a ONE-rank RCCL group with its exchanges forced, so the RCCL code path of bench.py
+    itself (packed broadcast, all-gather, the timing collectives) still runs here."""
+    import torch
+
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--size", "64",
+           "--denoise-steps", "3", "--no-cpu-baseline", "--no-roofline"] + (["--force-collectives"] if n == 1 else [])
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=850)
+    assert p.returncode == 0, f"bench failed ({p.returncode}):\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
+    lines = [ln for ln in p.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["n_ranks_seen"] == n and out["backend"].startswith("nccl") and out["value"] > 0
+    assert len(out["per_rank_ms"]) == n and len(out["start_to_first_job_s"]) == n and all(t and t > 0 for t in out["start_to_first_job_s"])
+    assert out["config"]["global_batch"] == n
+    if n == 2:
+        assert len({d["hip_device"] for d in out["rank_devices"]}) == 2
+        assert "mapped from rank 0" in p.stderr   # rank 1 did not generate its own weights
+    else:
+        assert out.get("collectives_forced") is True
