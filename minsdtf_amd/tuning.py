@@ -126,8 +126,9 @@ def _load() -> Dict[str, list]:
 
 
 def heuristic(M: int, N: int, nk: int, allow_split: bool) -> Tuple[int, int, int, int]:
-    """(tile_m, tile_n, splitk, stages) when the shape has not been measured.  M = rows of ONE sample: split-K and the
-    column tile are part of a layer's arithmetic (order of the fp32 sums) and must not depend on the batch."""
+    """(tile_m, tile_n, splitk, stages) on the plain tile kernel from the sizes alone (the tuner's starting point and the
+    tensor-less shape walks).  M = rows of ONE sample: split-K and the column tile are part of a layer's arithmetic (order of
+    the fp32 sums) and must not depend on the batch."""
     bn = 128 if (N % 128 == 0 or N > 1024) else 64
     bm = 128
     if M <= 64:
@@ -137,6 +138,104 @@ def heuristic(M: int, N: int, nk: int, allow_split: bool) -> Tuple[int, int, int
     if allow_split and tiles < 160 and nk >= 32:
         sk = max(1, min((256 + tiles - 1) // tiles, nk // 8, 16))
     return bm, bn, sk, 0
+
+
+def _ceil_div(a: int, b: int) -> int:
+    return -(-a // b)
+
+
+def shape_class(h_in, w_in, cin, N, ksize, stride, upsample, allow_split, cx=0) -> Tuple[str, int, int]:
+    """The ARITHMETIC of a layer that is not in the table, from the shape of ONE sample only: (K walk, split-K slices,
+    column tile of the LayerNorm-fold partials or 0).  K walk: "chunk" = chunk-major (the halo-tile kernel's order: for every
+    64-channel chunk its nine taps; split-K over chunks), "chunk_sc" = the same with the shortcut chunks behind a slice's main
+    chunks (staged-halo big form), "tap" = tap-major (tile / wreg / big forms; split-K over K tiles).  What the measured table
+    shows per shape class (tools/tune_conv.py + tune_insitu.py, 512x512 / 768x768, batches 1-8) written as rules: the forms this
+    library's speed lives in reach any image size, not only the tuned ones."""
+    hl, wl = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
+    pad = 1 if ksize == 3 else 0
+    ho, wo = (hl + 2 * pad - ksize) // stride + 1, (wl + 2 * pad - ksize) // stride + 1
+    hw_out = ho * wo
+    nkc = cin // 64
+    nk = ksize * ksize * nkc + cx // 64
+    tile16 = stride == 1 and hl % 16 == 0 and wl % 16 == 0
+    walk = "tap"
+    if ksize == 3 and stride == 1:
+        if cx == 0 and not upsample and w_in % 16 == 0 and h_in % 8 == 0 and hw_out >= 256:
+            walk = "chunk"       # halo-tile kernel (8 x 16-pixel tiles), staged-halo big form on whole 16 x 16 tiles
+        elif cx == 0 and upsample and tile16 and h_in * w_in >= 256:
+            walk = "chunk"       # nearest x2 + conv on the staged halo (chunk-major big form where the tiles are not whole)
+        elif cx and tile16 and hw_out >= 2304:
+            walk = "chunk_sc"    # shortcut-folded conv on the staged halo: pays from 48 x 48 pixels per sample at every batch
+    sk = 1
+    if allow_split:
+        if walk != "tap":
+            wgs = _ceil_div(hw_out, 128) * _ceil_div(N, 64)      # 8 x 16-pixel tiles x 64 columns, per sample
+            if wgs < 256 and hw_out < 4096:
+                sk = max(1, min(_ceil_div(512, 2 * wgs), nkc // (2 if N < 64 else 6)))
+        elif ksize == 3 or nk >= 32:                             # 3x3 on the tile forms, long-K Dense (ff.net.2 + proj_out, K = 5 C)
+            if ksize == 3 and hw_out < 4096:
+                sk = max(1, min(_ceil_div(96, max(1, int(hw_out ** 0.5))), nk // 8, 16))
+            elif ksize == 1 and hw_out < 1024:
+                sk = max(1, min(_ceil_div(48, max(1, int(hw_out ** 0.5))), nk // 8, 16))
+        elif nk >= 16:                                            # short-K Dense at the lowest levels
+            sk = 4 if hw_out <= 64 else 2 if hw_out <= 144 else 1
+    ln_tile = 64 if (ksize == 1 and allow_split and cx == 0 and cin == N) else 0   # (the layers that may produce LayerNorm-fold partials)
+    return walk, sk, ln_tile
+
+
+def shape_config(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split, cx=0) -> Tuple[int, int, int, int]:
+    """(tile_m, tile_n, splitk, stages) for a layer the table has no entry of: the arithmetic from shape_class() (per-sample
+    shape: a sample's bits do not depend on its batch), the kernel FORM inside that class from the size of the whole launch
+    (bit-neutral: row tile, 3x3 column tile, ring depth, wave layout, row-panel / wreg / big / staged-halo form).  Every
+    configuration named here is one the library builds and the table uses somewhere."""
+    walk, sk, ln_tile = shape_class(h_in, w_in, cin, N, ksize, stride, upsample, allow_split, cx)
+    hl, wl = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
+    tile16 = stride == 1 and hl % 16 == 0 and wl % 16 == 0
+    wide = 128 if (N % 128 == 0 or N > 1024) else 64
+    if walk == "chunk_sc":
+        return 5256, 128, sk, 20
+    if walk == "chunk":
+        wgs16 = batch * (hl // 16) * (wl // 16) * _ceil_div(N, 128) * sk if tile16 else 0
+        if upsample:
+            if tile16:
+                return 5256, (160 if (N % 160 == 0 and M >= 32768) else 128), sk, 20
+            return 5256, 128, sk, 10      # (never reached today: "chunk" + upsample implies whole tiles)
+        if N >= 128 and wgs16 >= 128:     # the staged-halo big form once it fills half the chip
+            return 5256, (160 if (N % 160 == 0 and M >= 32768 and allow_split) else 128), sk, 20
+        if M <= 4096 or N < 80:
+            return 2128, 64, sk, (33 if M <= 16384 else 0)
+        return 1128, (80 if (N % 80 == 0 and allow_split) else 64), sk, 93
+    # ---- tap-major: tile / row-panel / wreg / big forms
+    if ln_tile:                            # C -> C 1x1 that may write LayerNorm partials: the column tile is part of the class
+        return (64, 64, sk, 0) if M <= 2048 else (128, 64, sk, 13)
+    if ksize == 1 and not allow_split:     # q|k|v, GEGLU and context k|v projections (never split, never LayerNorm producers)
+        if cin in ROWPANEL_ROWS and N % 32 == 0 and M >= 4096 and stride == 1 and not upsample and not cx:
+            panels = _ceil_div(M, 128)
+            cols = [c for c in ROWPANEL_COLS if N % c == 0]
+            fit = [c for c in cols if panels * (N // c) >= 512]
+            if cols:
+                return ROWPANEL_ROWS[cin][0], (max(fit) if fit else min(cols)), 1, 0
+        if M <= 512:
+            return 64, 64, 1, 14
+        if M <= 4096 or N <= 64:
+            return 128, wide, 1, 0
+        return 256, 128, 1, 0
+    if ksize == 1 and nk < 32:             # short-K 1x1 with cin != N (conv_shortcut, zero convs, time-embedding projections)
+        if M <= 2048:
+            return 64, 64, sk, 0
+        if M < 16384 or N < 128:
+            return 128, 64, sk, 13
+        return 5256, (160 if N % 160 == 0 else 128), sk, (1 if N % 160 == 0 else 0)
+    # 3x3 (stride 2, odd geometry, shortcut-folded, 8x8 level) and long-K Dense
+    if M <= 256:
+        return 64, 64, sk, 14
+    if M <= 1024:
+        return (4064, 128, sk, 23) if N % 128 == 0 else (128, 64, sk, 0)
+    if M <= 4096 or N < 128:
+        return (128, 128, sk, 4) if wide == 128 else (128, 64, sk, 0)
+    if M < 8192:
+        return 256, 128, sk, 0
+    return 5256, (160 if N % 160 == 0 else 128), sk, (1 if N % 160 == 0 else 0)
 
 
 def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split, cx=0) -> Tuple[int, int, int, int]:
@@ -166,7 +265,7 @@ def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_spli
         if not allow_split:
             sk = 1
         return bm, bn, sk, stages
-    return heuristic(M // max(1, batch), N, nk, allow_split)
+    return shape_config(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split, cx)
 
 
 def numerics_class(ksize: int, tile_m: int, tile_n: int, splitk: int, ln_producer: bool = True, stages: int = 0) -> Tuple[bool, int, int]:

@@ -130,6 +130,68 @@ def test_unmeasured_batch_at_512(gpu, unet512, B):
         np.testing.assert_array_equal(both[i:i + 1], one)
 
 
+@pytest.fixture(scope="module")
+def oracle_unet_weights():
+    """The synthetic SD1.5 UNet checkpoint as the oracle's named fp32 tensors (the same seed unet512 packs)."""
+    from minsdtf_amd import weights as Wt
+    from oracle import sd_oracle as O
+
+    return O.named_weights(Wt.table("civitai_model"), Wt.synth_keras_weights("civitai_model", seed=0))
+
+
+@pytest.mark.parametrize("height,width", [(640, 640), (512, 768)])
+def test_untuned_sizes(gpu, unet512, oracle_unet_weights, height, width):
+    """Image sizes the tuning table holds NO row of (legal for the reference: H, W multiples of 64, stable_diffusion.py:588-593):
+    every conv / dense launch takes tuning.shape_config() - the halo / staged-halo / wreg / row-panel / big forms chosen from
+    the shape class, not the plain-tile fallback of rounds 1-5.  Parity against the oracle RUN HERE (2 steps, CFG + rescale;
+    the latent after the chain), a sample's bits independent of its batch (fused batches 2 and 6), and no table row used."""
+    from minsdtf_amd import tuning
+    from minsdtf_amd.models import DiffusionModel
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+    from oracle import sd_oracle as O
+
+    h, w = height // 8, width // 8
+    assert not any(k.split("x")[1:3] == [str(h), str(w)] for k in tuning._load()), "this size has table rows: pick another"
+    unet = DiffusionModel(height, width, device=gpu)
+    unet.share_weights(unet512)
+    sd = StableDiffusion(height, width, jit_compile=True, device=gpu)
+    sd._diffusion_model = unet
+    rng = np.random.default_rng(640 + width)
+    B = 3
+    ctx = rng.standard_normal((B, 77, 768)).astype(np.float32)
+    unc = rng.standard_normal((B, 77, 768)).astype(np.float32)
+    noise = rng.standard_normal((B, h, w, 4)).astype(np.float32)
+    kw = dict(num_steps=2, unconditional_guidance_scale=7.5, guidance_rescale=0.7, return_latent=True)
+    one = sd.generate_image(ctx[0], negative_prompt=unc[0], batch_size=1, diffusion_noise=noise[0], **kw)
+    assert one.shape == (1, h, w, 4) and np.isfinite(one).all()
+    W = oracle_unet_weights
+    ref = O.denoise_loop(lambda l, t, c, ctl: O.unet_forward(W, l, t, c), ctx[:1], unc[:1], noise[:1], num_steps=2, guidance=7.5,
+                         guidance_rescale=0.7)
+    p = O.psnr(one, ref)
+    print(f"untuned {height}x{width}, 2 steps: final-latent PSNR {p:.1f} dB vs the oracle")
+    assert p >= PSNR_MIN
+    three = sd.generate_image(ctx, negative_prompt=unc, batch_size=B, diffusion_noise=noise, **kw)
+    np.testing.assert_array_equal(three[:1], one)
+    last = sd.generate_image(ctx[2], negative_prompt=unc[2], batch_size=1, diffusion_noise=noise[2], **kw)
+    np.testing.assert_array_equal(three[2:], last)
+
+
+def test_untuned_size_vae_decode(gpu, decoder):
+    """The VAE decoder at an untuned size (latent 80 x 80 -> 640 x 640): the staged-halo forms from the shape class, against the
+    oracle's decode run here on a quarter-resolution check grid of the output."""
+    from minsdtf_amd import weights as Wt
+    from oracle import sd_oracle as O
+
+    Wv = O.named_weights(Wt.table("decoder"), Wt.synth_keras_weights("decoder", seed=0))
+    lat = (np.random.default_rng(80).standard_normal((1, 80, 80, 4)) * 0.18215 * 4.0).astype(np.float32)
+    got = decoder.predict_on_batch(lat)
+    ref = np.asarray(O.decoder_forward(Wv, lat), dtype=np.float32)
+    assert got.shape == ref.shape == (1, 640, 640, 3) and np.isfinite(got).all()
+    p = O.psnr(got, ref)
+    print(f"untuned VAE decode 640x640: PSNR {p:.1f} dB vs the oracle")
+    assert p >= PSNR_MIN
+
+
 def test_pipeline_bits_are_reproducible_run_to_run(gpu, unet512):
     """The same job twice is the same bits - at the REAL layer shapes, with the weights streaming from HBM, 150 times.  Round 5
     found a run-to-run difference in about 1 of 50 two-step jobs (one bf16 tile of a GEGLU projection changed, ~1e-4 on the

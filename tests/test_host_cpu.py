@@ -380,7 +380,7 @@ def test_tuning_table_pins_one_numerics_class_per_layer():
     assert tuning.numerics_class(3, a[0], a[1], a[2]) == tuning.numerics_class(3, b[0], b[1], b[2])
     h1 = tuning.lookup(1, 40, 40, 704, 704, 3, 1, False, 1600, 99, True)
     h5 = tuning.lookup(5, 40, 40, 704, 704, 3, 1, False, 8000, 99, True)
-    assert h1[1:3] == h5[1:3]
+    assert tuning.numerics_class(3, h1[0], h1[1], h1[2], stages=h1[3]) == tuning.numerics_class(3, h5[0], h5[1], h5[2], stages=h5[3])
 
 
 def test_engine_contexts_accept_mixed_host_and_device_inputs():
@@ -550,3 +550,120 @@ def test_release_library_refuses_experiment_modes():
     for mode in (1, 2, 8, 15):
         assert lib.msd_set_option(b"xattn160_mode", mode) == -1
         assert b"instrumented build" in lib.msd_last_error()
+
+
+def _walk_shapes(nb, h, w, what="unet"):
+    """Every msd_conv_gemm shape of a network at a latent size, through the emitters (tensor-less weights): the tuner's walk."""
+    from minsdtf_amd import engine, tuning
+
+    rec = []
+    orig = tuning.lookup
+
+    def hook(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split, cx=0):
+        rec.append((batch, h_in, w_in, cin, N, ksize, stride, bool(upsample), M, nk, bool(allow_split), cx))
+        return tuning.heuristic(M, N, nk, allow_split)
+
+    class AnyW(dict):
+        def __contains__(self, k):
+            return True
+
+        def __missing__(self, k):
+            return None
+
+    class T:
+        ptr = 0
+
+        def at(self, off):
+            return self
+
+    tuning.lookup = hook
+    try:
+        p = engine.Plan("cpu")
+        e = engine.Emitter(p, AnyW())
+        if what == "unet":
+            ctx = engine.Act(p.alloc(nb * 77 * 768 * 2), nb, 77, 1, 768)
+            kv = engine.emit_context_kv(e, ctx, engine.UNET_ATTN_LAYERS, p)
+            engine.emit_unet(e, T(), nb, nb, h, w, (T(), 0, 0, engine.temb_columns(False)), kv, 77, T(), None)
+        else:
+            engine.emit_decoder(e, T(), nb, h, w, T(), 0)
+    finally:
+        tuning.lookup = orig
+    return rec
+
+
+def _config_is_built(cfg, shape):
+    """The (tile_m, tile_n, stages) of a launch configuration names a kernel the library builds AND that takes this shape (the
+    tuner's candidate filters, tools/tune_conv.py): the wreg / big / staged-halo forms fail the launch otherwise."""
+    from minsdtf_amd import tuning as t
+
+    bm, bn, sk, stg = cfg
+    batch, h_in, w_in, cin, N, ks, stride, ups, M, nk, allow_split, cx = shape
+    hl, wl = (2 * h_in, 2 * w_in) if ups else (h_in, w_in)
+    key = (bm, bn, stg)
+    if t.is_halo(bm):
+        return key in t.HALO_TILES and ks == 3 and stride == 1 and not ups and not cx and w_in % 16 == 0 and h_in % ((bm % 1000) // 16) == 0
+    if t.is_rowpanel(bm):
+        return ks == 1 and stride == 1 and not ups and not cx and cin in t.ROWPANEL_ROWS and bm in t.ROWPANEL_ROWS[cin] and bn in t.ROWPANEL_COLS and N % bn == 0 and N % 32 == 0
+    if t.is_wreg(bm):
+        waves_n = 4 if (stg % 20 < 10 or bm == 4256) else 8
+        return key in t.WREG_TILES and N % 16 == 0 and not (bn > 64 and N <= 64) and (allow_split or (bn // 16 // waves_n) % 2 == 0)
+    if t.is_big(bm):
+        ok = not (bn == 160 and (N % 160 or not allow_split)) and not (bn > 128 and N <= 128) and not (ks == 1 and allow_split and cin == N and not cx)
+        if stg >= 20:
+            return ok and key in t.BIG_TILES_HALO_IMAGE and ks == 3 and stride == 1 and not (cx and ups) and hl % 16 == 0 and wl % 16 == 0 and M >= t.HALO_IMAGE_MIN_ROWS
+        if stg >= 10:
+            return ok and key in t.BIG_TILES_CHUNK_MAJOR and ks == 3 and stride == 1 and not cx
+        return ok and key in t.BIG_TILES
+    if key not in t.TILES:
+        return False
+    return not (bm == 256 and M < 1024) and not (bn == 128 and N <= 64) and not (bn == 80 and (N % 80 or not allow_split)) and not (bn == 160 and (N % 160 or N < 1280))
+
+
+def test_shape_config_reaches_the_fast_forms_at_untuned_sizes():
+    """speed is a property of the shape class, not of a table row.  For image sizes the table has no entry of
+    (640x640, 512x768, 1024x1024, 704x576) every conv / dense launch of the UNet and the VAE decoder gets (a) a configuration
+    the library builds and that takes the shape, (b) ONE numerics class per layer whatever the batch, (c) the halo / staged-halo
+    forms on the 3x3 convs whose geometry allows them (what a table row would have chosen) - never just the plain tile."""
+    from minsdtf_amd import tuning
+
+    table = tuning._load()
+    for (lh, lw) in ((80, 80), (64, 96), (128, 128), (88, 72)):
+        classes, forms = {}, {}
+        for net in ("unet", "vae"):
+            for nb in ((1, 2, 4, 8) if net == "unet" else (1, 4)):
+                for sh in _walk_shapes(nb, lh, lw, net):
+                    batch, h_in, w_in, cin, N, ks, stride, ups, M, nk, allow_split, cx = sh
+                    key = tuning.shape_key(batch, h_in, w_in, cin, N, ks, stride, ups, allow_split, cx)
+                    cfg = tuning.lookup(*sh)
+                    layer = key.split("x", 1)[1]
+                    if key not in table and layer not in tuning._families:   # (a table row was measured on the GPU: it launched)
+                        assert _config_is_built(cfg, sh), (key, cfg)
+                    cls = tuning.numerics_class(ks, cfg[0], cfg[1], cfg[2], tuning.key_is_ln_producer(key), cfg[3])
+                    classes.setdefault(layer, set()).add(cls)
+                    if key not in table and layer not in tuning._families:
+                        forms.setdefault((ks, stride, ups, bool(cx)), set()).add((cfg[0], h_in, w_in))
+        bad = {k: v for k, v in classes.items() if len(v) != 1}
+        assert not bad, (lh, lw, bad)
+        plain3 = {(bm, h, w) for (bm, h, w) in forms.get((3, 1, False, False), ()) if bm < 1000 and w % 16 == 0 and h % 8 == 0 and h * w >= 256}
+        assert not plain3, f"{lh}x{lw}: 3x3 convs on the plain tile although the halo forms take them: {sorted(plain3)}"
+        ups3 = {(bm, h, w) for (bm, h, w) in forms.get((3, 1, True, False), ()) if not tuning.is_big(bm) and (2 * h) % 16 == 0 and (2 * w) % 16 == 0 and h * w >= 256}
+        assert not ups3, f"{lh}x{lw}: upsampling convs off the staged halo: {sorted(ups3)}"
+
+
+def test_shape_class_reads_the_sample_only():
+    """shape_class() has no batch argument; shape_config() may move the FORM with the batch but never the class."""
+    from minsdtf_amd import tuning
+
+    for (h, w, cin, N, ks, st, up, split, cx) in ((80, 80, 320, 320, 3, 1, False, True, 0), (40, 40, 640, 640, 3, 1, False, True, 1280),
+                                                  (10, 10, 2560, 1280, 3, 1, False, True, 0), (80, 80, 320, 2560, 1, 1, False, False, 0),
+                                                  (20, 20, 6400, 1280, 1, 1, False, True, 0), (40, 40, 1280, 1280, 3, 1, True, True, 0),
+                                                  (80, 80, 320, 320, 3, 2, False, True, 0), (160, 160, 512, 512, 3, 1, False, True, 0)):
+        pad = 1 if ks == 3 else 0
+        hl, wl = (2 * h, 2 * w) if up else (h, w)
+        ho, wo = (hl + 2 * pad - ks) // st + 1, (wl + 2 * pad - ks) // st + 1
+        nk = ks * ks * (cin // 64) + cx // 64
+        seen = set()
+        for b in (1, 2, 3, 4, 8, 16, 32):
+            cfg = tuning.shape_config(b, h, w, cin, N, ks, st, up, b * ho * wo, nk, split, cx)
+            seen.add(tuning.numerics_class(ks, cfg[0], cfg[1], cfg[2], ks == 1 and split and cin == N and not cx, cfg[3]))
+        assert len(seen) == 1, ((h, w, cin, N, ks, st, up, split, cx), seen)
