@@ -177,7 +177,7 @@ def shape_class(h_in, w_in, cin, N, ksize, stride, upsample, allow_split, cx=0) 
                 sk = max(1, min(_ceil_div(96, max(1, int(hw_out ** 0.5))), nk // 8, 16))
             elif ksize == 1 and hw_out < 1024:
                 sk = max(1, min(_ceil_div(48, max(1, int(hw_out ** 0.5))), nk // 8, 16))
-        elif nk >= 16:                                            # short-K Dense at the lowest levels
+        elif nk >= 16 and N <= 2048:                              # short-K Dense at the lowest levels (few column tiles)
             sk = 4 if hw_out <= 64 else 2 if hw_out <= 144 else 1
     ln_tile = 64 if (ksize == 1 and allow_split and cx == 0 and cin == N) else 0   # (the layers that may produce LayerNorm-fold partials)
     return walk, sk, ln_tile
@@ -221,6 +221,8 @@ def shape_config(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allo
             return 128, wide, 1, 0
         return 256, 128, 1, 0
     if ksize == 1 and nk < 32:             # short-K 1x1 with cin != N (conv_shortcut, zero convs, time-embedding projections)
+        if N > 4096:                       # (the concatenated time-embedding projections, N = 20,160: at most 255 column tiles per launch)
+            return (64, 128, sk, 0) if M <= 2048 else (128, 128, sk, 0)
         if M <= 2048:
             return 64, 64, sk, 0
         if M < 16384 or N < 128:
@@ -265,6 +267,8 @@ def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_spli
         if not allow_split:
             sk = 1
         return bm, bn, sk, stages
+    if os.environ.get("MSD_SHAPE_CONFIG", "1") == "0":   # (A/B runs: the plain-tile fallback of rounds 1-5)
+        return heuristic(M // max(1, batch), N, nk, allow_split)
     return shape_config(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_split, cx)
 
 

@@ -616,6 +616,8 @@ def _config_is_built(cfg, shape):
         return ok and key in t.BIG_TILES
     if key not in t.TILES:
         return False
+    if -(-N // bn) >= 256:   # column tiles travel in 8 bits of a packed launch argument (cg_hot_ok)
+        return False
     return not (bm == 256 and M < 1024) and not (bn == 128 and N <= 64) and not (bn == 80 and (N % 80 or not allow_split)) and not (bn == 160 and (N % 160 or N < 1280))
 
 
@@ -657,7 +659,8 @@ def test_shape_class_reads_the_sample_only():
     for (h, w, cin, N, ks, st, up, split, cx) in ((80, 80, 320, 320, 3, 1, False, True, 0), (40, 40, 640, 640, 3, 1, False, True, 1280),
                                                   (10, 10, 2560, 1280, 3, 1, False, True, 0), (80, 80, 320, 2560, 1, 1, False, False, 0),
                                                   (20, 20, 6400, 1280, 1, 1, False, True, 0), (40, 40, 1280, 1280, 3, 1, True, True, 0),
-                                                  (80, 80, 320, 320, 3, 2, False, True, 0), (160, 160, 512, 512, 3, 1, False, True, 0)):
+                                                  (80, 80, 320, 320, 3, 2, False, True, 0), (160, 160, 512, 512, 3, 1, False, True, 0),
+                                                  (25, 1, 1280, 20160, 1, 1, False, True, 0)):
         pad = 1 if ks == 3 else 0
         hl, wl = (2 * h, 2 * w) if up else (h, w)
         ho, wo = (hl + 2 * pad - ks) // st + 1, (wl + 2 * pad - ks) // st + 1
