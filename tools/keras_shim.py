@@ -1,0 +1,397 @@
+"""An EAGER torch stand-in for the part of the Keras-3 API the reference's model files use, so that the reference's own
+GRAPH CODE (stable_diffusion/diffusion_model.py, layers.py, image_decoder.py, image_encoder.py, control_net.py,
+text_encoder.py - read from /root/reference, never copied) can be EXECUTED in the build container, where `keras` itself is not
+installed and not installable.  Test infrastructure only (tools/make_ref_graph_goldens.py,
+tests/test_ref_graph_cpu.py's live comparison); nothing under minsdtf_amd/ imports it.
+
+What this pins and what it does not.  The reference builds its networks inside `__init__` on symbolic `layers.Input`s; here
+`layers.Input` hands out the REAL input tensor, so the constructor body - the reference's own wiring: which tensor feeds
+which layer, the skip stack and its pop order, where swish / softmax / the attention scale sit, the GEGLU split, the head
+reshapes, the ControlNet adds, the VAE's resnet / attention order - runs eagerly, and `Model.__init__(inputs, outputs)`
+receives the finished output.  The weights arrive through the reference's own loader (ckpt_loader.load_weights_from_file
+-> `model.set_weights(list)`, its key tables and transposes) from a synthetic checkpoint file.  That pins the ORACLE'S
+TOPOLOGY AND WEIGHT PLACEMENT against the reference's code.  What stays restated from the Keras documentation (and is written
+here independently of oracle/sd_oracle.py: no shared helper, different formulations) is the arithmetic INSIDE each Keras
+primitive: Conv2D 'valid' on channels_last with an HWIO kernel, ZeroPadding2D, Dense, GroupNormalization(groups=32, biased
+variance over (H, W, C/G)), LayerNormalization (biased variance, last axis), UpSampling2D nearest, softmax over the last
+axis, swish = x * sigmoid(x), Embedding lookup.
+
+Weight placement.  Keras assigns `set_weights(list)` by position in `model.weights`; that order is the library's (for a
+functional model: its own layer sort - e.g. time_embedding.linear_1, conv_in, time_embedding.linear_2) and cannot be derived
+without Keras.  The list is in the reference table's order, which differs from the order in which the layers execute only
+where shapes differ, so the shim places every incoming array on the FIRST not yet assigned variable (in build order) of the
+same shape, and fails if one finds no place.
+
+Two passes per model (the constructor runs the graph before it loads the weights): pass 1 ("trace") builds every variable as
+zeros and lets the reference's loader fill them; pass 2 ("run") serves each variable, in the same build order, the value it
+received in pass 1.
+"""
+from __future__ import annotations
+
+import sys
+import types
+
+import numpy as np
+import torch
+
+F32 = torch.float32
+
+
+class _State:
+    def __init__(self):
+        self.inputs = []        # queue of real input tensors handed out by layers.Input
+        self.variables = []     # every variable of the model under construction, in build order
+        self.served = None      # pass 2: values per variable ordinal (from pass 1)
+        self.set_weights_calls = 0
+
+
+STATE = _State()
+
+
+def begin(inputs, served=None):
+    STATE.inputs = [torch.as_tensor(np.asarray(a)) for a in inputs]
+    STATE.variables = []
+    STATE.served = served
+    STATE.set_weights_calls = 0
+
+
+class Variable:
+    def __init__(self, shape, name, init="zeros"):
+        k = len(STATE.variables)
+        self.shape = tuple(int(s) for s in shape)
+        self.name = name
+        if STATE.served is not None:
+            v = STATE.served[k]
+            assert tuple(v.shape) == self.shape, (name, tuple(v.shape), self.shape)
+            self.value = v.detach().clone().requires_grad_(True)
+            self.assigned = True
+        else:
+            self.value = (torch.ones(self.shape, dtype=F32) if init == "ones" else torch.zeros(self.shape, dtype=F32)).requires_grad_(True)
+            self.assigned = False
+        self.in_graph = True    # set by Model.__init__: whether the model's outputs depend on this variable
+        STATE.variables.append(self)
+
+
+def _place(arrays):
+    """model.set_weights(list): first free variable of the same shape, in build order (see the module docstring)."""
+    free = [v for v in STATE.variables if v.in_graph]
+    for i, a in enumerate(arrays):
+        a = np.asarray(a)
+        for j, v in enumerate(free):
+            if v.shape == tuple(a.shape):
+                v.value = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).requires_grad_(True)
+                v.assigned = True
+                del free[j]
+                break
+        else:
+            raise ValueError(f"set_weights: array {i} of shape {a.shape} fits no free variable")
+    STATE.set_weights_calls += 1
+
+
+# ----------------------------------------------------------------------------- layers
+class _Shape(tuple):
+    def as_list(self):
+        return list(self)
+
+
+def _shape_of(x):
+    if isinstance(x, (list, tuple)):
+        return [_shape_of(t) for t in x]
+    return _Shape(int(s) for s in x.shape)
+
+
+torch.Tensor.get_shape = lambda self: _Shape(int(s) for s in self.shape)   # (the reference calls the TensorFlow tensor method)
+
+
+class Layer:
+    compute_dtype = "float32"
+
+    def __init__(self, name=None, **kwargs):
+        self.name = name if name is not None else type(self).__name__.lower()
+        self.built = False
+
+    def build(self, input_shape):
+        pass
+
+    def __call__(self, inputs, *args, **kwargs):
+        if not self.built:
+            self.build(_shape_of(inputs))
+            self.built = True
+        return self.call(inputs, *args, **kwargs)
+
+    def call(self, inputs):   # pragma: no cover
+        raise NotImplementedError
+
+
+def Input(shape=None, dtype=None, name=None, **kw):
+    t = STATE.inputs.pop(0)
+    want = tuple(shape)
+    got = tuple(t.shape[1:])
+    assert len(want) == len(got) and all(w is None or int(w) == int(g) for w, g in zip(want, got)), (name, want, got)
+    if dtype is not None and "int" in str(dtype):
+        return t.to(torch.int64)
+    return t.to(F32)
+
+
+class Dense(Layer):
+    def __init__(self, units, use_bias=True, activation=None, **kw):
+        super().__init__(**kw)
+        self.units, self.use_bias, self.activation = int(units), use_bias, activation
+
+    def build(self, input_shape):
+        self.kernel = Variable((input_shape[-1], self.units), self.name + "/kernel")
+        self.bias = Variable((self.units,), self.name + "/bias") if self.use_bias else None
+
+    def call(self, x):
+        y = torch.tensordot(x, self.kernel.value, dims=([x.dim() - 1], [0]))
+        if self.bias is not None:
+            y = y + self.bias.value
+        return self.activation(y) if self.activation is not None else y
+
+
+class Conv2D(Layer):
+    """channels_last, padding 'valid', kernel (kh, kw, cin, cout), bias."""
+
+    def __init__(self, filters, kernel_size, strides=1, **kw):
+        super().__init__(**kw)
+        self.filters, self.k, self.s = int(filters), int(kernel_size), int(strides)
+
+    def build(self, input_shape):
+        self.kernel = Variable((self.k, self.k, input_shape[-1], self.filters), self.name + "/kernel")
+        self.bias = Variable((self.filters,), self.name + "/bias")
+
+    def call(self, x):
+        # out[b, i, j, o] = sum_{u, v, c} x[b, s i + u, s j + v, c] kernel[u, v, c, o]: windows by unfold, then one einsum
+        win = x.unfold(1, self.k, self.s).unfold(2, self.k, self.s)          # (B, Ho, Wo, C, kh, kw)
+        return torch.einsum("bijcuv,uvco->bijo", win, self.kernel.value) + self.bias.value
+
+
+class ZeroPadding2D(Layer):
+    def __init__(self, padding=0, **kw):
+        super().__init__(**kw)
+        if isinstance(padding, int):
+            padding = ((padding, padding), (padding, padding))
+        self.p = tuple(tuple(int(v) for v in pr) for pr in padding)
+
+    def call(self, x):
+        (t, b), (l, r) = self.p
+        if not (t or b or l or r):
+            return x
+        out = torch.zeros(x.shape[0], x.shape[1] + t + b, x.shape[2] + l + r, x.shape[3], dtype=x.dtype)
+        out[:, t:t + x.shape[1], l:l + x.shape[2], :] = x
+        return out
+
+
+class GroupNormalization(Layer):
+    def __init__(self, groups=32, axis=-1, epsilon=1e-3, **kw):
+        super().__init__(**kw)
+        assert axis == -1
+        self.groups, self.eps = int(groups), float(epsilon)
+
+    def build(self, input_shape):
+        self.gamma = Variable((input_shape[-1],), self.name + "/gamma", "ones")
+        self.beta = Variable((input_shape[-1],), self.name + "/beta")
+
+    def call(self, x):
+        B, C = x.shape[0], x.shape[-1]
+        g = x.reshape(B, -1, self.groups, C // self.groups).to(torch.float64)
+        mean = g.mean(dim=(1, 3), keepdim=True)
+        var = ((g - mean) ** 2).mean(dim=(1, 3), keepdim=True)
+        y = ((g - mean) / torch.sqrt(var + self.eps)).to(F32).reshape(x.shape)
+        return y * self.gamma.value + self.beta.value
+
+
+class LayerNormalization(Layer):
+    def __init__(self, epsilon=1e-3, axis=-1, **kw):
+        super().__init__(**kw)
+        assert axis == -1
+        self.eps = float(epsilon)
+
+    def build(self, input_shape):
+        self.gamma = Variable((input_shape[-1],), self.name + "/gamma", "ones")
+        self.beta = Variable((input_shape[-1],), self.name + "/beta")
+
+    def call(self, x):
+        d = x.to(torch.float64)
+        mean = d.mean(dim=-1, keepdim=True)
+        var = ((d - mean) ** 2).mean(dim=-1, keepdim=True)
+        return ((d - mean) / torch.sqrt(var + self.eps)).to(F32) * self.gamma.value + self.beta.value
+
+
+class Embedding(Layer):
+    def __init__(self, input_dim, output_dim, **kw):
+        super().__init__(**kw)
+        self.n, self.d = int(input_dim), int(output_dim)
+
+    def build(self, input_shape):
+        self.table = Variable((self.n, self.d), self.name + "/embeddings")
+
+    def call(self, idx):
+        return self.table.value[idx.to(torch.int64)]
+
+
+class UpSampling2D(Layer):
+    def __init__(self, size=2, **kw):
+        super().__init__(**kw)
+        self.size = int(size)
+
+    def call(self, x):   # nearest: every pixel becomes a size x size block
+        B, H, W, C = x.shape
+        s = self.size
+        return x[:, :, None, :, None, :].expand(B, H, s, W, s, C).reshape(B, H * s, W * s, C)
+
+
+class Activation(Layer):
+    def __init__(self, fn, **kw):
+        super().__init__(**kw)
+        self.fn = {"swish": _swish, "silu": _swish}[fn] if isinstance(fn, str) else fn
+
+    def call(self, x):
+        return self.fn(x)
+
+
+class Rescaling(Layer):
+    def __init__(self, scale, offset=0.0, **kw):
+        super().__init__(**kw)
+        self.scale, self.offset = float(scale), float(offset)
+
+    def call(self, x):
+        return x * self.scale + self.offset
+
+
+class Lambda(Layer):
+    def __init__(self, fn, **kw):
+        super().__init__(**kw)
+        self.fn = fn
+
+    def call(self, x):
+        return self.fn(x)
+
+
+class Concatenate(Layer):
+    def __init__(self, axis=-1, **kw):
+        super().__init__(**kw)
+        self.axis = axis
+
+    def call(self, xs):
+        return torch.cat(list(xs), dim=self.axis)
+
+
+class Dot(Layer):   # (only named by the reference's unused td_dot helper)
+    def __init__(self, axes=None, **kw):
+        super().__init__(**kw)
+
+
+def _swish(x):
+    return x * (1.0 / (1.0 + torch.exp(-x)))
+
+
+def _softmax(x, axis=-1):
+    m = x.max(dim=axis, keepdim=True).values
+    e = torch.exp(x - m)
+    return e / e.sum(dim=axis, keepdim=True)
+
+
+# ----------------------------------------------------------------------------- models
+class Model:
+    """A functional Keras model owns the layers on a path from its inputs to its outputs and no others (TextEncoder with
+    clip_skip = -2 builds 12 encoder layers and outputs final_layer_norm(out[-2]): the last layer's variables are not in
+    `model.weights`).  The shim finds that set with autograd: every variable is a leaf that requires grad, and the variables the
+    outputs do not depend on get no gradient."""
+
+    def __init__(self, inputs=None, outputs=None, name=None, **kw):
+        self.name = name or type(self).__name__.lower()
+        outs = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
+        total = sum(o.sum() for o in outs)
+        grads = torch.autograd.grad(total, [v.value for v in STATE.variables], allow_unused=True)
+        for v, g in zip(STATE.variables, grads):
+            v.in_graph = g is not None
+        det = [o.detach() for o in outs]
+        self.outputs = det if isinstance(outputs, (list, tuple)) else det[0]
+
+    @property
+    def weights(self):
+        return [v for v in STATE.variables if v.in_graph]
+
+    def set_weights(self, arrays):
+        _place(arrays)
+
+
+class Sequential(Model):
+    def __init__(self, layers_=None, name=None, **kw):
+        x = layers_[0]                      # the layers.Input of the list: already the real tensor
+        assert isinstance(x, torch.Tensor), "Sequential: the first list element must be layers.Input(...)"
+        for layer in layers_[1:]:
+            x = layer(x)
+        super().__init__(None, x, name=name)
+
+
+# ----------------------------------------------------------------------------- ops
+def _t(x):
+    return x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+
+
+class _NN(types.SimpleNamespace):
+    pass
+
+
+def install():
+    """Put the shim in sys.modules as `keras` (+ submodules).  Import torch first; call before importing the reference."""
+    mods = {n: types.ModuleType(n) for n in ("keras", "keras.layers", "keras.ops", "keras.activations", "keras.utils", "keras.random")}
+    for m in mods.values():
+        m.__file__ = "<tools/keras_shim.py>"
+        m.__path__ = []
+    L, O, A, U, R = (mods["keras." + s] for s in ("layers", "ops", "activations", "utils", "random"))
+    for cls in (Layer, Dense, Conv2D, ZeroPadding2D, GroupNormalization, LayerNormalization, Embedding, UpSampling2D, Activation, Rescaling,
+                Lambda, Concatenate, Dot):
+        setattr(L, cls.__name__, cls)
+    L.Input = Input
+    O.shape = lambda x: tuple(int(s) for s in x.shape)
+    O.reshape = lambda x, shape: _t(x).reshape(tuple(int(s) for s in shape))
+    O.transpose = lambda x, axes=None: _t(x).permute(*axes) if axes is not None else _t(x).t()
+    O.einsum = lambda eq, *xs: torch.einsum(eq, *[_t(x) for x in xs])
+    O.sqrt = lambda x: torch.sqrt(_t(x).to(F32))
+    O.cast = lambda x, dtype=None: _t(x).to(F32 if "float" in str(dtype) else torch.int64)
+    O.sigmoid = lambda x: 1.0 / (1.0 + torch.exp(-x))
+    O.split = lambda x, n, axis=-1: list(torch.chunk(x, int(n), dim=axis))
+    O.nn = _NN(softmax=_softmax)
+    A.softmax = _softmax
+    A.tanh = torch.tanh
+    A.silu = _swish
+    A.swish = _swish
+    U.get_file = lambda *a, **k: "/nonexistent/keras_shim_has_no_downloads"
+
+    class Progbar:
+        def __init__(self, *a, **k):
+            pass
+
+        def update(self, *a, **k):
+            pass
+
+    U.Progbar = Progbar
+
+    def _no_rng(*a, **k):
+        raise RuntimeError("keras.random is backend specific: inject diffusion_noise")
+
+    R.normal = _no_rng
+    k = mods["keras"]
+    k.layers, k.ops, k.activations, k.utils, k.random = L, O, A, U, R
+    k.Model, k.Sequential = Model, Sequential
+    sys.modules.update(mods)
+    return k
+
+
+def run_model(build, inputs):
+    """build() -> the reference model object (constructor given ckpt_path=...).  Returns (outputs, info)."""
+    begin(inputs)
+    build()
+    n_loader = STATE.set_weights_calls
+    assert n_loader == 1, f"the reference's loader called set_weights {n_loader} times (checkpoint not found?)"
+    unassigned = [v.name for v in STATE.variables if v.in_graph and not v.assigned]
+    outside = sum(1 for v in STATE.variables if not v.in_graph)
+    served = [v.value.detach() for v in STATE.variables]
+    begin(inputs, served=served)
+    model = build()
+    out = model.outputs
+    info = {"variables": len(served), "outside_the_functional_graph": outside, "left_at_init": unassigned}
+    return out, info
