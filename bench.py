@@ -541,8 +541,8 @@ def main(argv=None):
                    # what a job does NOT redo: uploaded / computed when the schedule changes (DenoiseEngine.prepare), i.e. once for the run;
                    # everything else of the hot path (context K/V, the loop, decode, D2H) runs inside every timed job
                    "cached_across_jobs": ["sampler coefficient table", "time-embedding table (25 x timestep MLP + the 22 ResBlock projections)"],
-                   # process-wide arithmetic choices read from the environment (minsdtf_amd/tuning.py, _lib.py): "latency" = the default
-                   "profile": os.environ.get("MSD_PROFILE", "latency") or "latency", "gn_rows": os.environ.get("MSD_GN_ROWS")},
+                   # the one process-wide arithmetic choice read from the environment (minsdtf_amd/_lib.py); None = the default (9216)
+                   "gn_rows": os.environ.get("MSD_GN_ROWS")},
         "n_ranks_seen": n_ranks_seen, "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
         "launcher": os.environ.get("MSD_BENCH_LAUNCHER", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "external" if world > 1 else "none"),
         "rank_devices": rank_devices(dev, world),

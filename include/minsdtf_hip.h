@@ -150,7 +150,9 @@ typedef struct MsdConvGemm {
                             20 + code with tile_m 5256 = that chunk-major walk over a STAGED 18 x 18-pixel halo per 64-channel chunk
                             (3x3 / stride 1 / pad 1, with or without `upsample`, h_out and w_out multiples of 16; otherwise
                             MSD_E_UNSUPPORTED): 5256x160:20 5256x128:20/21 (weight ring of 3 / 4).  With a shortcut operand (a2) a
-                            slice's shortcut chunks follow its main chunks: an order of sums no other form has */
+                            slice's shortcut chunks follow its main chunks; since round 6 the halo tiles (tile_m 1128 / 2128 / 1256, any
+                            of their `stages`) walk a shortcut operand in exactly that order: one numerics class, the halo tiles for
+                            small launches, this form from about 128 workgroups on */
     const float* ln_in;      /* float2 [M][ln_in_slots] row-moment partials of the input rows, or NULL */
     const float* ln_colsum;  /* [N]: sum_k W[n][k] of the gamma-folded bf16 weights (with ln_in) */
     float* ln_out;           /* float2 [M][ln_out_slots] row-moment partials of the stored output, or NULL */
@@ -160,7 +162,9 @@ typedef struct MsdConvGemm {
     /* Shortcut operand (ResBlock, diffusion_model.py:36-38,50: conv2(h) + conv_shortcut(x) as ONE contraction): after the
      * ksize*ksize*(c0+c1) taps of a0|a1, K continues with the channels of a2|a3 read at the OUTPUT pixel (a 1x1 tap);
      * W rows are [taps of a0|a1 ... | channels of a2|a3], K = ksize*ksize*(c0+c1) + c2 + c3.  Needs stride 1, same-size
-     * output, c2 % 64 == 0, c3 % 64 == 0; runs on the general tile kernel (no halo tiles). */
+     * output, c2 % 64 == 0, c3 % 64 == 0.  On the tile / wreg / big forms the shortcut chunks are K tiles behind the last tap
+     * (tap-major class); on the halo tiles and the staged-halo big form they follow each split-K slice's main chunks, dealt
+     * over the slices in order (chunk-major class; round 6). */
     const void* a2;          /* bf16 [batch][h_out][w_out][c2] or NULL */
     const void* a3;          /* bf16 [batch][h_out][w_out][c3] or NULL (channel concat a2|a3) */
     int32_t c2, c3;

@@ -151,17 +151,15 @@ def shutdown() -> None:
 
 
 def _apply_env_options(lib) -> None:
-    """Process-wide arithmetic choices made through the environment, validated before the library handle is cached.
-    MSD_GN_ROWS=<pixels>: the row-major cluster GroupNorm from that sample size on - 4096 pays from two images
-    per GPU and costs at one; MSD_PROFILE=throughput (parsed in ONE place, tuning.profile()) implies 4096 unless given.  Under
-    either setting a sample's bits do not depend on its batch."""
-    from . import tuning
-
-    try:
-        prof = tuning.profile()
-    except ValueError as e:
-        raise HipExtensionError(str(e)) from e
-    gn_rows = os.environ.get("MSD_GN_ROWS") or ("4096" if prof == "throughput" else "")
+    """The one process-wide arithmetic choice made through the environment, validated before the library handle is cached:
+    MSD_GN_ROWS=<pixels> - the row-major cluster GroupNorm from that sample size on (default 9216; 4096 pays from
+    two images per GPU and costs at one).  Under either setting a sample's bits do not depend on its batch.  MSD_PROFILE (round
+    5's second tuning table) no longer exists: the layers it moved are in ONE numerics class at every batch since round 6, and
+    a process that still sets it is told so instead of silently running something else."""
+    if os.environ.get("MSD_PROFILE") not in (None, "", "latency"):
+        raise HipExtensionError(f"MSD_PROFILE={os.environ['MSD_PROFILE']!r}: the throughput profile was removed in round 6 (its launch "
+                                "configurations are in the one tuning table now); unset it.  MSD_GN_ROWS=4096 is still available.")
+    gn_rows = os.environ.get("MSD_GN_ROWS") or ""
     if not gn_rows:
         return
     try:

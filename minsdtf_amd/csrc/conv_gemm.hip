@@ -549,7 +549,8 @@ extern "C" int msd_conv_gemm(const MsdConvGemm* q, msd_stream_t stream_) {
     int halo_th = 0;
     if (q->tile_m >= 1000 && q->tile_m < 3000) {
         const int th = (q->tile_m % 1000) / 16;   // 1128 / 1256: 8x16 / 16x16 pixels; 2128: 8x16 on 8 waves
-        const bool ok = !q->a2 && q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
+        // (a shortcut operand - stride 1, same-size output, < 4 GB: checked above - is walked behind the slice's main chunks, conv_halo.hip)
+        const bool ok = q->ksize == 3 && q->stride == 1 && q->pad == 1 && q->h_out == q->h_in &&
                         q->w_out == q->w_in && !q->upsample && (q->w_in % 16) == 0 &&
                         (long long)q->N * a.K * 2 < (1ll << 32) - 4096 &&   // 32-bit weight / activation byte offsets
                         (long long)a.M * (q->c0 > q->c1 ? q->c0 : q->c1) * 2 < (1ll << 32) - 4096 &&

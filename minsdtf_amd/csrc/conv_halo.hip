@@ -14,7 +14,8 @@
 //   The swizzle (16-byte chunk XOR (row>>1)&7) is keyed on the HALO row, so a fragment = 16 consecutive
 //   halo rows starting anywhere is still bank-conflict free.
 // Requirements (host-checked, else the generic kernel runs): ksize 3, stride 1, no upsample,
-// w % 16 == 0, h % TH == 0.
+// w % 16 == 0, h % TH == 0.  A shortcut operand (a2 | a3: extra K chunks read at the output pixel) is walked behind the
+// slice's main chunks (round 6).
 #include "conv_common.h"
 
 #ifdef MSD_STAMPS
@@ -22,6 +23,10 @@ extern "C" MSD_API int msd_debug_stamps_halo(unsigned long long* host_out, int c
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count);
 }
 #endif
+
+// LDS bytes of an instance that walks a shortcut operand: what the main walk needs and no more (asking for room for five shortcut slots
+// everywhere took the small-ring configurations from two workgroups per CU to one: batch-1 loop + 3.9 %)
+constexpr int halo_xsc_lds(int base, int xslot) { return base >= 2 * xslot ? base : 2 * xslot; }
 
 // wait until at most min(later, MAXL) weight tiles (BR instructions each) + optionally one halo (HR) are in flight
 template <int BR, int HR, int MAXL>
@@ -59,7 +64,9 @@ __device__ __forceinline__ void halo_wait(int later, bool halo) {
 // step's tap 0 | MFMAs 2 — every read is issued in front of MFMAs that do not depend on it.  The barrier in the middle of a step orders the
 // stage reuse: in front of it every wave has retired the reads of the step's own stage (lgkmcnt(0)), so that stage takes filter row it + 3
 // right behind the barrier and a row keeps two steps to land.  Same taps in the same order: the same bits.
-template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1, int NL = 0, int PFX = 0>
+// XSC = the instance that walks a shortcut operand behind the main chunks (its own instantiation: the plain 3x3 convs keep the register
+// allocation and schedule they were tuned with - with the shortcut steps compiled into the one kernel the batch-1 loop measured 0.3 % slower)
+template <int TH, int BN, int WGM, int WGN, int S, int TAPS = 1, int NL = 0, int PFX = 0, bool XSC = false>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HALO_HOT_PARAMS, const CGArgs p) {
     const int hot_tiles_m = (int)(hot_pk_tiles & 0x7FFFFFu), hot_tiles_n = (int)((hot_pk_tiles >> 23) & 0xFFu), hot_m_fast = (int)(hot_pk_tiles >> 31);
     constexpr int TW = 16, BM = TH * TW;
@@ -424,6 +431,89 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HAL
         if (++stage == S) stage = 0;
         if (++tap == SPC) { tap = 0; ++c; hbuf ^= 1; }
     }
+    // ---- shortcut operand (ResBlock: conv2(h) + conv_shortcut(x) as ONE contraction, diffusion_model.py:34-38,50): after the slice's main
+    //      chunks, its share of the 64-channel chunks of a2 | a3, read at the OUTPUT pixel - one K step each on the plain TH x 16-pixel tile.
+    //      The same walk, the same dealing of the shortcut chunks over the slices and therefore the same bits as conv_bighalo_kernel's
+    //      (conv_big.hip), which takes these layers from about 128 of its 16 x 16-pixel workgroups on; here they run at ONE image per GPU
+    //      without leaving that numerics class.  The whole LDS of the workgroup (the halo buffers and the weight ring are free by now) is a
+    //      ring of XS slots {A tile: BM rows x 128 B | the chunk's BN x 64 weight tile}, XS - 1 chunks in flight behind a counted wait: with
+    //      two slots and one step of lead every step stood for a whole HBM latency (the weights are cold in the loop) and the form lost 0.3 %
+    //      of the batch-1 loop against the tile kernels it beats by 10 % in isolation.
+    const int nxc = XSC ? p.nk - p.nk_main : 0;
+    if constexpr (XSC) {
+        const int eps = (nxc + p.nslices - 1) / p.nslices;
+        const int e0 = min(nxc, (int)blockIdx.y * eps), e1 = min(nxc, e0 + eps);
+        const int cx3 = p.K - p.nk_main * 64 - p.c2;   // channels of a3
+        constexpr int AR = BM / RPP;                  // DMA rounds of the A tile
+        constexpr int XSLOT = BM * 128 + W1_BYTES;    // bytes per ring slot
+        constexpr int LDS_ALL = halo_xsc_lds(2 * H_BYTES + S * W_BYTES, XSLOT);
+        constexpr int XS = LDS_ALL / XSLOT < 6 ? LDS_ALL / XSLOT : 6;
+        constexpr int XI = AR + BR1;                  // DMA instructions per thread and chunk
+        static_assert(BM % RPP == 0 && XS >= 2 && (XS - 2) * XI <= 63, "shortcut ring: rows per DMA round, slots, countable waits");
+        int xpix[AR], xsrc[AR];
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int q = lrow + RPP * i;             // row of the tile = pixel (q >> 4, q & 15)
+            xpix[i] = (b * hot_h_in + ty0 + (q >> 4)) * hot_w_in + tx0 + (q & 15);
+            xsrc[i] = (cpos ^ ((q >> 1) & 7)) * 16;   // (swizzle keyed on the LDS row, as everywhere)
+        }
+        auto issue_extra = [&](int e, int slot) {
+            const int ce = e * 64;
+            const bool first = ce < p.c2;
+            const uint64_t sb = (uint64_t)(first ? p.a2 : p.a3) + (uint64_t)(uint32_t)((first ? ce : ce - p.c2) * 2);
+            const uint32_t cs2 = (uint32_t)(first ? p.c2 : cx3) * 2u;
+            const uint32_t baseA = __builtin_amdgcn_readfirstlane(lds_wave + (uint32_t)slot * (uint32_t)XSLOT);
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                dma16(reinterpret_cast<const void*>(sb + ((uint64_t)(uint32_t)xpix[i] * cs2 + (uint32_t)xsrc[i])), baseA + (uint32_t)(RPP * i) * 128u);
+            const uint32_t koff = (uint32_t)(p.nk_main + e) * p.w_ks;
+            const uint32_t baseW = baseA + (uint32_t)(BM * 128);
+#pragma unroll
+            for (int i = 0; i < BR1; ++i) dma16s(hot_w, woff[i] + koff, baseW + (uint32_t)(RPP * i) * 128u);
+        };
+        if (computes) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the main walk's last fragments are in registers ...
+        if (stages_tiles) wait_vmcnt<0>();                                   // ... and nothing of it is still on its way into LDS
+        __builtin_amdgcn_s_barrier();
+        if (stages_tiles) {
+#pragma unroll
+            for (int k = 0; k < XS - 1; ++k)
+                if (e0 + k < e1) issue_extra(e0 + k, k);
+        }
+        const int rw = cg_wrow(r);
+        int slot = 0, islot = XS - 1;   // slot of chunk e; slot the next issue goes to (= the one chunk e - 1 was read from)
+        for (int e = e0; e < e1; ++e) {
+            // chunk e has landed; younger in the queue and free to fly on: the chunks e + 1 .. e + XS - 2 as far as they exist
+            if (stages_tiles) halo_wait<XI, 0, XS - 2>(min(XS - 2, e1 - 1 - e), false);
+            if (computes) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // ... for every wave; the readers of chunk e - 1's slot have their fragments
+            if (stages_tiles && e + XS - 1 < e1) issue_extra(e + XS - 1, islot);
+            if (computes) {
+                const char* bA = smem + slot * XSLOT;
+                const char* bW = bA + BM * 128 + (wn * WNT + rw) * 128;
+                bf16x8 af[2][MI], wf[2][NJ];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int wc = ((ks * 4 + g) ^ (rw >> 1)) << 4;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        const int q = (wm * MI + i) * 16 + r;
+                        af[ks][i] = *reinterpret_cast<const bf16x8*>(bA + q * 128 + (((ks * 4 + g) ^ ((q >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) wf[ks][j] = *reinterpret_cast<const bf16x8*>(bW + j * 16 * 128 + wc);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+            }
+            if (++slot == XS) slot = 0;
+            if (++islot == XS) islot = 0;
+        }
+    }
     MSD_STAMP(3);
     if (NL > 0 && loader) return;
     int mrow[MI];
@@ -476,12 +566,13 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv3x3_halo_kernel(HAL
     X(16, 80, 4, 1, 153, 0, 1, 0) \
     X(16, 80, 4, 1, 155, 0, 1, 0)
 
-template <int TH, int BN, int WGM, int WGN, int SC, int TAPS, int NL>
+template <int TH, int BN, int WGM, int WGN, int SC, int TAPS, int NL, bool XSC = false>
 static constexpr int halo_lds() {
     constexpr int S = SC % 30;   // (SC = stages code: 30 + depth for the 3-taps-per-step form, 60 + depth: the same with 2 loader waves)
     constexpr int NT = (NL ? NL : WGM * WGN) * 64, RPP = NT / 8, HROWS = (TH + 2) * 18, HR = (HROWS + RPP - 1) / RPP;
     constexpr int BNP = (BN + RPP - 1) / RPP * RPP;
-    constexpr int bytes = 2 * HR * RPP * 128 + S * TAPS * BNP * 128;
+    constexpr int base = 2 * HR * RPP * 128 + S * TAPS * BNP * 128;
+    constexpr int bytes = XSC ? halo_xsc_lds(base, TH * 16 * 128 + BNP * 128) : base;
     static_assert(bytes <= 160 * 1024, "LDS budget");
     return bytes;
 }
@@ -492,8 +583,11 @@ int msd_conv_halo_init() {
     hipError_t e = hipSuccess;
 #define X(th, bn, wgm, wgn, st, var, taps, nl)                                                                         \
     if (e == hipSuccess)                                                                                              \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st % 30, taps, nl, (st >= 90)>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st, taps, nl>());
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st % 30, taps, nl, (st >= 90), false>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st, taps, nl>());                           \
+    if (e == hipSuccess)                                                                                              \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<th, bn, wgm, wgn, st % 30, taps, nl, (st >= 90), true>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, halo_lds<th, bn, wgm, wgn, st, taps, nl, true>());
     MSD_HALO_CFGS(X)
 #undef X
     if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(conv_halo): %s", hipGetErrorString(e));
@@ -524,8 +618,12 @@ int msd_conv_halo_launch(const CGArgs& a, int th, int bn, int stages, int varian
     }
 #define X(th_, bn_, wgm, wgn, st, var, taps, nl)                                                                          \
     if (th == th_ && bn == bn_ && stages == st && variant == var) {                                                       \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps, nl, (st >= 90)>), grid, dim3((wgm * wgn + nl) * 64), \
-                           (halo_lds<th_, bn_, wgm, wgn, st, taps, nl>()), stream, HALO_HOT_ARGS(a), a);                                    \
+        if (a.nk > a.nk_main)   /* a shortcut operand: the instance with the extra steps */                              \
+            hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps, nl, (st >= 90), true>), grid, dim3((wgm * wgn + nl) * 64), \
+                               (halo_lds<th_, bn_, wgm, wgn, st, taps, nl, true>()), stream, HALO_HOT_ARGS(a), a);                          \
+        else                                                                                                              \
+            hipLaunchKernelGGL((conv3x3_halo_kernel<th_, bn_, wgm, wgn, st % 30, taps, nl, (st >= 90), false>), grid, dim3((wgm * wgn + nl) * 64), \
+                               (halo_lds<th_, bn_, wgm, wgn, st, taps, nl>()), stream, HALO_HOT_ARGS(a), a);                                \
         return MSD_OK;                                                                                                    \
     }
     MSD_HALO_CFGS(X)

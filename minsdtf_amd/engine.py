@@ -355,12 +355,12 @@ FF_PROJ_FOLD = True
 MFMA_CONV_OUT = True
 # ResBlock with a 1x1 shortcut: conv2 and conv_shortcut as one GEMM (the shortcut's channels are extra K tiles)
 SHORTCUT_FOLD = os.environ.get("MSD_SHORTCUT_FOLD", "1") != "0"   # (env switch: same-box A/B runs)
-# ... except at the UNet / ControlNet levels with >= this many pixels per SAMPLE (64x64 and up), where conv2 runs on the halo-tile kernel
-# (which has no shortcut operand) and conv2 + a separate 1x1 shortcut launch is faster than the folded general-kernel
-# contraction (in place at batch 1: 26.3 + 12.5 us against 43-47 us folded; below 64x64 the fold wins by 6-13 us).  The
-# rule reads the per-sample shape only: folding changes the order of a layer's sums, and a sample's bits must not depend
-# on the batch it runs in.
-SHORTCUT_FOLD_MAX_PIXELS = int(os.environ.get("MSD_SHORTCUT_FOLD_MAX_PIXELS", "4096"))
+# ... below this many pixels per SAMPLE.  Rounds 2-5 stopped folding at 64x64 (4096): conv2 ran on the halo-tile kernel, which had no shortcut
+# operand, and conv2 + a separate 1x1 launch beat the folded general-kernel contraction there.  Round 6: the halo-tile kernel walks the
+# shortcut chunks itself (csrc/conv_halo.hip) and the fold wins at every level (in place, batch 1: 36.5 -> 29.2 us per 64x64-level block), so
+# there is no limit any more; the switch stays for same-box A/B runs.  The rule reads the per-sample shape only: folding changes the order of
+# a layer's sums, and a sample's bits must not depend on the batch it runs in.
+SHORTCUT_FOLD_MAX_PIXELS = int(os.environ.get("MSD_SHORTCUT_FOLD_MAX_PIXELS", str(1 << 30)))
 # packed msd_conv_gemm weights stored chunk-major [K/64][N][64] (packing.chunk_major) instead of [N][K] rows
 W_CHUNK_MAJOR = os.environ.get("MSD_W_CHUNK_MAJOR", "1") != "0"
 # the concatenated time_emb_proj Dense of the preparation plan on the MFMA path (bf16 weights and input, fp32 table)

@@ -15,7 +15,6 @@ import re
 from typing import Dict, Optional, Tuple
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning.json")
-_PROFILE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tuning_throughput.json")
 _table: Optional[Dict[str, list]] = None
 _families: Optional[Dict[str, Dict[int, list]]] = None   # batch-agnostic key -> {batch: entry}
 
@@ -85,14 +84,6 @@ def shape_key(batch, h_in, w_in, cin, N, ksize, stride, upsample, allow_split=Tr
             f"{'+x' + str(cx) if cx else ''}")
 
 
-def profile() -> str:
-    """"latency" (default: every choice made for one image per GPU, the headline) or "throughput" ($MSD_PROFILE)."""
-    p = os.environ.get("MSD_PROFILE", "latency") or "latency"
-    if p not in ("latency", "throughput"):
-        raise ValueError(f"MSD_PROFILE={p!r}: latency or throughput")
-    return p
-
-
 def _load() -> Dict[str, list]:
     global _table, _families
     if _table is None:
@@ -101,16 +92,6 @@ def _load() -> Dict[str, list]:
                 _table = json.load(f)
         except (OSError, ValueError):
             _table = {}
-        # Serving profile: MSD_PROFILE=throughput lays conv_tuning_throughput.json over the table - whole LAYERS (every measured batch of a
-        # layer shape, so the one-class-per-layer rule holds inside the profile) moved to the configuration that pays from two images per GPU
-        # and costs at one: the shortcut-folded 3x3 convs on the staged-halo big form.  A process-wide arithmetic choice, like
-        # MSD_GN_ROWS (which this profile also sets to 4096 unless given: minsdtf_amd/_lib.py).
-        if profile() == "throughput":
-            try:
-                with open(_PROFILE_PATH) as f:
-                    _table.update(json.load(f))
-            except (OSError, ValueError) as e:
-                raise RuntimeError(f"MSD_PROFILE=throughput: cannot read {_PROFILE_PATH}: {e}") from e
         # A/B runs: $MSD_TUNE_OVERRIDE = JSON {shape key: [tile_m, tile_n, splitk, stages]} (or @file) laid over the table
         ov = os.environ.get("MSD_TUNE_OVERRIDE")
         if ov:
@@ -164,8 +145,8 @@ def shape_class(h_in, w_in, cin, N, ksize, stride, upsample, allow_split, cx=0) 
             walk = "chunk"       # halo-tile kernel (8 x 16-pixel tiles), staged-halo big form on whole 16 x 16 tiles
         elif cx == 0 and upsample and tile16 and h_in * w_in >= 256:
             walk = "chunk"       # nearest x2 + conv on the staged halo (chunk-major big form where the tiles are not whole)
-        elif cx and tile16 and hw_out >= 2304:
-            walk = "chunk_sc"    # shortcut-folded conv on the staged halo: pays from 48 x 48 pixels per sample at every batch
+        elif cx and w_in % 16 == 0 and h_in % 8 == 0 and hw_out >= 256:
+            walk = "chunk_sc"    # shortcut-folded conv: halo-tile kernel (one or two images per GPU) / staged-halo big form, one class (round 6)
     sk = 1
     if allow_split:
         if walk != "tap":
@@ -193,7 +174,12 @@ def shape_config(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allo
     tile16 = stride == 1 and hl % 16 == 0 and wl % 16 == 0
     wide = 128 if (N % 128 == 0 or N > 1024) else 64
     if walk == "chunk_sc":
-        return 5256, 128, sk, 20
+        wgs16 = batch * (hl // 16) * (wl // 16) * _ceil_div(N, 128) * sk if tile16 else 0
+        if N >= 128 and wgs16 >= 128:
+            return 5256, (160 if (N % 160 == 0 and M >= 32768 and allow_split) else 128), sk, 20
+        if M <= 4096 or N < 80:
+            return 1128, 64, sk, 0        # (in place the plain 8 x 16 loop won at one image per GPU: tools/unify_shortcut_insitu.py)
+        return 1128, (80 if (N % 80 == 0 and allow_split) else 64), sk, 93
     if walk == "chunk":
         wgs16 = batch * (hl // 16) * (wl // 16) * _ceil_div(N, 128) * sk if tile16 else 0
         if upsample:
@@ -253,8 +239,9 @@ def lookup(batch, h_in, w_in, cin, N, ksize, stride, upsample, M, nk, allow_spli
                 ent = [128] + list(ent[1:])
             if is_big(int(ent[0])) and M < BIG_MIN_ROWS:   # (a 256-row macro tile on a small launch: the same class on small tiles)
                 stg = int(ent[3]) if len(ent) > 4 else 0
-                if stg >= 20 and cx:   # (shortcut-folded conv on the staged halo: no other kernel walks it chunk-major; it takes any whole number of tiles)
-                    pass
+                if stg >= 20 and cx:   # (shortcut-folded conv of the chunk-major class: a small launch runs on the halo-tile kernel, the same bits)
+                    if w_in % 16 == 0 and h_in % 8 == 0:
+                        ent = [1128, 80 if (N % 80 == 0 and M > 4096) else 64, int(ent[2]), 93 if M > 4096 else 0, 0.0]
                 elif stg >= 10 and not upsample and stride == 1 and w_in % 16 == 0 and h_in % 8 == 0:
                     ent = [1128, 80 if N % 80 == 0 else 64, int(ent[2]), 0, 0.0]
                 elif stg >= 10:   # (an upsampling layer of the chunk-major class: the halo-tile kernel does not take it; the big form walks any M)

@@ -268,21 +268,3 @@ def test_c5_controlnet_512(gpu, unet512, nsteps):
     p = O.psnr(got, g["latent"])
     print(f"C5 ControlNet 512x512, {steps} steps: final-latent PSNR {p:.1f} dB")
     assert p >= PSNR_MIN
-
-
-def test_throughput_profile_keeps_batch_independence_and_parity(gpu):
-    """MSD_PROFILE=throughput (minsdtf_amd/tuning.py: the shortcut-folded 3x3 convs of the 64x64 / 32x32 / 16x16 levels on the staged-halo big
-    form for every batch, the 64x64-level GroupNorms on the row-major cluster form) is a second, process-wide arithmetic: inside it a sample's
-    bits still do not depend on its batch, and the 25-step latent still clears the parity bar (tests/_profile_child.py, its own process: the
-    profile is read at import)."""
-    import json
-    import subprocess
-    import sys
-
-    env = dict(os.environ, MSD_PROFILE="throughput")
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_profile_child.py")], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    res = json.loads(r.stdout.strip().splitlines()[-1])
-    print("throughput profile:", res)
-    assert res["finite"] and res["batch_independent"], res
-    assert res["psnr_db"] >= PSNR_MIN, res

@@ -360,20 +360,17 @@ def test_tuning_table_pins_one_numerics_class_per_layer():
     from minsdtf_amd import tuning
 
     table = json.load(open(os.path.join(ROOT, "minsdtf_amd", "conv_tuning.json")))
-    overlay = json.load(open(os.path.join(ROOT, "minsdtf_amd", "conv_tuning_throughput.json")))   # MSD_PROFILE=throughput lays this over the table
-    assert overlay and set(overlay) <= set(table), "the throughput overlay moves measured entries only"
-    for tab in (table, {**table, **overlay}):   # ... inside either profile
-        fams = {}
-        for key, ent in tab.items():
-            b, rest = key.split("x", 1)
-            ks = int(re.search(r"k(\d)s", rest).group(1))
-            fams.setdefault(rest, set()).add(tuning.numerics_class(ks, int(ent[0]), int(ent[1]), int(ent[2]), tuning.key_is_ln_producer(key), stages=int(ent[3]) if len(ent) > 4 else 0))
-        bad = {k: v for k, v in fams.items() if len(v) != 1}
-        assert not bad, bad
-    # the overlay moves WHOLE layers (every measured batch of a layer shape), and only shortcut-folded 3x3 convs onto the staged-halo big form
-    moved = {k.split("x", 1)[1] for k in overlay}
-    assert all((k in overlay) for k in table if k.split("x", 1)[1] in moved)
-    assert all("+x" in k and int(e[0]) == 5256 and int(e[3]) >= 20 for k, e in overlay.items())
+    assert not os.path.exists(os.path.join(ROOT, "minsdtf_amd", "conv_tuning_throughput.json")), "round 6: ONE table, one set of bits per layer"
+    fams = {}
+    for key, ent in table.items():
+        b, rest = key.split("x", 1)
+        ks = int(re.search(r"k(\d)s", rest).group(1))
+        fams.setdefault(rest, set()).add(tuning.numerics_class(ks, int(ent[0]), int(ent[1]), int(ent[2]), tuning.key_is_ln_producer(key), stages=int(ent[3]) if len(ent) > 4 else 0))
+    bad = {k: v for k, v in fams.items() if len(v) != 1}
+    assert not bad, bad
+    # the shortcut-folded 3x3 convs of the 16x16 / 32x32 / 64x64 levels: chunk-major (halo-tile kernel or staged-halo big form) at EVERY batch
+    sc = {k: e for k, e in table.items() if re.search(r"x(16x16|32x32|64x64)x\d+->\d+k3s1u0\+x", k)}
+    assert len(sc) >= 36 and all(tuning.is_halo(int(e[0])) or (tuning.is_big(int(e[0])) and int(e[3]) >= 20) for e in sc.values()), sc
     # an unmeasured batch lands in the same class as the measured ones; an unknown layer falls back per SAMPLE
     a = tuning.lookup(2, 8, 8, 1280, 1280, 3, 1, False, 128, 180, True)
     b = tuning.lookup(6, 8, 8, 1280, 1280, 3, 1, False, 384, 180, True)
@@ -530,8 +527,8 @@ def test_env_options_are_validated_before_the_library_is_cached(monkeypatch):
     with pytest.raises(_lib.HipExtensionError, match="MSD_GN_ROWS"):
         _lib.load()
     monkeypatch.delenv("MSD_GN_ROWS")
-    monkeypatch.setenv("MSD_PROFILE", "Throughput")
-    with pytest.raises(_lib.HipExtensionError, match="MSD_PROFILE"):
+    monkeypatch.setenv("MSD_PROFILE", "throughput")   # round 5's second table is gone: a process that still asks for it is told so
+    with pytest.raises(_lib.HipExtensionError, match="removed in round 6"):
         _lib.load()
     assert _lib._lib is None
     monkeypatch.delenv("MSD_PROFILE")
@@ -601,7 +598,7 @@ def _config_is_built(cfg, shape):
     hl, wl = (2 * h_in, 2 * w_in) if ups else (h_in, w_in)
     key = (bm, bn, stg)
     if t.is_halo(bm):
-        return key in t.HALO_TILES and ks == 3 and stride == 1 and not ups and not cx and w_in % 16 == 0 and h_in % ((bm % 1000) // 16) == 0
+        return key in t.HALO_TILES and ks == 3 and stride == 1 and not ups and w_in % 16 == 0 and h_in % ((bm % 1000) // 16) == 0   # (round 6: with a shortcut operand too)
     if t.is_rowpanel(bm):
         return ks == 1 and stride == 1 and not ups and not cx and cin in t.ROWPANEL_ROWS and bm in t.ROWPANEL_ROWS[cin] and bn in t.ROWPANEL_COLS and N % bn == 0 and N % 32 == 0
     if t.is_wreg(bm):

@@ -281,6 +281,16 @@ def test_conv_gemm(gpu, case):
     dict(B=1, H=32, W=16, c=192, cx0=128, cx1=64, N=272, ks=3, tile_m=5256, tile_n=128, stages=20, other=(5256, 160, 20)),            # shortcut over a concat: 3 chunks, ragged N
     dict(B=2, H=16, W=16, c=320, cx0=640, cx1=0, N=320, ks=3, splitk=3, tile_m=5256, tile_n=128, stages=21, other=(5256, 160, 20)),   # 5 + 10 chunks over 3 slices (2, 2, 1 main; 4, 4, 2 extra)
     dict(B=1, H=16, W=16, c=128, cx0=64, cx1=0, N=128, ks=3, splitk=2, tile_m=5256, tile_n=128, stages=20, other=(5256, 128, 21)),    # the second slice has no shortcut chunk
+    # round 6: the halo-tile kernel walks the shortcut chunks behind the slice's main chunks too (conv_halo.hip) - every loop form of it, against
+    # the staged-halo big form: ONE numerics class for these layers at every batch (the table no longer needs a second profile)
+    dict(B=2, H=16, W=32, c=128, cx0=64, cx1=0, N=160, ks=3, tile_m=1128, tile_n=64, stages=0, other=(5256, 128, 20)),                 # plain loop, ONE shortcut chunk, ragged N
+    dict(B=1, H=32, W=16, c=192, cx0=128, cx1=64, N=272, ks=3, tile_m=2128, tile_n=64, stages=33, other=(5256, 160, 20)),              # 3 taps per step on 8 waves; shortcut over a concat
+    dict(B=2, H=16, W=16, c=320, cx0=640, cx1=0, N=320, ks=3, splitk=3, tile_m=1128, tile_n=80, stages=93, other=(5256, 128, 21)),     # rotated loop + loader waves; 5 + 10 chunks over 3 slices
+    dict(B=1, H=16, W=16, c=128, cx0=64, cx1=0, N=128, ks=3, splitk=2, tile_m=1128, tile_n=64, stages=153, other=(5256, 128, 20)),     # one-tap rotated loop; the second slice has no shortcut chunk
+    dict(B=2, H=16, W=16, c=128, cx0=192, cx1=0, N=256, ks=3, tile_m=1256, tile_n=128, stages=0, other=(5256, 128, 20)),               # 16 x 16-pixel tiles: a 256-row shortcut tile
+    dict(B=2, H=16, W=32, c=192, cx0=64, cx1=128, N=160, ks=3, tile_m=1128, tile_n=80, stages=63, other=(5256, 160, 20)),              # loader waves, lock-step loop; concat boundary between shortcut chunks
+    dict(B=3, H=32, W=32, c=64, cx0=320, cx1=0, N=128, ks=3, tile_m=1128, tile_n=128, stages=6, other=(5256, 128, 20)),                # more shortcut chunks (5) than main chunks (1), deep ring
+    dict(B=2, H=8, W=16, c=128, cx0=128, cx1=0, N=64, ks=3, splitk=2, tile_m=2128, tile_n=64, stages=33),                              # an 8-row image (no 16 x 16 tile): the kernel against the fp32 answer alone
 ])
 def test_conv_gemm_shortcut_operand(gpu, case):
     """conv(h) + conv1x1(x) as one contraction (diffusion_model.py:34-38,50): K = taps of h, then the channels of x."""

@@ -60,9 +60,9 @@ if [ "$WHAT" = all ] || [ "$WHAT" = b4 ]; then      # C3's per-GPU shape: batch 
     pmc _b4 --batch 4 || exit $?
     MSD_BENCH_KEEP_TRACE=$OUT/${TAG}_graph $T 400 python bench.py --batch-per-gpu 4 --steps 3 --no-cpu-baseline --quoted-traffic > $OUT/${TAG}_bench_b4.json 2>> $OUT/bench_cfg.err
     echo "b4 done"
-    # the opt-in serving profile at the same shape (MSD_PROFILE=throughput: DESIGN.md 4.1 / 4.3), its own file
-    MSD_PROFILE=throughput $T 300 python bench.py --batch-per-gpu 4 --steps 3 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_b4_throughput.json 2>> $OUT/bench_cfg.err
-    echo "b4 throughput profile done"
+    # the serving choice for the GroupNorm form (MSD_GN_ROWS=4096: DESIGN.md 4.3), its own file
+    MSD_GN_ROWS=4096 $T 300 python bench.py --batch-per-gpu 4 --steps 3 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_b4_gn_rows4096.json 2>> $OUT/bench_cfg.err
+    echo "b4 gn_rows 4096 done"
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = 768 ]; then     # C4: 768x768, 50 steps
     pmc _768 --size 768 || exit $?

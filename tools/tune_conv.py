@@ -130,7 +130,7 @@ def tune_one(shape, iters=10, only=None, sks_only=None):
     best = None
     results = []
     cands = list(tuning.TILES)
-    if ks == 3 and stride == 1 and not ups and w_in % 16 == 0 and not cx:  # halo-tile kernel (tile_m = 1000 + pixels per tile)
+    if ks == 3 and stride == 1 and not ups and w_in % 16 == 0:  # halo-tile kernel (tile_m = 1000 + pixels per tile; round 6: with a shortcut operand too)
         cands += [t for t in tuning.HALO_TILES if h_in % ((t[0] % 1000) // 16) == 0]
     if ks == 1 and stride == 1 and not ups and not cx and cin in tuning.ROWPANEL_ROWS and N % 32 == 0:   # row-panel Dense kernel
         cands += [(rows, cols, 0) for rows in tuning.ROWPANEL_ROWS[cin] for cols in tuning.ROWPANEL_COLS if N % cols == 0]
