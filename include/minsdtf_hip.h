@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MSD_ABI_VERSION 10
+#define MSD_ABI_VERSION 11
 
 #define MSD_OK 0
 #define MSD_E_ARG (-1)      /* bad / inconsistent argument */
@@ -344,6 +344,13 @@ MSD_API int msd_softmax_rows(const float* x, void* out, int64_t rows, int32_t co
 MSD_API int msd_embedding_sum(const int32_t* tokens, const int32_t* positions, const float* tok_table, const float* pos_table,
                       void* out, int32_t rows, int32_t dim, int32_t vocab, int32_t max_len, int32_t* status,
                       msd_stream_t stream);
+
+/* msd_replicate (ABI 11) — dst = `copies` replicas of the `bytes` bytes at src, back to back (bytes % 16 == 0; src == dst: replica 0
+ * stays where it is; any other overlap: MSD_E_ARG).  The classifier-free-guidance pair of one step (stable_diffusion.py:454-457: the
+ * unconditional and the conditioned call get the SAME latent and time embedding) is identical up to the first cross-attention
+ * (diffusion_model.py:191-196: conv_in, down_blocks.0.resnets.0, and norm / proj_in / attn1 of down_blocks.0.attentions.0); the fused
+ * batch computes that prefix once per image and replicates three tensors (engine.SHARE_CFG_PREFIX). */
+MSD_API int msd_replicate(const void* src, void* dst, int64_t bytes, int32_t copies, msd_stream_t stream);
 
 /* msd_memset_zero — stream-ordered hipMemsetAsync(ptr, 0, bytes) (GroupNorm statistic slots). */
 MSD_API int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream);

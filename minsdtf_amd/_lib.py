@@ -15,7 +15,7 @@ import weakref
 LIB_NAME = "libminsdtf_hip.so"
 # $MSD_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one box); default = the in-tree build
 LIB_PATH = os.environ.get("MSD_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_QUICK_GELU = 0, 1, 2, 3
 OUT_BF16, OUT_F32, OUT_U8 = 0, 1, 2
@@ -108,6 +108,7 @@ SYMBOLS = {
     "msd_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                    C.c_void_p]),
     "msd_memset_zero": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "msd_replicate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "msd_embedding_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_void_p, C.c_void_p]),
     "msd_cfg_step": (C.c_int, [C.POINTER(MsdCfgStep), C.c_void_p]),

@@ -225,6 +225,28 @@ extern "C" int msd_cast_bf16_to_f32(const void* in, float* out, int64_t n, msd_s
     MSD_CHECK_LAUNCH();
     return MSD_OK;
 }
+// dst holds `copies` replicas of the `nvec` 16-byte vectors at src, back to back; src == dst: replica 0 is in place
+__global__ __launch_bounds__(256) void replicate_kernel(const uint4* src, uint4* dst, long long nvec, int copies, int first) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const uint4 v = src[i];
+        for (int j = first; j < copies; ++j) dst[(long long)j * nvec + i] = v;
+    }
+}
+extern "C" int msd_replicate(const void* src, void* dst, int64_t bytes, int32_t copies, msd_stream_t stream_) {
+    if (!src || !dst || bytes <= 0 || (bytes % 16) || copies < 1 || copies > 64) MSD_FAIL(MSD_E_ARG, "replicate: bad arguments (bytes %% 16 == 0, 1 <= copies <= 64)");
+    if (!msd_aligned16(src) || !msd_aligned16(dst)) MSD_FAIL(MSD_E_ALIGN, "replicate: alignment");
+    const char* s0 = (const char*)src;
+    const char* d0 = (const char*)dst;
+    const bool in_place = s0 == d0;
+    // any other overlap of the source with the replicas would read bytes this launch writes
+    if (!in_place && s0 < d0 + (long long)copies * bytes && d0 < s0 + bytes) MSD_FAIL(MSD_E_ARG, "replicate: src overlaps dst (only src == dst is allowed)");
+    if (in_place && copies == 1) return MSD_OK;
+    hipLaunchKernelGGL(replicate_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, (hipStream_t)stream_, (const uint4*)src, (uint4*)dst,
+                       (long long)(bytes / 16), (int)copies, in_place ? 1 : 0);
+    MSD_CHECK_LAUNCH();
+    return MSD_OK;
+}
+
 extern "C" int msd_memset_zero(void* ptr, int64_t bytes, msd_stream_t stream_) {
     if (!ptr || bytes <= 0) MSD_FAIL(MSD_E_ARG, "memset_zero: bad arguments");
     hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream_);

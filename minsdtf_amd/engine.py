@@ -361,6 +361,13 @@ SHORTCUT_FOLD = os.environ.get("MSD_SHORTCUT_FOLD", "1") != "0"   # (env switch:
 # there is no limit any more; the switch stays for same-box A/B runs.  The rule reads the per-sample shape only: folding changes the order of
 # a layer's sums, and a sample's bits must not depend on the batch it runs in.
 SHORTCUT_FOLD_MAX_PIXELS = int(os.environ.get("MSD_SHORTCUT_FOLD_MAX_PIXELS", str(1 << 30)))
+# Classifier-free guidance runs the UNet twice per step on the SAME latent and time embedding (stable_diffusion.py:454-457); the two
+# forwards differ only in the text context, which first enters at down_blocks.0.attentions.0's attn2 (diffusion_model.py:191-196,88-95).
+# In the fused batch (rows [0, B) unconditional, [B, 2B) conditioned) everything in front of that point - conv_in, down_blocks.0.resnets.0,
+# and norm / proj_in / q|k|v / self-attention / to_out of the first transformer block, 10 % of a step's FLOP - is therefore computed ONCE per
+# image and three tensors are replicated (msd_replicate).  Exact: a sample's bits do not depend on the batch it runs in, so
+# the replicated rows are the rows the second computation would have produced, bit for bit (tests/test_configs_gpu.py).
+SHARE_CFG_PREFIX = os.environ.get("MSD_SHARE_CFG_PREFIX", "1") != "0"   # (env switch: same-box A/B runs)
 # packed msd_conv_gemm weights stored chunk-major [K/64][N][64] (packing.chunk_major) instead of [N][K] rows
 W_CHUNK_MAJOR = os.environ.get("MSD_W_CHUNK_MAJOR", "1") != "0"
 # the concatenated time_emb_proj Dense of the preparation plan on the MFMA path (bf16 weights and input, fp32 table)
@@ -456,6 +463,16 @@ class Emitter:
         p.rec(ops.conv_gemm, **kw)
         return out
 
+    def widen(self, x: Act, copies: int, name: str) -> Act:
+        """`x` is the first x.B samples of a buffer that was allocated for copies * x.B: fill the rest with replicas of it and
+        return the whole (the fused cond + uncond batch behind the part of the UNet both halves share, SHARE_CFG_PREFIX)."""
+        if copies == 1:
+            return x
+        nbytes = x.B * x.H * x.W * x.C * 2
+        assert x.buf.nbytes >= copies * nbytes
+        self.p.rec(ops.replicate, src=x.buf, dst=x.buf, nbytes=nbytes, copies=copies, name=name + ".replicate")
+        return Act(x.buf, x.B * copies, x.H, x.W, x.C)
+
     def group_norm(self, x, name, silu: bool) -> Act:
         p = self.p
         x0, x1 = (x if isinstance(x, tuple) else (x, None))
@@ -473,8 +490,9 @@ class Emitter:
         return out
 
     # ---- reference layer types
-    def res_block(self, x, name, cout, temb=None, free_input=False) -> Act:
-        """ResBlock (diffusion_model.py:22-51) / VAE ResnetBlock (layers.py:62-80, temb=None)."""
+    def res_block(self, x, name, cout, temb=None, free_input=False, out_copies: int = 1) -> Act:
+        """ResBlock (diffusion_model.py:22-51) / VAE ResnetBlock (layers.py:62-80, temb=None).  out_copies > 1: the result is written
+        into the head of a buffer for out_copies * B samples and replicated (SHARE_CFG_PREFIX); the returned Act is the wide one."""
         p = self.p
         x0 = x[0] if isinstance(x, tuple) else x
         cin = sum(a.C for a in x) if isinstance(x, tuple) else x.C
@@ -484,9 +502,13 @@ class Emitter:
         g2 = self.group_norm(h, name + ".norm2", silu=True)
         p.free(h)
         fold = SHORTCUT_FOLD and (temb is None or x0.H * x0.W < SHORTCUT_FOLD_MAX_PIXELS)   # (VAE blocks: measured equal, stay folded)
+        head = None
+        if out_copies > 1:   # the block's output in the head of the wide buffer
+            wide = p.act(x0.B * out_copies, x0.H, x0.W, cout)
+            head = Act(wide.buf, x0.B, x0.H, x0.W, cout)
         if cin != cout and fold and (name + ".conv2sc.w") in self.W:
             # conv2(h) + conv_shortcut(x) as ONE contraction: K = 9 C_out taps of g2, then the C_in channels of x
-            out = self.conv(g2, name + ".conv2sc", cout, ksize=3, extra=x)
+            out = self.conv(g2, name + ".conv2sc", cout, ksize=3, extra=x, out=head)
             p.free(g2)
         else:
             if cin != cout:
@@ -494,18 +516,27 @@ class Emitter:
             else:
                 assert not isinstance(x, tuple)
                 res = x0
-            out = self.conv(g2, name + ".conv2", cout, ksize=3, residual=res)
+            out = self.conv(g2, name + ".conv2", cout, ksize=3, residual=res, out=head)
             p.free(g2)
             if res is not x0:
                 p.free(res)
+        if out_copies > 1:
+            out = self.widen(out, out_copies, name)
         if free_input:
             for a in (x if isinstance(x, tuple) else (x,)):
                 p.free(a)
         return out
 
-    def attentions(self, x: Act, name, ctx_kv, ctx_len, heads=8, free_input=False) -> Act:
-        """Attentions / TransformerBlock / CrossAttention / GEGLU (diffusion_model.py:54-153)."""
+    def attentions(self, x: Act, name, ctx_kv, ctx_len, heads=8, free_input=False, shared: int = 1) -> Act:
+        """Attentions / TransformerBlock / CrossAttention / GEGLU (diffusion_model.py:54-153).  shared > 1 (SHARE_CFG_PREFIX): `x` holds
+        `shared` identical copies of x.B / shared samples (the cond and uncond halves in front of the first cross-attention): norm,
+        proj_in, q|k|v, the self-attention and its to_out run on ONE copy, their result (rows + LayerNorm partials) is replicated, and the
+        block continues on the whole batch from attn2 on, where the halves' text contexts differ."""
         p = self.p
+        x_all = x
+        if shared > 1:
+            assert x.B % shared == 0
+            x = Act(x.buf, x.B // shared, x.H, x.W, x.C)   # the first copy
         B, H, Wd, C = x.B, x.H, x.W, x.C
         S = H * Wd
         d = C // heads
@@ -529,8 +560,22 @@ class Emitter:
         p.rec(ops.attention, q=q.buf, k=k.buf, vt=vt, out=a1.buf, batch=B, heads=heads, head_dim=d, s=S, t=S, q_ld=C,
               k_ld=C, vt_ld=sp, o_ld=C, scale=d ** -0.5, q_prescaled=True, name=tb + ".attn1")
         p.free(q, k, vt)
-        t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0, ln_out=fold)
-        p.free(a1, t0)
+        if shared > 1:
+            t1_wide = p.act(B * shared, H, Wd, C)
+            t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0, ln_out=fold, out=Act(t1_wide.buf, B, H, Wd, C))
+            p.free(a1, t0)
+            ln = t1.ln
+            t1 = self.widen(t1, shared, tb + ".attn1.to_out.0")
+            if ln is not None:   # the row-moment partials of the rows, replicated like the rows
+                nb_ln = B * H * Wd * ln[1] * 8
+                ln_wide = p.alloc(shared * nb_ln)
+                p.rec(ops.replicate, src=ln[0], dst=ln_wide, nbytes=nb_ln, copies=shared, name=tb + ".attn1.to_out.0.ln.replicate")
+                p.free(ln[0])
+                t1.ln = (ln_wide, ln[1])
+            x, B = x_all, B * shared
+        else:
+            t1 = self.conv(a1, tb + ".attn1.to_out.0", C, residual=t0, ln_out=fold)
+            p.free(a1, t0)
         # cross-attention over the text context (k, v^T precomputed once per prompt)
         kc, vtc, tp = ctx_kv[tb + ".attn2"]
         a2 = p.act(B, H, Wd, C)
@@ -650,11 +695,18 @@ def temb_columns(encoder_only: bool) -> Dict[str, int]:
     return cols
 
 
-def _emit_encoder(e: Emitter, x: Act, temb_of, ctx_kv, ctx_len, outputs: List[Act]) -> Act:
-    """Down path + mid block shared by the UNet (diffusion_model.py:193-229) and the ControlNet."""
+def _emit_encoder(e: Emitter, x: Act, temb_of, ctx_kv, ctx_len, outputs: List[Act], shared: int = 1) -> Act:
+    """Down path + mid block shared by the UNet (diffusion_model.py:193-229) and the ControlNet.  shared > 1: `x` (conv_in's output) is
+    `shared` identical copies of x.B / shared samples - the first ResBlock and the front of the first transformer block run on one."""
     for lvl, ch in enumerate(wtab.UNET_CH):
         for r in range(2):
             name = f"down_blocks.{lvl}.resnets.{r}"
+            if shared > 1 and lvl == 0 and r == 0:
+                one = Act(x.buf, x.B // shared, x.H, x.W, x.C)
+                x = e.res_block(one, name, ch, temb=temb_of(name), out_copies=shared)
+                x = e.attentions(x, f"down_blocks.{lvl}.attentions.{r}", ctx_kv, ctx_len, free_input=True, shared=shared)
+                outputs.append(x)
+                continue
             x = e.res_block(x, name, ch, temb=temb_of(name))
             if lvl < 3:
                 x = e.attentions(x, f"down_blocks.{lvl}.attentions.{r}", ctx_kv, ctx_len, free_input=True)
@@ -693,7 +745,9 @@ def emit_unet(e: Emitter, latent_f32, latent_batch_mod: int, NB: int, h: int, w:
           in_batch_mod=latent_batch_mod, h_in=h, w_in=w, c_in=4, c_out=320, ksize=3, in_dtype=ops.OUT_F32,
           out_dtype=ops.OUT_BF16, name="conv_in")
     outputs: List[Act] = [x]
-    x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs)
+    # (conv_in itself stays on the whole batch: every row reads latent row b % latent_batch_mod, a 10-us launch whose output is skip 0)
+    shared = NB // latent_batch_mod if (SHARE_CFG_PREFIX and latent_batch_mod > 0 and NB % latent_batch_mod == 0) else 1
+    x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs, shared=shared)
     p.mark("controls")   # everything above is independent of the ControlNet (its encoder may run beside it on another stream)
     if control_taps is not None:
         e_c, feats = control_taps
@@ -745,7 +799,9 @@ def emit_controlnet_features(e: Emitter, latent_f32, latent_batch_mod: int, NB: 
           in_batch_mod=latent_batch_mod, h_in=h, w_in=w, c_in=4, c_out=320, ksize=3, in_dtype=ops.OUT_F32,
           out_dtype=ops.OUT_BF16, name="conv_in+hint")
     outputs: List[Act] = [x]
-    x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs)
+    # (the hint is tiled to both halves - emit_hintnet's copies - so conv_in + hint is the same in every copy of the batch too)
+    shared = NB // latent_batch_mod if (SHARE_CFG_PREFIX and latent_batch_mod > 0 and NB % latent_batch_mod == 0) else 1
+    x = _emit_encoder(e, x, temb_of, ctx_kv, ctx_len, outputs, shared=shared)
     outputs.append(x)
     assert len(outputs) == 13
     return outputs

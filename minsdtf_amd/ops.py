@@ -205,6 +205,12 @@ def embedding_sum(*, tokens, positions, tok_table, pos_table, out, rows, dim, vo
                                         _p(status)), name)
 
 
+def replicate(*, src, dst, nbytes, copies, name="replicate") -> Call:
+    """dst = `copies` replicas of src's nbytes back to back (src may be dst: replica 0 in place)."""
+    lib = _lib.load()
+    return Call(lib.msd_replicate, (_p(src), _p(dst), int(nbytes), int(copies)), name)
+
+
 def memset_zero(*, ptr, nbytes, name="memset") -> Call:
     lib = _lib.load()
     return Call(lib.msd_memset_zero, (_p(ptr), nbytes), name)

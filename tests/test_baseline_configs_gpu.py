@@ -268,3 +268,24 @@ def test_c5_controlnet_512(gpu, unet512, nsteps):
     p = O.psnr(got, g["latent"])
     print(f"C5 ControlNet 512x512, {steps} steps: final-latent PSNR {p:.1f} dB")
     assert p >= PSNR_MIN
+
+
+def test_cfg_prefix_sharing_is_exact_at_512(gpu, unet512):
+    """The shared classifier-free-guidance prefix (engine.SHARE_CFG_PREFIX, tests/test_configs_gpu.py) at the REAL layer shapes:
+    the one-copy prefix runs on the batch-1 table rows, the two-copy computation on the batch-2 rows - different kernel forms of one
+    numerics class - and the 2-step latent is the same bits."""
+    from minsdtf_amd import engine
+
+    ctx, unc, noise = _inputs(2, 64)
+    sd = _pipeline(gpu, 512, unet512)
+    kw = dict(negative_prompt=unc, batch_size=2, num_steps=2, unconditional_guidance_scale=7.5, diffusion_noise=noise, guidance_rescale=0.7,
+              return_latent=True)
+    shared = sd.generate_image(ctx, **kw)
+    try:
+        engine.SHARE_CFG_PREFIX = False
+        sd._engines = {}
+        both = sd.generate_image(ctx, **kw)
+    finally:
+        engine.SHARE_CFG_PREFIX = True
+        sd._engines = {}
+    np.testing.assert_array_equal(shared, both)

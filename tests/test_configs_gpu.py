@@ -168,3 +168,43 @@ def test_tcd_sampler_fused_loop(gpu, nets, jit):
     np.random.seed(78)
     other = sd.generate_image(ctx[0], **kw)      # a different draw of the per-step noise gives a different sample
     assert O.psnr(other, ref) < 30.0
+
+
+@pytest.mark.parametrize("control", [False, True])
+def test_cfg_prefix_sharing_is_exact(gpu, nets, control):
+    """engine.SHARE_CFG_PREFIX: the unconditional and the conditioned forward of a step get the same latent and time embedding
+    (stable_diffusion.py:454-457) and differ only from the first cross-attention on (diffusion_model.py:88-95), so the fused batch
+    computes conv_in / down_blocks.0.resnets.0 / the front of down_blocks.0.attentions.0 once per image and replicates three tensors.
+    Because a sample's bits do not depend on its batch, the result must be THE SAME BITS as computing both halves - with and without
+    the ControlNet (whose encoder shares the same prefix: conv_in + hint is identical in both halves too), batch 1 and 3."""
+    from minsdtf_amd import engine
+    from minsdtf_amd.stable_diffusion import StableDiffusion
+
+    sd = StableDiffusion(64, 64, jit_compile=True, device=gpu, **(dict(controlnet_path="synthetic") if control else {}))
+    sd._diffusion_model = nets["unet"]
+    if control:
+        sd._control_net, sd._hint_net = nets["cn"], nets["hn"]
+    rng = np.random.default_rng(61)
+    for B in (1, 3):
+        ctx = rng.standard_normal((B, 77, 768)).astype(np.float32)
+        unc = rng.standard_normal((B, 77, 768)).astype(np.float32)
+        noise = rng.standard_normal((B, 8, 8, 4)).astype(np.float32)
+        kw = dict(negative_prompt=unc, batch_size=B, num_steps=3, unconditional_guidance_scale=7.5, diffusion_noise=noise,
+                  guidance_rescale=0.7, return_latent=True)
+        if control:
+            kw["control_net_image"] = rng.integers(0, 256, (64, 64, 3)).astype(np.float32)
+        assert engine.SHARE_CFG_PREFIX
+        eng = sd._engine(B, 77, 77, 3, 7.5, 0.7, control)
+        names = [c.name for c in eng.calls]
+        assert sum(n.endswith(".replicate") for n in names) >= (3 if not control else 6), "the shared prefix is not in the launch list"
+        shared = sd.generate_image(ctx, **kw)
+        try:
+            engine.SHARE_CFG_PREFIX = False
+            sd._engines = {}
+            both = sd.generate_image(ctx, **kw)
+            assert not any(c.name.endswith(".replicate") for c in sd._engine(B, 77, 77, 3, 7.5, 0.7, control).calls)
+        finally:
+            engine.SHARE_CFG_PREFIX = True
+            sd._engines = {}
+        assert np.isfinite(shared).all()
+        np.testing.assert_array_equal(shared, both)

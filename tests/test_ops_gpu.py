@@ -1147,3 +1147,26 @@ def test_argument_errors(gpu):
         args.update(kw)
         with pytest.raises(_lib.HipExtensionError, match=what):
             run_calls(ops.conv_gemm(**args))
+
+
+def test_replicate(gpu):
+    """msd_replicate (ABI 11): `copies` replicas back to back, in place (src == dst: replica 0 stays) or into another buffer; a
+    source that overlaps the replicas in any other way is refused."""
+    from minsdtf_amd import _lib, ops
+
+    torch.manual_seed(5)
+    src = torch.randint(0, 2 ** 15, (3, 8, 8, 320), dtype=torch.int16, device=gpu)
+    nbytes = src.numel() * 2
+    dst = torch.full((3 * 3, 8, 8, 320), -1, dtype=torch.int16, device=gpu)
+    run_calls(ops.replicate(src=src, dst=dst, nbytes=nbytes, copies=3))
+    assert torch.equal(dst, src.repeat(3, 1, 1, 1))
+    wide = torch.full((2 * 3, 8, 8, 320), -1, dtype=torch.int16, device=gpu)
+    wide[:3] = src
+    run_calls(ops.replicate(src=wide, dst=wide, nbytes=nbytes, copies=2))
+    assert torch.equal(wide, src.repeat(2, 1, 1, 1))
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.msd_replicate(wide.data_ptr() + 16, wide.data_ptr(), nbytes, 2, st) == -1    # overlapping, not in place
+    assert lib.msd_replicate(src.data_ptr(), dst.data_ptr(), nbytes + 8, 3, st) == -1       # not whole 16-byte vectors
+    assert lib.msd_replicate(src.data_ptr(), dst.data_ptr(), nbytes, 0, st) == -1
+    torch.cuda.synchronize()
