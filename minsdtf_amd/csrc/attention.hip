@@ -1859,6 +1859,10 @@ static constexpr int attn32_lds_bytes() {
 static bool g_attn_attr_done = false;
 static int g_attn_cus = 256;   // compute units of the device (msd_attention_init)
 static int g_attn_qf = 0;     // 0 = automatic, 1 / 2 = 64 / 128 queries per workgroup forced (A/B runs)
+static int g_attn_qf4_min = 512;   // d = 40, software-pipelined form: 256-query workgroups from this many 128-query workgroups on (round 6: 512, was 256:
+                                   // the ONE-copy self-attention of the shared classifier-free-guidance prefix - 8 batch-heads at S = 4096 - filled half
+                                   // the chip with 256-query workgroups; 128-query ones fill it: batch-1 loop -0.3 %; scheduling only, same bits)
+void msd_set_attn_qf4_min(int v) { g_attn_qf4_min = v; }
 void msd_set_attn_qf(int v) { g_attn_qf = v; }
 static int g_attn_form = 2;   // head sizes 40 and 80: 2 = 32x32x16 MFMA form, software-pipelined for long key walks [default], 1 = 32x32x16 plain loop, 0 = 16x16x32 form like the other head sizes (A/B runs)
 void msd_set_attn_form(int v) { g_attn_form = v; }
@@ -2021,12 +2025,12 @@ extern "C" int msd_attention(const MsdAttention* q, msd_stream_t stream_) {
     // and below at batch 2: 128 / 32 / 8 workgroups).  Measured on one box (us, 128 vs 64 queries per workgroup): S=4096
     // d=40 116 / 125; S=1024 d=80 35 / 28; S=256 d=160 17 / 13; S=4096 T=77 8.8 / 9.8; S=9216 525 / 584.
     // The software-pipelined form at d = 40 takes 256 queries (8 compute waves + 2 loaders: one workgroup per CU is all that
-    // fits beside the loaders' wave slots, so it had better be a big one) once that grid has >= 128 workgroups; at d = 80
+    // fits beside the loaders' wave slots, so it had better be a big one) once that grid has >= 256 workgroups (g_attn_qf4_min); at d = 80
     // (201 registers: 8 wave slots per CU) 64 queries while the grid is small, 128 beyond.
     const long long wgs128 = (long long)((q->s + 127) / 128) * q->heads * q->batch;
     int qf = g_attn_qf ? g_attn_qf : (wgs128 < 384 ? 1 : 2);
     if (attn_swp(a, q->head_dim) && !g_attn_qf) {
-        if (q->head_dim == 40) qf = wgs128 >= 256 ? 4 : (wgs128 >= 128 ? 2 : 1);
+        if (q->head_dim == 40) qf = wgs128 >= g_attn_qf4_min ? 4 : (wgs128 >= 128 ? 2 : 1);
         else qf = wgs128 <= 256 ? 1 : 2;
     }
     if (qf == 4 && !(attn_swp(a, q->head_dim) && q->head_dim == 40)) qf = 2;

@@ -31,6 +31,7 @@ void msd_set_gn_rows(int v);
 void msd_set_gn_xmap(int v);
 void msd_set_gn_poll_limit(int v);
 void msd_set_attn_qf(int v);
+void msd_set_attn_qf4_min(int v);
 void msd_set_xattn_nw(int v);
 int msd_set_xattn160_mode(int v);
 void msd_set_attn_form(int v);
@@ -45,6 +46,11 @@ extern "C" int msd_set_option(const char* key, int value) {
     if (key && strcmp(key, "attn_qf") == 0) {     // 0 = automatic [default], 1 / 2 = 64 / 128 queries per workgroup
         if (value < 0 || value > 4 || value == 3) MSD_FAIL(MSD_E_ARG, "set_option: attn_qf takes 0, 1, 2 or 4");
         msd_set_attn_qf(value);
+        return MSD_OK;
+    }
+    if (key && strcmp(key, "attn_qf4_min") == 0) {   // d = 40 software-pipelined attention: 256-query workgroups from this many 128-query workgroups on (scheduling only: same bits)
+        if (value < 128) MSD_FAIL(MSD_E_ARG, "set_option: attn_qf4_min takes a workgroup count >= 128");
+        msd_set_attn_qf4_min(value);
         return MSD_OK;
     }
     if (key && strcmp(key, "attn_form") == 0) {   // d = 40 / 80: 2 = 32x32x16 MFMAs, software-pipelined on long key walks [default], 1 = 32x32x16 plain, 0 = 16x16x32
