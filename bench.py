@@ -541,6 +541,9 @@ def main(argv=None):
                    # what a job does NOT redo: uploaded / computed when the schedule changes (DenoiseEngine.prepare), i.e. once for the run;
                    # everything else of the hot path (context K/V, the loop, decode, D2H) runs inside every timed job
                    "cached_across_jobs": ["sampler coefficient table", "time-embedding table (25 x timestep MLP + the 22 ResBlock projections)"],
+                   # exact common-subexpression sharing inside a step: the part of the UNet in front of the first cross-attention
+                   # is the same in the unconditional and the conditioned forward and is computed once per image (same bits as computing it twice)
+                   "cfg_prefix_shared": os.environ.get("MSD_SHARE_CFG_PREFIX", "1") != "0",
                    # the one process-wide arithmetic choice read from the environment (minsdtf_amd/_lib.py); None = the default (9216)
                    "gn_rows": os.environ.get("MSD_GN_ROWS")},
         "n_ranks_seen": n_ranks_seen, "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
