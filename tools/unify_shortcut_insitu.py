@@ -90,7 +90,7 @@ def main():
                 log[key] = {"today_us": today / n_calls, "calls": n_calls, "ranked": [[list(c), t / n_calls] for c, t in ranked]}
         finally:
             hook.close()
-            engine.SHORTCUT_FOLD_MAX_PIXELS = int(os.environ.get("MSD_SHORTCUT_FOLD_MAX_PIXELS", "4096"))
+            engine.SHORTCUT_FOLD_MAX_PIXELS = int(os.environ.get("MSD_SHORTCUT_FOLD_MAX_PIXELS", str(1 << 30)))
     with open(args.out, "w") as f:
         json.dump(result, f, indent=0)
     with open(args.out.replace(".json", "_log.json"), "w") as f:
