@@ -28,6 +28,8 @@ received in pass 1.
 """
 from __future__ import annotations
 
+import contextlib
+import io
 import sys
 import types
 
@@ -43,6 +45,9 @@ class _State:
         self.variables = []     # every variable of the model under construction, in build order
         self.served = None      # pass 2: values per variable ordinal (from pass 1)
         self.set_weights_calls = 0
+        self.auto = False       # pipeline mode (enable_pipeline_mode): constructors called without begin() trace on zero inputs
+        self.created = []       # the tensors layers.Input handed out, in creation order
+        self.in_ctor = 0        # depth of wrapped model constructors
 
 
 STATE = _State()
@@ -53,6 +58,7 @@ def begin(inputs, served=None):
     STATE.variables = []
     STATE.served = served
     STATE.set_weights_calls = 0
+    STATE.created = []
 
 
 class Variable:
@@ -124,13 +130,18 @@ class Layer:
 
 
 def Input(shape=None, dtype=None, name=None, **kw):
-    t = STATE.inputs.pop(0)
+    if STATE.auto and STATE.served is None and not STATE.inputs:
+        # pipeline mode, trace pass: the reference constructs its models before any data exists - a batch of one zero input
+        # (an open axis, e.g. the text context's token axis, gets 77)
+        t = torch.zeros((1,) + tuple(77 if d is None else int(d) for d in shape))
+    else:
+        t = STATE.inputs.pop(0)
     want = tuple(shape)
     got = tuple(t.shape[1:])
     assert len(want) == len(got) and all(w is None or int(w) == int(g) for w, g in zip(want, got)), (name, want, got)
-    if dtype is not None and "int" in str(dtype):
-        return t.to(torch.int64)
-    return t.to(F32)
+    t = t.to(torch.int64) if dtype is not None and "int" in str(dtype) else t.to(F32)
+    STATE.created.append(t)
+    return t
 
 
 class Dense(Layer):
@@ -299,15 +310,76 @@ class Model:
     `model.weights`).  The shim finds that set with autograd: every variable is a leaf that requires grad, and the variables the
     outputs do not depend on get no gradient."""
 
+    def __init_subclass__(cls, **kw):
+        # Pipeline mode needs to run a model more than once (predict_on_batch) although the shim executes a model's graph INSIDE
+        # its constructor: every subclass constructor (the reference's DiffusionModel, ImageDecoder, ...) is wrapped to remember
+        # its own arguments and the variables it built, so that predict_on_batch can run that same constructor again on real inputs.
+        super().__init_subclass__(**kw)
+        orig = cls.__dict__.get("__init__")
+        if orig is None:
+            return
+
+        def wrapped(self, *a, **k):
+            top = STATE.in_ctor == 0
+            if top and STATE.auto and STATE.served is None and not STATE.inputs:
+                begin([])
+            if top:
+                self._ctor = (orig, a, k)
+            STATE.in_ctor += 1
+            try:
+                orig(self, *a, **k)
+            finally:
+                STATE.in_ctor -= 1
+            if top:
+                self._vars = list(STATE.variables)
+
+        wrapped.__wrapped__ = orig
+        cls.__init__ = wrapped
+
     def __init__(self, inputs=None, outputs=None, name=None, **kw):
         self.name = name or type(self).__name__.lower()
         outs = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
-        total = sum(o.sum() for o in outs)
-        grads = torch.autograd.grad(total, [v.value for v in STATE.variables], allow_unused=True)
-        for v, g in zip(STATE.variables, grads):
-            v.in_graph = g is not None
+        if STATE.served is None:   # (trace pass: which variables the outputs depend on)
+            total = sum(o.sum() for o in outs)
+            grads = torch.autograd.grad(total, [v.value for v in STATE.variables], allow_unused=True)
+            for v, g in zip(STATE.variables, grads):
+                v.in_graph = g is not None
         det = [o.detach() for o in outs]
         self.outputs = det if isinstance(outputs, (list, tuple)) else det[0]
+        # position of each model input (Model(inputs=[...]) order = predict_on_batch order) among the layers.Input calls
+        ins = list(inputs) if isinstance(inputs, (list, tuple)) else ([inputs] if inputs is not None else [])
+        ids = [id(t) for t in STATE.created]
+        self._input_perm = [ids.index(id(t)) for t in ins] if ins else list(range(len(ids)))
+
+    def compile(self, *a, **k):
+        pass
+
+    def predict_on_batch(self, x):
+        """Run the model's graph - the reference's constructor body - once more, on `x`, with the variables the loader filled."""
+        import inspect
+
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        assert len(xs) == len(self._input_perm), (len(xs), self._input_perm)
+        order = [None] * len(xs)
+        for j, kpos in enumerate(self._input_perm):
+            order[kpos] = xs[j]
+        orig, a, k = self._ctor
+        bound = inspect.signature(orig).bind(self, *a, **k)
+        for name in ("ckpt_path", "controlnet_path"):   # (no file: the constructor skips its loader, the variables are served)
+            if name in inspect.signature(orig).parameters:
+                bound.arguments[name] = "/nonexistent/keras_shim_serves_the_variables"
+        begin(order, served=[v.value.detach() for v in self._vars])
+        clone = object.__new__(type(self))
+        STATE.in_ctor += 1
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                orig(clone, *bound.args[1:], **bound.kwargs)
+        finally:
+            STATE.in_ctor -= 1
+            STATE.served, STATE.inputs = None, []
+        assert STATE.set_weights_calls == 0, "the loader ran during predict_on_batch"
+        out = clone.outputs
+        return [o.numpy() for o in out] if isinstance(out, list) else out.numpy()
 
     @property
     def weights(self):
@@ -379,6 +451,12 @@ def install():
     k.Model, k.Sequential = Model, Sequential
     sys.modules.update(mods)
     return k
+
+
+def enable_pipeline_mode(on=True):
+    """Models may be constructed without begin() (they trace on zero inputs and load their checkpoint) and run with
+    predict_on_batch afterwards - what the reference's StableDiffusion class does with its lazily built model properties."""
+    STATE.auto = bool(on)
 
 
 def run_model(build, inputs):
