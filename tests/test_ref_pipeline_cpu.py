@@ -2,9 +2,9 @@
 
 tests/golden/g12_ref_pipeline.npz holds what minSDTF's own `StableDiffusion.generate_image` (reference stable_diffusion.py:317-486,
 with its scheduler.py, its model properties :672-760, its pre-processing :217-302, its checkpoint loader) produced in the build
-container over tools/keras_shim.py's pipeline mode for six jobs on seeded synthetic checkpoints: text-to-image with guidance +
+container over tools/keras_shim.py's pipeline mode for seven jobs on seeded synthetic checkpoints: text-to-image with guidance +
 rescale (batch 2), plain guidance, no guidance (one UNet call per step), ControlNet (hint picture of another size), image-to-image
-(strength 0.6 of 5 steps) and inpainting (mask blur 3, per-step latent blend, final pixel blend) - the final latent handed to the
+(strength 0.6 of 5 steps), inpainting (mask blur 3, per-step latent blend, final pixel blend) and the TCD sampler (4 stochastic steps) - the final latent handed to the
 decoder, the uint8 picture, and the unconditional context from the CLIP models (tools/make_ref_pipeline_goldens.py).  G1-G10 pin the
 reference's host arithmetic piece by piece and G11 its networks one by one; here the oracle's whole job (networks + denoise_loop +
 decode + cast, with the product's picture / mask pre-processing in front) must land where the reference's whole job landed.
@@ -55,7 +55,7 @@ def test_the_comparison_has_teeth():
     g = _gen()
     gold = np.load(GOLD)
     one = gold["txt2img.latent"][:1]
-    for other in ("txt2img_plain_cfg", "no_cfg", "controlnet", "img2img", "inpaint"):
+    for other in ("txt2img_plain_cfg", "no_cfg", "controlnet", "img2img", "inpaint", "tcd"):
         assert g.rel_rms(gold[other + ".latent"], one) > 1000 * TOL, other
     assert g.rel_rms(gold["inpaint.latent"], gold["img2img.latent"]) > 1000 * TOL
     assert g.rel_rms(gold["txt2img.latent"][1:], one) > 1000 * TOL      # the two samples of the batch are different jobs

@@ -1,7 +1,7 @@
 """The HIP pipeline against the REFERENCE'S OWN PIPELINE, executed end to end (G12, tests/golden/g12_ref_pipeline.npz: minSDTF's
 `StableDiffusion.generate_image` run over tools/keras_shim.py in the build container, see tests/test_ref_pipeline_cpu.py).  The same
-six jobs through minsdtf_amd's `StableDiffusion.generate_image` - the same keyword arguments, the drop-in API - on the same seeded
-weights: unconditional context from the device CLIP models, fused device loop, ControlNet, image-to-image, inpainting, decode and
+seven jobs through minsdtf_amd's `StableDiffusion.generate_image` - the same keyword arguments, the drop-in API - on the same seeded
+weights: unconditional context from the device CLIP models, fused device loop, ControlNet, image-to-image, inpainting, the TCD sampler, decode and
 the fused uint8 cast.  Bar: >= 40 dB PSNR on the final latent (R = max - min of the reference's latent) and on the picture (R = 255)."""
 import os
 import sys
@@ -33,7 +33,10 @@ def g12(gpu):
         setattr(with_cn, k, m)
     for k, m in cnets.items():
         setattr(with_cn, k, m)
-    return g, np.load(os.path.join(ROOT, "tests", "golden", "g12_ref_pipeline.npz")), g.inputs(), plain, with_cn
+    tcd = StableDiffusion(g.IMG, g.IMG, jit_compile=True, device=gpu, active_tcd=True)
+    for k, m in nets.items():
+        setattr(tcd, k, m)
+    return g, np.load(os.path.join(ROOT, "tests", "golden", "g12_ref_pipeline.npz")), g.inputs(), plain, dict(controlnet=with_cn, tcd=tcd)
 
 
 def test_unconditional_context_vs_reference_pipeline(gpu, g12):
@@ -47,17 +50,19 @@ def test_unconditional_context_vs_reference_pipeline(gpu, g12):
     assert p >= PSNR_MIN
 
 
-@pytest.mark.parametrize("name", ["txt2img", "txt2img_plain_cfg", "no_cfg", "controlnet", "img2img", "inpaint"])
+@pytest.mark.parametrize("name", ["txt2img", "txt2img_plain_cfg", "no_cfg", "controlnet", "img2img", "inpaint", "tcd"])
 def test_job_vs_reference_pipeline(gpu, g12, name):
     from oracle import sd_oracle as O
 
-    g, gold, x, plain, with_cn = g12
-    sd = with_cn if name == "controlnet" else plain
+    g, gold, x, plain, special = g12
+    sd = special.get(name, plain)
     ctx, kw = g.case_kwargs(name, x)
+    np.random.seed(g.TCD_NP_SEED)   # (the TCD sampler's per-step noise is numpy's global stream on every side, scheduler.py:301)
     lat = sd.generate_image(ctx, return_latent=True, **kw)
     ref = gold[name + ".latent"]
     assert lat.shape == ref.shape and np.isfinite(lat).all()
     p = O.psnr(lat, ref)
+    np.random.seed(g.TCD_NP_SEED)
     img = sd.generate_image(ctx, **kw)
     rimg = gold[name + ".image"]
     assert img.dtype == np.uint8 and img.shape == rimg.shape
