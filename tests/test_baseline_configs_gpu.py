@@ -143,8 +143,9 @@ def oracle_unet_weights():
 def test_untuned_sizes(gpu, unet512, oracle_unet_weights, height, width):
     """Image sizes the tuning table holds NO row of (legal for the reference: H, W multiples of 64, stable_diffusion.py:588-593):
     every conv / dense launch takes tuning.shape_config() - the halo / staged-halo / wreg / row-panel / big forms chosen from
-    the shape class, not the plain-tile fallback of rounds 1-5.  Parity against the oracle RUN HERE (2 steps, CFG + rescale;
-    the latent after the chain), a sample's bits independent of its batch (fused batches 2 and 6), and no table row used."""
+    the shape class, not the plain-tile fallback of rounds 1-5.  Parity against the oracle RUN HERE (one whole sampler step: uncond + cond
+    forward, CFG + rescale, scheduler step - the oracle's two forwards at this size are 20 s of CPU), a sample's bits independent of
+    its batch over two steps (fused batches 2 and 6), and no table row used."""
     from minsdtf_amd import tuning
     from minsdtf_amd.models import DiffusionModel
     from minsdtf_amd.stable_diffusion import StableDiffusion
@@ -162,14 +163,15 @@ def test_untuned_sizes(gpu, unet512, oracle_unet_weights, height, width):
     unc = rng.standard_normal((B, 77, 768)).astype(np.float32)
     noise = rng.standard_normal((B, h, w, 4)).astype(np.float32)
     kw = dict(num_steps=2, unconditional_guidance_scale=7.5, guidance_rescale=0.7, return_latent=True)
+    first = sd.generate_image(ctx[0], negative_prompt=unc[0], batch_size=1, diffusion_noise=noise[0], **dict(kw, num_steps=1))
+    W = oracle_unet_weights
+    ref = O.denoise_loop(lambda l, t, c, ctl: O.unet_forward(W, l, t, c), ctx[:1], unc[:1], noise[:1], num_steps=1, guidance=7.5,
+                         guidance_rescale=0.7)
+    p = O.psnr(first, ref)
+    print(f"untuned {height}x{width}, one sampler step: latent PSNR {p:.1f} dB vs the oracle")
+    assert p >= PSNR_MIN
     one = sd.generate_image(ctx[0], negative_prompt=unc[0], batch_size=1, diffusion_noise=noise[0], **kw)
     assert one.shape == (1, h, w, 4) and np.isfinite(one).all()
-    W = oracle_unet_weights
-    ref = O.denoise_loop(lambda l, t, c, ctl: O.unet_forward(W, l, t, c), ctx[:1], unc[:1], noise[:1], num_steps=2, guidance=7.5,
-                         guidance_rescale=0.7)
-    p = O.psnr(one, ref)
-    print(f"untuned {height}x{width}, 2 steps: final-latent PSNR {p:.1f} dB vs the oracle")
-    assert p >= PSNR_MIN
     three = sd.generate_image(ctx, negative_prompt=unc, batch_size=B, diffusion_noise=noise, **kw)
     np.testing.assert_array_equal(three[:1], one)
     last = sd.generate_image(ctx[2], negative_prompt=unc[2], batch_size=1, diffusion_noise=noise[2], **kw)
