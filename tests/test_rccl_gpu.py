@@ -58,3 +58,30 @@ def test_bench_through_rccl_with_shared_weights(gpu, tmp_path):
         assert "mapped from rank 0" in p.stderr   # rank 1 did not generate its own weights
     else:
         assert out.get("collectives_forced") is True
+
+
+def test_packed_weights_file_gives_the_same_bits(gpu, tmp_path):
+    """What ranks > 0 of an N-GPU bench do (bench.load_synthetic_shared): adopt the packed weights another process wrote to a
+    RAM-backed file instead of generating and packing their own - on the real networks and the real device here: the mapped
+    UNet and VAE decoder give the bits of the models that generated theirs, through plans with every kernel form (the
+    fragment-major copies the wreg form reads are not in the file: each plan makes its own)."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from minsdtf_amd.models import DiffusionModel, ImageDecoder
+
+    rng = np.random.default_rng(5)
+    x = [rng.standard_normal((2, 8, 8, 4)).astype(np.float32), rng.standard_normal((2, 320)).astype(np.float32),
+         rng.standard_normal((2, 77, 768)).astype(np.float32)]
+    lat = (rng.standard_normal((1, 8, 8, 4)) * 0.5).astype(np.float32)
+    sdir = str(tmp_path)
+    for make, inp in ((lambda: DiffusionModel(64, 64, device=gpu), x), (lambda: ImageDecoder(device=gpu), lat)):
+        r0, r1 = make(), make()
+        assert bench.load_synthetic_shared(r0, 0, sdir, seed=0, bias_scale=0.05) is not None      # rank 0: generates, packs, writes
+        assert bench.load_synthetic_shared(r1, 1, sdir, seed=0, bias_scale=0.05) is None           # rank 1: maps the file
+        a, b = r0.predict_on_batch(inp), r1.predict_on_batch(inp)
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+        with pytest.raises(ValueError):
+            bench.load_synthetic_shared(make(), 1, sdir, seed=1, bias_scale=0.05)                 # another checkpoint's file is refused
