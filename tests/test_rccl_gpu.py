@@ -60,6 +60,7 @@ def test_bench_through_rccl_with_shared_weights(gpu, tmp_path):
         assert out.get("collectives_forced") is True
 
 
+@pytest.mark.gpu
 def test_packed_weights_file_gives_the_same_bits(gpu, tmp_path):
     """What ranks > 0 of an N-GPU bench do (bench.load_synthetic_shared): adopt the packed weights another process wrote to a
     RAM-backed file instead of generating and packing their own - on the real networks and the real device here: the mapped
