@@ -410,8 +410,16 @@ def main(argv=None):
     import torch.distributed as dist
 
     from minsdtf_amd import dist as mdist
+    from minsdtf_amd import host as mhost
 
     rank, local_rank, world = mdist.env_rank()
+    # torch sizes its CPU thread pool by os.cpu_count() (256 on these hosts: 128 threads) although the container's cgroup grants
+    # a fraction of that (16 CPUs per GPU): 8 runnable threads per CPU made the weight packing and the CPU baseline 3-5x slower
+    # than the CPUs allow.  N ranks of one node share the quota.
+    cpu_threads = mhost.fit_torch_threads()
+    if world > 1 and torch.get_num_threads() > max(1, mhost.effective_cpus() // world):
+        torch.set_num_threads(max(1, mhost.effective_cpus() // world))
+        cpu_threads = torch.get_num_threads()
     if world != args.gpus:
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     stub = args.stub_local
@@ -999,7 +1007,7 @@ def cpu_baseline(unet_arrays, vae_arrays, ctx, unc, noise, nsteps):
     return {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 of {nsteps} denoise steps (2 UNet forwards, B=1) = {t_step:.2f}s + 1 VAE decode = {t_dec:.2f}s, "
                       f"extrapolated to {nsteps} steps + decode = {per_image:.1f}s/image; torch fp32 CPU, "
-                      f"os.cpu_count()={os.cpu_count()}"}
+                      f"{torch.get_num_threads()} threads = the CPUs the container is granted (os.cpu_count()={os.cpu_count()})"}
 
 
 if __name__ == "__main__":

@@ -667,3 +667,34 @@ def test_shape_class_reads_the_sample_only():
             cfg = tuning.shape_config(b, h, w, cin, N, ks, st, up, b * ho * wo, nk, split, cx)
             seen.add(tuning.numerics_class(ks, cfg[0], cfg[1], cfg[2], ks == 1 and split and cin == N and not cx, cfg[3]))
         assert len(seen) == 1, ((h, w, cin, N, ks, st, up, split, cx), seen)
+
+
+def test_effective_cpus_respects_affinity_and_quota(tmp_path, monkeypatch):
+    """minsdtf_amd.host.effective_cpus: never more than os.cpu_count() or the affinity mask, and the cgroup quota where one is
+    set; fit_torch_threads only ever lowers torch's thread count."""
+    import builtins
+
+    import torch
+
+    from minsdtf_amd import host
+
+    n = host.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text("300000 100000\n")
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert host.effective_cpus() == min(3, n if n < 3 else 3)
+    before = torch.get_num_threads()
+    try:
+        assert host.fit_torch_threads() == min(before, host.effective_cpus())
+    finally:
+        torch.set_num_threads(before)
