@@ -16,8 +16,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     import argparse
 
+    from minsdtf_amd import host
     from minsdtf_amd.stable_diffusion import StableDiffusion
 
+    host.fit_torch_threads()   # (weight packing on the CPUs the container is granted, not on os.cpu_count() threads)
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1)
