@@ -26,7 +26,7 @@ import sys
 FLOP_PER_CYCLE = 256 * 4 * 1024.0   # dense bf16 MFMA, whole chip
 XCDS = 8                            # rocprofv3 reports the raw GRBM_GUI_ACTIVE summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back);
                                     # MfmaUtil's own formula takes the per-XCD maximum
-CONV = ("conv_gemm_dma", "conv3x3_halo", "dense_rowpanel", "conv_wreg")
+CONV = ("conv_gemm_dma", "conv3x3_halo", "dense_rowpanel", "conv_wreg", "conv_big")   # (conv_big_kernel and conv_bighalo_kernel)
 
 
 def find(d, pat):
