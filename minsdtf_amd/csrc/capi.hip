@@ -25,6 +25,7 @@ extern "C" int msd_init(void) {
 
 void msd_set_gn_impl(int v);
 void msd_set_conv_dense(int v);
+void msd_set_gn_rows_q(int v);
 void msd_set_gn_wide(int v);
 void msd_set_gn_cluster(int v);
 void msd_set_gn_rows(int v);
@@ -39,6 +40,11 @@ void msd_set_attn_d160_pipe(int v);
 /* Tuning / A-B switches (not needed for normal use). Known keys: "gn_impl" (1 = single-launch per-group
  * GroupNorm where the group slab fits in registers [default], 0 = always stats/finalize/apply). */
 extern "C" int msd_set_option(const char* key, int value) {
+    if (key && strcmp(key, "gn_rows_q") == 0) {   // row-major GroupNorm: log2 of the workgroups sharing a part by channels (0 .. 2), -1 = by launch size [default]; placement only
+        if (value < -1 || value > 2) MSD_FAIL(MSD_E_ARG, "set_option: gn_rows_q %d (-1 .. 2)", value);
+        msd_set_gn_rows_q(value);
+        return MSD_OK;
+    }
     if (key && strcmp(key, "conv_dense") == 0) {   // 1 = DENSE loader for 1x1 / Dense layers [default], 0 = general loader
         msd_set_conv_dense(value);
         return MSD_OK;

@@ -524,24 +524,30 @@ __global__ __launch_bounds__(1024) void gn_cluster_kernel(GN_HOT_PARAMS, int psh
 // reduces per-channel moments through LDS, folds them into the 32 groups' moments, publishes 64 tagged granules and collects the other
 // parts' (the exchange of gn_cluster_kernel, 64 values per part instead of 2), then normalises from registers: one read, one write.
 // The parts are summed in part order and P depends on the sample's size only, so a sample's bits do not depend on its batch.
+// Q = 1 << qshift workgroups share a part by CHANNELS (Q quarters / halves of the 8-channel chunks = 32 / Q whole groups each): the same
+// thread -> (pixel row, channel chunk) map, the same per-thread, per-channel and per-group sums in the same order, the same granules at the
+// same places - only who computes which of a part's 64 granules changes, so Q is PLACEMENT (chosen from the launch's size: B x P x Q
+// workgroups should cover the chip), not arithmetic.  A workgroup polls only its own groups' granules of the other parts.
 template <int NPT>
 __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, const bf16_t* hot_x1, int hot_C, int hot_hw, int hot_c0, int hot_c1,
-                                                       int cpr, int rows, uint32_t mg_cpr, int pshift, int ppart, const GNArgs p,
+                                                       int cpr, int rows, uint32_t mg_cpr, int pshift, int ppart, int qshift, const GNArgs p,
                                                        uint32_t* sync_region, int poll_limit) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int t = threadIdx.x, T = cpr * rows;
+    const int t = threadIdx.x, T = cpr * rows;               // cpr: 8-channel chunks per pixel row THIS workgroup owns (C / 8 / Q)
+    const int Cq = cpr * 8, Gq = 32 >> qshift;               // its channels, its groups
     float* red = reinterpret_cast<float*>(smem_raw);         // [T][16]: per thread 8 sums, 8 sums of squares
-    float* chan = red + (size_t)T * 16;                      // [2][C]
-    float* parts = chan + 2 * hot_C;                         // [P][64]
-    float* tot = parts + ((size_t)64 << pshift);             // [64]: 32 sums, 32 sums of squares of the whole sample
-    float* stat = tot + 64;                                  // [32][2] mean, rstd
+    float* chan = red + (size_t)T * 16;                      // [2][Cq]
+    float* parts = chan + 2 * Cq;                            // [P][2 Gq]
+    float* tot = parts + ((size_t)(2 * Gq) << pshift);       // [2 Gq]: sums, sums of squares of the whole sample (this workgroup's groups)
+    float* stat = tot + 64;                                  // [Gq][2] mean, rstd
     uint32_t* s_epoch = reinterpret_cast<uint32_t*>(stat + 64);
     const int P = 1 << pshift;
-    const int part = blockIdx.x & (P - 1), b = blockIdx.x >> pshift;
+    const int qi = blockIdx.x & ((1 << qshift) - 1);
+    const int part = (blockIdx.x >> qshift) & (P - 1), b = blockIdx.x >> (pshift + qshift);
     const int row = udiv_magic(t, cpr, mg_cpr), ch = t - row * cpr;
     const bool active = t < T;
     const int px0 = part * ppart, px1 = min(hot_hw, px0 + ppart);
-    const int c = ch * 8;
+    const int c = qi * Cq + ch * 8;
     const size_t row0 = (size_t)b * hot_hw;
     const bool first = c < hot_c0;
     const int sstride = first ? hot_c0 : hot_c1;
@@ -560,9 +566,9 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
         for (int e = 0; e < 8; ++e) { gm[e] = p.gamma[c + e]; bt[e] = p.beta[c + e]; }
     }
     uint32_t ticket = 0;
-    // (every launch adds exactly 64 to the sample's ticket - 64 / P per workgroup - whatever its P: ticket / 64 + 1 is the same number in the
-    //  P workgroups of a launch and larger than in every earlier launch, of any P, that wrote these granules)
-    if (t == 0) ticket = __hip_atomic_fetch_add(sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS, 64u >> pshift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (every launch adds exactly 64 to the sample's ticket - 64 / (P Q) per workgroup - whatever its P and Q: ticket / 64 + 1 is the same number in
+    //  all workgroups of a launch and larger than in every earlier launch, of any P, that wrote these granules)
+    if (t == 0) ticket = __hip_atomic_fetch_add(sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS, 64u >> (pshift + qshift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (active) {
         float sm[8], sq[8];
 #pragma unroll
@@ -582,8 +588,8 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
     if (t == 0) *s_epoch = (ticket >> 6) + 1u;
     __syncthreads();
     // per-channel moments of the part: channel cc, moment m <- sum over the pixel rows (fixed order)
-    for (int j = t; j < 2 * hot_C; j += 1024) {
-        const int m = j >= hot_C ? 1 : 0, cc = j - m * hot_C;
+    for (int j = t; j < 2 * Cq; j += blockDim.x) {
+        const int m = j >= Cq ? 1 : 0, cc = j - m * Cq;
         const float* q = red + (size_t)(cc >> 3) * 16 + (cc & 7) + 8 * m;
         float a = 0.f;
         for (int r = 0; r < rows; ++r) a += q[(size_t)r * cpr * 16];
@@ -592,25 +598,32 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
     __syncthreads();
     const uint32_t epoch = *s_epoch;
     unsigned long long* gran = reinterpret_cast<unsigned long long*>(sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS + GN_SYNC_WORDS_PER_SLOT);
-    if (t < 64) {   // group moments of the part: published as {value, epoch} granules
-        const int cpg = hot_C >> 5, g = t & 31, m = t >> 5;
-        const float* q = chan + m * hot_C + g * cpg;
+    const int cpg = hot_C >> 5, g0 = qi * Gq;                // this workgroup's groups: g0 .. g0 + Gq - 1
+    if (t < 2 * Gq) {   // group moments of the part: published as {value, epoch} granules (granule g + 32 m of the part's 64, as with Q = 1)
+        const int gl = t & (Gq - 1), m = t >> (5 - qshift);
+        const float* q = chan + m * Cq + gl * cpg;
         float a = 0.f;
         for (int e = 0; e < cpg; ++e) a += q[e];
-        __hip_atomic_store(gran + (size_t)part * 64 + t, ((unsigned long long)epoch << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gran + (size_t)part * 64 + g0 + gl + 32 * m, ((unsigned long long)epoch << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // collect the P x 64 granules of the sample (thread i: granules i, i + 1024, .. - at most 4, polled TOGETHER: a poll is a round trip
-    // to the memory side); bounded, as in gn_cluster_kernel
+    // collect the P x 2 Gq granules of this workgroup's groups (thread i: granules i, i + blockDim, .. - at most 4, polled TOGETHER: a poll is a
+    // round trip to the memory side); bounded, as in gn_cluster_kernel
     {
-        const int ng = 64 << pshift;
+        const int ng = (2 * Gq) << pshift, nt = (int)blockDim.x;
         unsigned long long v[4] = {0, 0, 0, 0};
         bool done[4];
+        const unsigned long long* at[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) done[k] = t + 1024 * k >= ng;
+        for (int k = 0; k < 4; ++k) {
+            const int i = t + nt * k;                           // local granule: part' = i / (2 Gq), then (m, gl)
+            done[k] = i >= ng;
+            const int pp = i >> (6 - qshift), rr = i & (2 * Gq - 1);
+            at[k] = gran + (size_t)(done[k] ? 0 : pp) * 64 + g0 + (rr & (Gq - 1)) + 32 * (rr >> (5 - qshift));
+        }
         for (int it = 0; it < poll_limit; ++it) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (!done[k]) v[k] = __hip_atomic_load(gran + t + 1024 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!done[k]) v[k] = __hip_atomic_load(at[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (!done[k]) done[k] = (uint32_t)(v[k] >> 32) == epoch;
@@ -620,31 +633,31 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
         if (!(done[0] && done[1] && done[2] && done[3])) { sync_region[(size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS + 8] = 1u; sync_region[8] = 1u; }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (t + 1024 * k < ng) parts[t + 1024 * k] = __uint_as_float((uint32_t)v[k]);
+            if (t + nt * k < ng) parts[t + nt * k] = __uint_as_float((uint32_t)v[k]);
     }
     __syncthreads();
-    if (t < 64) {   // the sample's moments: parts in part order, ((p0 + p1) + p2) + ...
+    if (t < 2 * Gq) {   // the sample's moments: parts in part order, ((p0 + p1) + p2) + ...   (t = gl + Gq m, as the parts' rows are laid out)
         float a = 0.f;
-        for (int j = 0; j < P; ++j) a += parts[j * 64 + t];
+        for (int j = 0; j < P; ++j) a += parts[j * 2 * Gq + t];
         tot[t] = a;
     }
     __syncthreads();
-    if (t < 32) {
-        const float cnt = (float)p.hw * (float)(hot_C >> 5);
+    if (t < Gq) {
+        const float cnt = (float)p.hw * (float)cpg;
         const float mean = tot[t] / cnt;
-        const float var = fmaxf(tot[32 + t] / cnt - mean * mean, 0.f);
+        const float var = fmaxf(tot[Gq + t] / cnt - mean * mean, 0.f);
         const float rstd = rsqrtf(var + p.eps);
         stat[2 * t] = mean; stat[2 * t + 1] = rstd;
         if (part == 0) {
-            p.stats[((size_t)b * 32 + t) * 2 + 0] = mean;
-            p.stats[((size_t)b * 32 + t) * 2 + 1] = rstd;
+            p.stats[((size_t)b * 32 + g0 + t) * 2 + 0] = mean;
+            p.stats[((size_t)b * 32 + g0 + t) * 2 + 1] = rstd;
         }
     }
     __syncthreads();
     if (!active) return;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int g = udiv_magic(c + e, hot_C >> 5, p.mg_cpg);
+        const int g = udiv_magic(c + e, cpg, p.mg_cpg) - g0;
         const float mean = stat[2 * g], rstd = stat[2 * g + 1];
         gm[e] *= rstd; bt[e] -= mean * gm[e];
     }
@@ -712,6 +725,8 @@ static int g_gn_rows = 9216;      // row-major parts (gn_rows_kernel) for sample
                                   // 4096 adds the 64x64 level: same-box loop -1.7 % at batch 4, -0.7 % at batch 2, +0.6 % at batch 1 (2 samples
                                   // x 32 parts = 64 workgroups pull 80 KB each: a quarter of the chip's requests in flight) - a serving choice
 void msd_set_gn_rows(int v) { g_gn_rows = v; }
+static int g_gn_rows_q = -1;      // row-major form: log2 of the workgroups that share a part by channels; -1 = from the launch's size (A/B runs; same bits)
+void msd_set_gn_rows_q(int v) { g_gn_rows_q = v; }
 void msd_set_gn_impl(int v) { g_gn_impl = v; }
 void msd_set_gn_wide(int v) { g_gn_wide = v; }
 
@@ -752,7 +767,18 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
             if (q->sync_words < need)
                 MSD_FAIL(MSD_E_WORKSPACE, "group_norm: sync block too small (%lld < %lld words)", (long long)q->sync_words, need);
             if (((uintptr_t)q->sync) & 7u) MSD_FAIL(MSD_E_ALIGN, "group_norm: sync must be 8-byte aligned");
-            const size_t lds = ((size_t)cpr * rows * 16 + 2 * (size_t)C + ((size_t)64 << pshift) + 64 + 64 + 4) * sizeof(float);
+            // Q workgroups per part, by channels (placement only, see the kernel): enough of them that batch x P x Q covers the chip
+            int qshift = 0;
+            if (g_gn_rows_q < 0) {
+                while (qshift < 2 && ((long long)q->batch << (pshift + qshift)) < 256 && (cpr % (2 << qshift)) == 0 && pshift + qshift < 6) ++qshift;
+            } else {
+                while (qshift < g_gn_rows_q && qshift < 2 && (cpr % (2 << qshift)) == 0 && pshift + qshift < 6) ++qshift;
+            }
+            const int cprq = cpr >> qshift;
+            const int ngran = (64 >> qshift) << pshift;   // granules a workgroup collects: at most four per thread
+            int nthreads = (cprq * rows + 63) / 64 * 64;
+            if (nthreads * 4 < ngran) nthreads = ((ngran + 3) / 4 + 63) / 64 * 64;
+            const size_t lds = ((size_t)cprq * rows * 16 + 2 * (size_t)cprq * 8 + ((size_t)(64 >> qshift) << pshift) + 64 + 64 + 4) * sizeof(float);
             static bool attr_done = false;
             if (!attr_done) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -761,9 +787,9 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
                 if (e != hipSuccess) MSD_FAIL((int)e, "hipFuncSetAttribute(gn_rows): %s", hipGetErrorString(e));
                 attr_done = true;
             }
-            const dim3 grid((unsigned)q->batch << pshift);
-            const uint32_t mgc = udiv_magic_of(cpr);
-#define GN_ROWS_LAUNCH(N_) hipLaunchKernelGGL((gn_rows_kernel<N_>), grid, dim3(1024), lds, stream, a.x0, a.x1, a.C, a.hw, a.c0, a.c1, cpr, rows, mgc, pshift, ppart, a, q->sync, g_gn_poll_limit)
+            const dim3 grid((unsigned)q->batch << (pshift + qshift));
+            const uint32_t mgc = udiv_magic_of(cprq);
+#define GN_ROWS_LAUNCH(N_) hipLaunchKernelGGL((gn_rows_kernel<N_>), grid, dim3(nthreads), lds, stream, a.x0, a.x1, a.C, a.hw, a.c0, a.c1, cprq, rows, mgc, pshift, ppart, qshift, a, q->sync, g_gn_poll_limit)
             if (npt <= 2) GN_ROWS_LAUNCH(2);
             else if (npt <= 4) GN_ROWS_LAUNCH(4);
             else GN_ROWS_LAUNCH(6);

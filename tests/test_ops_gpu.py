@@ -723,6 +723,16 @@ def test_group_norm_cluster(gpu, case, form):
         plain = torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=d)
         run_calls([launch(plain)])
         assert torch.equal(plain.view(torch.int16), outs[0].view(torch.int16)), "the XCD dealing of the cluster form changed bits"
+        # the row-major form's parts shared by CHANNELS among 1 / 2 / 4 workgroups (norm.hip gn_rows_kernel qshift; default: from the launch's
+        # size): who computes which of a part's granules is placement only
+        for qv in (0, 1, 2):
+            lib.msd_set_option(b"gn_rows_q", qv)
+            split = torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=d)
+            st0 = stats.clone()
+            stats.fill_(float("nan"))
+            run_calls([launch(split)])
+            assert torch.equal(split.view(torch.int16), outs[0].view(torch.int16)), f"gn_rows_q={qv} changed bits"
+            assert torch.equal(stats.view(torch.int32), st0.view(torch.int32)), f"gn_rows_q={qv} changed the statistics"
         # (error words: word 8 of the 96 group slots and of the row-major form's header slot of every sample; behind them lie granules)
         assert int(sync.view(B, -1, 64)[:, :97, 8].max()) == 0, "a workgroup gave up waiting for its group's partial moments"
         rows_ran = int(sync.view(B, -1)[:, 3 * 32 * 64].max()) > 0     # the row-major form's ticket: first word behind the 96 group slots
@@ -733,6 +743,7 @@ def test_group_norm_cluster(gpu, case, form):
         lib.msd_set_option(b"gn_cluster", 256)
         lib.msd_set_option(b"gn_rows", 9216)
         lib.msd_set_option(b"gn_xmap", 1)
+        lib.msd_set_option(b"gn_rows_q", -1)
 
 
 @pytest.mark.parametrize("form", ["groups", "rows"])

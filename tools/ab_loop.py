@@ -91,7 +91,7 @@ def main():
         print(f"{v:40s} median {statistics.median(t):8.3f} ms  min {min(t):8.3f} ms   rounds {[round(x, 3) for x in t]}")
 
 
-DEFAULTS = {"attn_qf4_min": 512, "gn_xmap": 1, "gn_rows": 9216, "attn_qf": 0, "conv_dense": 1, "gn_wide": 1, "gn_impl": 1, "xattn_nw": 0, "gn_cluster": 256, "attn_form": 2, "attn_d160_pipe": 1}
+DEFAULTS = {"gn_rows_q": -1, "attn_qf4_min": 512, "gn_xmap": 1, "gn_rows": 9216, "attn_qf": 0, "conv_dense": 1, "gn_wide": 1, "gn_impl": 1, "xattn_nw": 0, "gn_cluster": 256, "attn_form": 2, "attn_d160_pipe": 1}
 
 if __name__ == "__main__":
     main()
