@@ -566,9 +566,10 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
         for (int e = 0; e < 8; ++e) { gm[e] = p.gamma[c + e]; bt[e] = p.beta[c + e]; }
     }
     uint32_t ticket = 0;
-    // (every launch adds exactly 64 to the sample's ticket - 64 / (P Q) per workgroup - whatever its P and Q: ticket / 64 + 1 is the same number in
-    //  all workgroups of a launch and larger than in every earlier launch, of any P, that wrote these granules)
-    if (t == 0) ticket = __hip_atomic_fetch_add(sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS, 64u >> (pshift + qshift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (every launch adds exactly 256 to the sample's ticket - 256 / (P Q) per workgroup - whatever its P and Q: ticket / 256 + 1 is the same number in
+    //  all workgroups of a launch and differs from every earlier launch's, of any P, that wrote these granules; 2^32 is a multiple of 256, so that
+    //  holds across the counter's wrap too)
+    if (t == 0) ticket = __hip_atomic_fetch_add(sync_region + (size_t)b * GN_SYNC_SAMPLE_WORDS + GN_SYNC_GROUP_WORDS, 256u >> (pshift + qshift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (active) {
         float sm[8], sq[8];
 #pragma unroll
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(1024) void gn_rows_kernel(const bf16_t* hot_x0, con
         rp[0] = make_float4(sm[0], sm[1], sm[2], sm[3]); rp[1] = make_float4(sm[4], sm[5], sm[6], sm[7]);
         rp[2] = make_float4(sq[0], sq[1], sq[2], sq[3]); rp[3] = make_float4(sq[4], sq[5], sq[6], sq[7]);
     }
-    if (t == 0) *s_epoch = (ticket >> 6) + 1u;
+    if (t == 0) *s_epoch = (ticket >> 8) + 1u;
     __syncthreads();
     // per-channel moments of the part: channel cc, moment m <- sum over the pixel rows (fixed order)
     for (int j = t; j < 2 * Cq; j += blockDim.x) {
@@ -770,9 +771,9 @@ extern "C" int msd_group_norm(const MsdGroupNorm* q, msd_stream_t stream_) {
             // Q workgroups per part, by channels (placement only, see the kernel): enough of them that batch x P x Q covers the chip
             int qshift = 0;
             if (g_gn_rows_q < 0) {
-                while (qshift < 2 && ((long long)q->batch << (pshift + qshift)) < 256 && (cpr % (2 << qshift)) == 0 && pshift + qshift < 6) ++qshift;
+                while (qshift < 2 && ((long long)q->batch << (pshift + qshift)) < 256 && (cpr % (2 << qshift)) == 0 && pshift + qshift < 8) ++qshift;
             } else {
-                while (qshift < g_gn_rows_q && qshift < 2 && (cpr % (2 << qshift)) == 0 && pshift + qshift < 6) ++qshift;
+                while (qshift < g_gn_rows_q && qshift < 2 && (cpr % (2 << qshift)) == 0 && pshift + qshift < 8) ++qshift;
             }
             const int cprq = cpr >> qshift;
             const int ngran = (64 >> qshift) << pshift;   // granules a workgroup collects: at most four per thread

@@ -748,7 +748,7 @@ def test_group_norm_cluster(gpu, case, form):
 
 @pytest.mark.parametrize("form", ["groups", "rows"])
 def test_group_norm_cluster_give_up_is_loud(gpu, form):
-    """The cluster GroupNorm's bounded poll (norm.hip gn_cluster_kernel; form "rows": gn_rows_kernel, whose 32 workgroups per sample add 2
+    """The cluster GroupNorm's bounded poll (norm.hip gn_cluster_kernel; form "rows": gn_rows_kernel, whose 128 workgroups per sample add 2
     each to ONE ticket) must never end in a silently wrong image: a ticket
     counter knocked off its multiple-of-P phase makes one workgroup of a group wait for an epoch nobody publishes; it gives
     up (poll bound shortened through set_option so the test takes milliseconds), raises word [8] of the sync block, and the
@@ -772,8 +772,8 @@ def test_group_norm_cluster_give_up_is_loud(gpu, form):
     words = plan._gn_sync_buf.tensor(torch.int32, (B * ops.GN_SYNC_WORDS_PER_SAMPLE,)).view(-1, 64)
     used = torch.nonzero(words[:, 0]).flatten()
     if form == "rows":   # (behind slot 96 lie granules, not counters)
-        assert int(torch.count_nonzero(words[:96, 0])) == 0 and int(words[96, 0]) == 64, "the row-major form did not run (one ticket per sample, 64 per launch)"
-        used, P, knock = [96] * 6, 63, 2                 # 32 workgroups x 2: off by 2, the last ticket of the next launch lands in the next epoch
+        assert int(torch.count_nonzero(words[:96, 0])) == 0 and int(words[96, 0]) == 256, "the row-major form did not run (one ticket per sample, 256 per launch)"
+        used, P, knock = [96] * 6, 255, 2                # 32 parts x 4 channel quarters x 2: off by 2, the last ticket of the next launch lands in the next epoch
     else:
         assert used.numel() == 32, "the cluster form did not run (one ticket counter per group expected)"
         P = int(words[used[5], 0])                           # one launch added exactly P to the counter
