@@ -237,7 +237,8 @@ MSD_API int msd_conv_direct(const MsdConvDirect* p, msd_stream_t stream);
  *             non-zero word as a failed job (minsdtf_amd/engine.py: check_gn_sync raises HipExtensionError).  Never observed
  *             under in-order dispatch.  Without `sync`: statistics + apply launches, no exchange, no flag.
  *             Samples of >= 9216 pixels (msd_set_option "gn_rows"; 4096 pays from batch 2 per GPU) whose parts fit in registers take the
- *             ROW-MAJOR form of the same exchange: 4-64 workgroups per SAMPLE, each owning a contiguous pixel range with all its
+ *             ROW-MAJOR form of the same exchange: 4-64 parts per SAMPLE (each shared by 1 / 2 / 4 workgroups by channels when the launch
+ *             would otherwise leave the chip idle: placement only, msd_set_option "gn_rows_q"), a part = a contiguous pixel range with all its
  *             channels (16-byte accesses), 64 granules per part; it shares the block (second region of every sample's share)
  *             and the give-up word.  (ABI 10: the share grew from 6,144 to 16,384 words for it.)
  *             The per-(sample, group) form deals its workgroups by XCD (an XCD takes the pixel ranges whose rows the conv launches
