@@ -424,6 +424,10 @@ def main(argv=None):
         log(f"note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     stub = args.stub_local
     if args.backend == "nccl":
+        # dmabuf IPC is the only mode this pool's host driver supports for RCCL / cross-process device memory; the HSA runtime reads
+        # the variable when it starts, i.e. at the first call below that touches the device (ranks started by torch.distributed.run
+        # do not pass through launch_ranks, which sets it for its own children)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if torch.cuda.device_count() <= local_rank:
             log(f"[rank {rank}] needs HIP device {local_rank}, {torch.cuda.device_count()} visible")
             sys.exit(2)
