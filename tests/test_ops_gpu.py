@@ -1181,3 +1181,34 @@ def test_replicate(gpu):
     assert lib.msd_replicate(src.data_ptr(), dst.data_ptr(), nbytes + 8, 3, st) == -1       # not whole 16-byte vectors
     assert lib.msd_replicate(src.data_ptr(), dst.data_ptr(), nbytes, 0, st) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("hw,C,sync_on,rows", [(64, 1280, False, 0), (1024, 640, True, 0), (4096, 320, True, 0), (4096, 320, True, 4096), (16384, 128, False, 0)])
+def test_group_norm_of_a_constant_tensor(gpu, hw, C, sync_on, rows):
+    """Zero variance in every group (a constant image, and a tensor constant per channel with a large offset: E[x^2] - E[x]^2 cancels
+    to rounding noise, clamped at 0): (x - mean) * rsqrt(var + eps) must stay finite and the output must be beta (+ swish) to bf16
+    round-off, in every form - one workgroup per group, the cluster, the row-major parts, statistics / apply."""
+    from minsdtf_amd import _lib, ops
+
+    d = gpu
+    lib = _lib.load()
+    lib.msd_set_option(b"gn_rows", rows if rows else 9216)
+    try:
+        B = 2
+        gamma, beta = (torch.randn(C) * 0.2 + 1).to(d), (torch.randn(C) * 0.2).to(d)
+        stats = torch.full((B * 64,), float("nan"), dtype=torch.float32, device=d)
+        partials = torch.full((B * ops.GN_MAX_CHUNKS * 64,), float("nan"), dtype=torch.float32, device=d)
+        sync = torch.zeros(B * ops.GN_SYNC_WORDS_PER_SAMPLE, dtype=torch.int32, device=d) if sync_on else None
+        for value in (0.0, 3.0, -117.0):
+            x = torch.full((B, hw, C), value, dtype=torch.bfloat16, device=d)
+            out = torch.full((B, hw, C), float("nan"), dtype=torch.bfloat16, device=d)
+            run_calls(ops.group_norm(partials=partials, x0=x, gamma=gamma, beta=beta, stats=stats, out=out, batch=B, hw=hw, c0=C, silu=False, sync=sync))
+            assert bool(torch.isfinite(out.float()).all()), value
+            st = stats.view(B, 32, 2)
+            assert float((st[..., 0] - float(x[0, 0, 0])).abs().max()) <= 1e-3 * max(1.0, abs(value))
+            # var in [0, a few ulp of mean^2]: rstd <= rsqrt(eps); the output is beta up to (x - mean) * rstd * gamma, which the clamp keeps tiny
+            assert float(st[..., 1].max()) <= (1e-5) ** -0.5 * 1.0001
+            err = (out.float() - beta.to(torch.bfloat16).float()[None, None, :]).abs().max()
+            assert float(err) <= 0.05, (value, float(err))
+    finally:
+        lib.msd_set_option(b"gn_rows", 9216)
