@@ -1212,3 +1212,29 @@ def test_group_norm_of_a_constant_tensor(gpu, hw, C, sync_on, rows):
             assert float(err) <= 0.05, (value, float(err))
     finally:
         lib.msd_set_option(b"gn_rows", 9216)
+
+
+@pytest.mark.parametrize("d,S,T", [(40, 4096, 4096), (40, 300, 77), (80, 1024, 1024), (160, 256, 256), (160, 64, 77), (64, 77, 77)])
+@pytest.mark.parametrize("presc", [False, True])
+def test_attention_of_zero_queries_is_the_mean_of_v(gpu, d, S, T, presc):
+    """q = 0: every score is 0, the softmax is uniform and the output is the mean of V over the keys, for every query - whatever the
+    keys hold (here: large) and with NaN in V^T's padding columns (>= t: never read).  Pins the denominator (the ones-row / row-sum
+    bookkeeping of every head size's form) apart from the exponentials."""
+    from minsdtf_amd import ops
+
+    torch.manual_seed(29)
+    B, H = 2, 8 if d != 64 else 12
+    C = H * d
+    Tp = (T + 7) // 8 * 8
+    dev = gpu
+    q = torch.zeros(B, S, C, dtype=torch.bfloat16, device=dev)
+    k = (bf(torch.randn(B, T, C)) * 30.0).to(torch.bfloat16).to(dev)
+    v = bf(torch.randn(B, T, C))
+    vt = torch.full((B, C, Tp), float("nan"), dtype=torch.bfloat16, device=dev)
+    vt[:, :, :T] = v.permute(0, 2, 1).to(torch.bfloat16).to(dev)
+    out = torch.full((B, S, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    run_calls(ops.attention(q=q, k=k, vt=vt, out=out, batch=B, heads=H, head_dim=d, s=S, t=T, q_ld=C, k_ld=C, vt_ld=Tp, o_ld=C,
+                            scale=d ** -0.5, q_prescaled=presc))
+    ref = v.mean(dim=1, keepdim=True).expand(B, S, C)
+    # (P = 1 exactly, so the only rounding is the fp32 sum over the keys and the bf16 store)
+    close(out, ref, rtol=1e-2, atol=4e-3, what=f"d={d} S={S} T={T} presc={presc}")
