@@ -291,3 +291,23 @@ def test_cfg_prefix_sharing_is_exact_at_512(gpu, unet512):
         engine.SHARE_CFG_PREFIX = True
         sd._engines = {}
     np.testing.assert_array_equal(shared, both)
+
+
+def test_batch_independence_at_768(gpu, unet512):
+    """C4's shape in a batch: at 96x96 the GroupNorm runs as row-major parts whose channel shares follow the LAUNCH's size (norm.hip
+    gn_rows_kernel qshift: 2 workgroups per part at fused batch 2, one at fused batch 4 and 6) - placement, never arithmetic: a
+    sample's 2-step latent is the same bits alone, as the first of two and as the last of three."""
+    from minsdtf_amd.models import DiffusionModel
+
+    unet = DiffusionModel(768, 768, device=gpu)
+    unet.share_weights(unet512)
+    sd = _pipeline(gpu, 768, unet)
+    ctx, unc, noise = _inputs(3, 96)
+    kw = dict(num_steps=2, unconditional_guidance_scale=7.5, guidance_rescale=0.7, return_latent=True)
+    three = sd.generate_image(ctx, negative_prompt=unc, batch_size=3, diffusion_noise=noise, **kw)
+    assert three.shape == (3, 96, 96, 4) and np.isfinite(three).all()
+    two = sd.generate_image(ctx[:2], negative_prompt=unc[:2], batch_size=2, diffusion_noise=noise[:2], **kw)
+    np.testing.assert_array_equal(two, three[:2])
+    for i in (0, 2):
+        one = sd.generate_image(ctx[i], negative_prompt=unc[i], batch_size=1, diffusion_noise=noise[i], **kw)
+        np.testing.assert_array_equal(one, three[i:i + 1])
